@@ -1,0 +1,198 @@
+"""Generate golden input/output vectors from the REFERENCE PyTorch model.
+
+TEST INFRASTRUCTURE.  Runs only in the build container (needs /root/reference); writes
+small `.npz` fixtures under tests/golden/.  Inputs and weights are procedural
+(`vista_slam_amd.weights`), so fixtures hold only expected outputs + taps.
+
+    python oracle/gen_golden.py            # all cases (full-size ones take minutes on CPU)
+    python oracle/gen_golden.py tiny ops   # subsets
+
+What is recorded follows SURVEY.md section 8(c): full outputs and intermediate taps for the tiny
+config, sub-sampled outputs + norms for the full config, and single-op vectors (RoPE incl.
+position -1, LayerNorm eps 1e-6, erf-GELU, ConvT, bilinear align_corners on odd sizes,
+SVD-orthogonalise incl. det<0).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from vista_slam_amd import weights as W          # noqa: E402
+from oracle.ref_import import load_reference_model   # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.set_grad_enabled(False)
+
+
+def _views(img_a, img_b, H, W_):
+    B = img_a.shape[0]
+    ts = torch.tensor([[H, W_]] * B)
+    return {"main_view": {"img": img_a, "true_shape": ts},
+            "neighbor_views": [{"img": img_b, "true_shape": ts}], "loop_views": []}
+
+
+def run_case(name, cfg, H, W_, B, qk_gain=1.0, taps=False, sub=1, smooth=False, seed=43):
+    t0 = time.time()
+    sd = W.state_dict(cfg, seed=seed, qk_gain=qk_gain)
+    model = load_reference_model(cfg, sd)
+    gen = W.smooth_images if smooth else W.synth_images
+    imgs = gen(2 * B, H, W_, seed=seed, tag=0)
+    img_a = torch.from_numpy(imgs[:B].copy())
+    img_b = torch.from_numpy(imgs[B:].copy())
+    rec = {}
+    handles = []
+    if taps:
+        def tap(key, mod, post=None):
+            store = []
+
+            def hook(_m, _inp, out):
+                o = out[0] if isinstance(out, tuple) else out
+                store.append(o.detach().clone())
+            handles.append(mod.register_forward_hook(hook))
+            rec[key] = (store, post)
+        tap("patch_embed", model.patch_embed)
+        tap("enc_block0", model.enc_blocks[0])
+        tap("dec_block0", model.dec_block[0])
+        dpt = model.downstream_head_pts.dpt
+        for i in (range(4) if taps != "light" else ()):
+            tap(f"dpt_act{i}", dpt.act_postprocess[i])
+            tap(f"dpt_rn{i}", dpt.scratch.layer_rn[i])
+        if taps != "light":
+            for r in (4, 3, 2, 1):
+                tap(f"dpt_path{r}", getattr(dpt.scratch, f"refinenet{r}"))
+            tap("dpt_head0", dpt.head[0])
+            tap("dpt_preact", dpt)
+    out = model(_views(img_a, img_b, H, W_))
+    for h in handles:
+        h.remove()
+    res = {}
+    for side, key in (("main", "main_views"), ("supp", "support_views")):
+        v = out[key][0]
+        pts = v["pts3d_pred"].numpy()
+        conf = v["conf"].numpy()
+        res[f"{side}_pose"] = v["relative_pose"].numpy()
+        res[f"{side}_pose_conf"] = v["relative_pose_conf"].numpy()
+        res[f"{side}_pts3d"] = pts[:, ::sub, ::sub].copy()
+        res[f"{side}_conf"] = conf[:, ::sub, ::sub].copy()
+        res[f"{side}_pts3d_l2"] = np.sqrt((pts.astype(np.float64) ** 2).sum(axis=(1, 2, 3)))
+        res[f"{side}_conf_l2"] = np.sqrt((conf.astype(np.float64) ** 2).sum(axis=(1, 2)))
+    # encoder / decoder taps through the split entry points the SLAM loop uses (slam.py:144,162)
+    ts = torch.tensor([[H, W_]] * B)
+    fa, pa = model._encode_image(img_a, ts, normalize=False)
+    fb, pb = model._encode_image(img_b, ts, normalize=False)
+    d1, d2 = model._decode_stereo(fa, fb, pa, pb)
+    hooks = cfg.hooks
+    tsub = max(1, sub)
+    res["enc_feat_a"] = fa.numpy()[:, ::tsub].copy()
+    res["enc_feat_b"] = fb.numpy()[:, ::tsub].copy()
+    res["enc_feat_a_l2"] = np.sqrt((fa.double().numpy() ** 2).sum(axis=(1, 2)))
+    for hk in hooks[1:]:
+        res[f"dec1_hook{hk - 1}"] = d1[hk - 1].numpy()[:, ::tsub].copy()
+        res[f"dec2_hook{hk - 1}"] = d2[hk - 1].numpy()[:, ::tsub].copy()
+    if taps:
+        res["dec1_in"] = d1[0].numpy()
+        for key, (store, _post) in rec.items():
+            # forward() calls each tapped module several times; keep first two (a-side, b-side order
+            # follows sta_model.py:257-277: enc(main), enc(supp), dec..., head(supp), head(main))
+            for i, t in enumerate(store[:2]):
+                res[f"tap_{key}_{i}"] = t.numpy()
+    meta = dict(H=H, W=W_, B=B, qk_gain=qk_gain, sub=sub, smooth=int(smooth), seed=seed,
+                **{f"cfg_{k}": v for k, v in cfg.as_dict().items() if not isinstance(v, tuple)})
+    res["meta_keys"] = np.array(list(meta.keys()))
+    res["meta_vals"] = np.array([float(v) for v in meta.values()], dtype=np.float64)
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **{k: (v.astype(np.float32) if v.dtype == np.float64 and not k.startswith("meta") and not k.endswith("_l2") else v)
+                                 for k, v in res.items()})
+    print(f"[golden] {name}: {os.path.getsize(path) / 1e6:.2f} MB in {time.time() - t0:.1f}s", flush=True)
+
+
+def gen_ops():
+    """Single-op vectors from the reference's own modules / the torch ops it calls."""
+    sys.path.insert(0, "/root/reference")
+    from oracle.ref_import import _install_xformers_stub
+    _install_xformers_stub()
+    from vista_slam.sta_model.pos_embed.pos_embed import RoPE2D
+    from vista_slam.sta_model.heads.pose_head import PoseHead_small
+    from vista_slam.sta_model.heads.postprocess import postprocess
+    g = torch.Generator().manual_seed(1234)
+    res = {}
+    # RoPE2D (pos_embed.py:169-185), tokens (B,H,N,64), positions incl. the pose-token -1
+    tok = torch.randn(2, 3, 7, 64, generator=g)
+    pos = torch.tensor([[[-1, -1], [0, 0], [0, 1], [3, 2], [13, 31], [23, 0], [5, 17]]] * 2)
+    pos[1, 2] = torch.tensor([7, 7])
+    res["rope_tok"] = tok.numpy()
+    res["rope_pos"] = pos.numpy()
+    res["rope_out"] = RoPE2D(freq=100.0)(tok.clone(), pos).numpy()
+    # LayerNorm eps=1e-6 (sta_model.py:43), exact-erf GELU (sta_blocks.py:60)
+    x = torch.randn(5, 96, generator=g) * 3 + 0.5
+    w = torch.randn(96, generator=g)
+    b = torch.randn(96, generator=g)
+    res["ln_x"], res["ln_w"], res["ln_b"] = x.numpy(), w.numpy(), b.numpy()
+    res["ln_out"] = torch.nn.functional.layer_norm(x, (96,), w, b, eps=1e-6).numpy()
+    gx = torch.linspace(-6, 6, 97)
+    res["gelu_x"], res["gelu_out"] = gx.numpy(), torch.nn.functional.gelu(gx).numpy()
+    # ConvTranspose2d k4 s4 and k2 s2 (dpt_block.py:369-390)
+    for k in (4, 2):
+        xi = torch.randn(1, 6, 3, 5, generator=g)
+        wt = torch.randn(6, 4, k, k, generator=g)
+        bt = torch.randn(4, generator=g)
+        res[f"convt{k}_x"], res[f"convt{k}_w"], res[f"convt{k}_b"] = xi.numpy(), wt.numpy(), bt.numpy()
+        res[f"convt{k}_out"] = torch.nn.functional.conv_transpose2d(xi, wt, bt, stride=k).numpy()
+    # conv 3x3 stride 2 pad 1 on odd and even sizes (dpt_block.py:404-408)
+    for tag, (h, w_) in (("odd", (7, 5)), ("even", (6, 8))):
+        xi = torch.randn(1, 5, h, w_, generator=g)
+        wt = torch.randn(4, 5, 3, 3, generator=g)
+        bt = torch.randn(4, generator=g)
+        res[f"conv3s2_{tag}_x"], res[f"conv3s2_{tag}_w"], res[f"conv3s2_{tag}_b"] = xi.numpy(), wt.numpy(), bt.numpy()
+        res[f"conv3s2_{tag}_out"] = torch.nn.functional.conv2d(xi, wt, bt, stride=2, padding=1).numpy()
+    # bilinear x2, align_corners=True, odd sizes (dpt_block.py:215-216)
+    xi = torch.randn(1, 3, 7, 5, generator=g)
+    res["bilin_x"] = xi.numpy()
+    res["bilin_out"] = torch.nn.functional.interpolate(xi, scale_factor=2, mode="bilinear", align_corners=True).numpy()
+    # SVD orthogonalisation (pose_head.py:38-57) incl. a det<0 input and a near-singular one
+    ph = PoseHead_small(input_dim=16)
+    m = torch.randn(6, 3, 3, generator=g)
+    m[1] = torch.tensor([[1.0, 0, 0], [0, 1, 0], [0, 0, -1]]) + 0.05 * torch.randn(3, 3, generator=g)  # reflection
+    m[2] = torch.eye(3) * torch.tensor([1.0, 1.0, 1e-4])
+    res["svd_in"] = m.numpy()
+    res["svd_out"] = ph.svd_orthogonalize(m.clone()).numpy()
+    # postprocess (postprocess.py:10-62) with modes ('exp',-inf,inf), ('exp',1,inf)
+    o = torch.randn(1, 4, 3, 5, generator=g)
+    o[0, :3, 0, 0] = 0.0   # zero-norm pixel: clip(1e-8) path
+    pp_ = postprocess(o, ("exp", -float("inf"), float("inf")), ("exp", 1, float("inf")))
+    res["post_in"], res["post_pts"], res["post_conf"] = o.numpy(), pp_["pts3d"].numpy(), pp_["conf"].numpy()
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, "ops.npz"), **res)
+    print("[golden] ops done", flush=True)
+
+
+CASES = {
+    "tiny": [
+        dict(name="tiny_32x32_b1", cfg=W.TINY, H=32, W_=32, B=1, taps=True),
+        dict(name="tiny_48x64_b2", cfg=W.TINY, H=48, W_=64, B=2),
+        dict(name="tiny_48x64_b2_sharp", cfg=W.TINY, H=48, W_=64, B=2, qk_gain=4.0, taps="light"),
+        dict(name="tiny_48x80_smooth_sharp", cfg=W.TINY, H=48, W_=80, B=1, qk_gain=4.0, smooth=True),
+    ],
+    "full224": [
+        dict(name="full_224_b1", cfg=W.FULL, H=224, W_=224, B=1, sub=8),
+        dict(name="full_224_b1_sharp", cfg=W.FULL, H=224, W_=224, B=1, sub=8, qk_gain=6.0),
+    ],
+    "full512": [
+        dict(name="full_384x512_b1", cfg=W.FULL, H=384, W_=512, B=1, sub=16),
+    ],
+}
+
+if __name__ == "__main__":
+    sel = sys.argv[1:] or ["ops", "tiny", "full224", "full512"]
+    torch.set_num_threads(os.cpu_count())
+    for s in sel:
+        if s == "ops":
+            gen_ops()
+        else:
+            for c in CASES[s]:
+                run_case(**c)
