@@ -1,0 +1,156 @@
+/*
+ * sta_mi355.h - C ABI of the MI355X-native Symmetric Two-view Association (STA) frontend.
+ *
+ * Drop-in boundary for ONE hot path of ViSTA-SLAM: the STA forward pass.  Every entry point
+ * below replaces a Python method of the reference `SymmetricTwoViewAssociation`
+ * (vista_slam/sta_model/sta_model.py) or its only native sub-boundary (curope):
+ *
+ *   sta_create / sta_load_tensor / sta_finalize_weights
+ *        <- STA() + load_state_dict(ckpt['model'], strict=True) + .to(device).eval()
+ *           (vista_slam/slam.py:95-106).  Tensor names == reference state_dict keys.
+ *   sta_encode        <- _encode_image(image, true_shape, normalize=False)
+ *                        (sta_model.py:163-174, called from slam.py:144)
+ *   sta_decode        <- _decode_stereo(feat1, feat2, pos1, pos2)
+ *                        (sta_model.py:177-244, called from slam.py:162)
+ *   sta_head_pose     <- head_pose_s(tok[:,0,:])        (heads/pose_head.py:109-120, slam.py:165)
+ *   sta_head_pts      <- head_pts(list14, true_shape)   (heads/dpt_head.py:34-66 +
+ *                        heads/postprocess.py:10-62 + utils/misc.py:36-78, slam.py:179-180)
+ *   sta_forward_pair  <- forward({'main_view','neighbor_views':[b],'loop_views':[]})
+ *                        (sta_model.py:247-291)
+ *   sta_rope2d_inplace<- curope.rope_2d(tokens, positions, base, fwd)
+ *                        (pos_embed/curope/curope.cpp:49-65, kernels.cu:84-108)
+ *
+ * Conventions
+ *   - Plain C types only.  All *_dev pointers are device (HBM) pointers owned by the caller
+ *     (the Python shim passes torch-ROCm tensor .data_ptr()).  The library owns only weights
+ *     and an internal workspace; the workspace grows on the first call of a new shape and is
+ *     then reused (no allocation in steady state).
+ *   - All work is enqueued on the caller-supplied hipStream_t (`stream`, passed as void*);
+ *     no host synchronisation inside, so ordering with surrounding torch ops is preserved.
+ *   - Return value: 0 on success, negative on error; sta_last_error() returns a thread-local
+ *     message.  A handle is not thread-safe; one handle per device.
+ *   - Images are NCHW fp32 in [-1,1]; H and W must be multiples of 16 and W >= H
+ *     (landscape incl. square; the portrait transpose of utils/misc.py:60 is not supported).
+ *   - Token tensors are row-major fp32: encoder [B, N, enc_dim], decoder [B, N+1, dec_dim]
+ *     (row 0 of every decoder sequence is the pose token, sta_model.py:206-219).
+ */
+#ifndef STA_MI355_H
+#define STA_MI355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sta_handle sta_handle;
+
+/* Arithmetic policy of every GEMM / attention contraction (fp32 accumulate always).
+ * gfx950 has no TF32/XF32 MFMA (the reference runs TF32: sta_model.py:5). */
+enum {
+    STA_PREC_F16   = 1,  /* fp16 x fp16 -> fp32 MFMA, one product  (10-bit mantissa == TF32 class) */
+    STA_PREC_F16X3 = 3   /* 2-term fp16 split of both operands, 3 products (~21-bit, fp32 class)   */
+};
+
+enum { STA_DTYPE_F32 = 0 };
+
+typedef struct sta_config {
+    int32_t patch_size;     /* 16 */
+    int32_t enc_embed_dim;  /* 1024 */
+    int32_t enc_depth;      /* 24 */
+    int32_t enc_num_heads;  /* 16  (head_dim must be 64) */
+    int32_t dec_embed_dim;  /* 768 */
+    int32_t dec_depth;      /* 12  (> 9, heads/dpt_head.py:102) */
+    int32_t dec_num_heads;  /* 12 */
+    int32_t mlp_ratio;      /* 4 */
+    float   rope_base;      /* 100.0 ('RoPE100', sta_model.py:44) */
+    float   ln_eps;         /* 1e-6  (sta_model.py:43) */
+    int32_t precision;      /* STA_PREC_* */
+} sta_config;
+
+/* Fill `cfg` with the reference constructor defaults (sta_model.py:33-52). */
+void sta_default_config(sta_config* cfg);
+
+int sta_create(const sta_config* cfg, int device, sta_handle** out);
+int sta_destroy(sta_handle* h);
+
+/* Change the arithmetic policy after creation (weights hold both split planes). */
+int sta_set_precision(sta_handle* h, int precision);
+
+/* Number of state_dict entries the handle expects / has received so far. */
+int sta_num_expected_tensors(const sta_handle* h);
+int sta_num_loaded_tensors(const sta_handle* h);
+
+/* Copy one state_dict entry from HOST memory.  `name` is the reference key
+ * (e.g. "enc_blocks.3.attn.qkv.weight"); shape must match exactly; unknown names fail
+ * (strict=True semantics).  Aliased keys (scratch.layerK_rn / scratch.layer_rn.{K-1}) and the
+ * never-executed tensors (enc_norm.*, refinenet4.resConfUnit1.*) are accepted and dropped. */
+int sta_load_tensor(sta_handle* h, const char* name, const void* host_ptr,
+                    const int64_t* shape, int ndim, int dtype);
+
+/* Verify every expected tensor arrived (strict) and build the packed fp16 hi/lo planes. */
+int sta_finalize_weights(sta_handle* h);
+
+/* img_dev [B,3,H,W] -> feat_dev [B, N, enc_dim], N = (H/16)*(W/16); no final norm. */
+int sta_encode(sta_handle* h, const float* img_dev, int B, int H, int W,
+               float* feat_dev, void* stream);
+
+/* feat1/feat2 [B, N, enc_dim] (N = hp*wp tokens, hp x wp patch grid).
+ * out1/out2: arrays of (dec_depth+1) device pointers, each [B, N+1, dec_dim] or NULL to skip
+ * that layer.  Index 0 = decoder input (embed + pose token), index i = output of block i,
+ * last index has dec_norm applied (sta_model.py:241-242). */
+int sta_decode(sta_handle* h, const float* feat1, const float* feat2, int B, int hp, int wp,
+               float* const* out1, float* const* out2, void* stream);
+
+/* tok: B rows of dec_dim floats, consecutive rows `tok_stride` floats apart.
+ * pose [B,16] row-major 4x4, conf [B]. */
+int sta_head_pose(sta_handle* h, const float* tok, int B, int64_t tok_stride,
+                  float* pose, float* conf, void* stream);
+
+/* DPT pointmap head + postprocess.  enc_feat [B,N,enc_dim] (batch stride enc_bstride floats);
+ * hookX point at the FIRST PATCH TOKEN (pose token already skipped) of the decoder outputs
+ * selected by hooks [0, d/2+1, 3d/4+1, d+1] (dpt_head.py:112); batch strides in floats.
+ * pts [B,H,W,3], conf [B,H,W]. */
+int sta_head_pts(sta_handle* h,
+                 const float* enc_feat, int64_t enc_bstride,
+                 const float* hook1, int64_t hook1_bstride,
+                 const float* hook2, int64_t hook2_bstride,
+                 const float* hook3, int64_t hook3_bstride,
+                 int B, int H, int W, float* pts, float* conf, void* stream);
+
+/* Monolithic two-view forward.  Outputs index 0 = main view (img_a), 1 = support (img_b):
+ * pts[k] [B,H,W,3], conf[k] [B,H,W], pose[k] [B,16], pose_conf[k] [B]. */
+int sta_forward_pair(sta_handle* h, const float* img_a, const float* img_b, int B, int H, int W,
+                     float* const pts[2], float* const conf[2],
+                     float* const pose[2], float* const pose_conf[2], void* stream);
+
+/* In-place 2-D RoPE on fp32 tokens (B,N,Hh,D) with element strides (stride of D must be 1,
+ * stride of Hh must be D; same contract as kernels.cu:91-94); pos int64 [B,N,2] contiguous. */
+int sta_rope2d_inplace(float* tokens_dev, int64_t stride_b, int64_t stride_n,
+                       const int64_t* pos_dev, int B, int N, int Hh, int D,
+                       float base, float fwd, void* stream);
+
+/* Algorithmic FLOPs of one pair at H x W for this handle's config (SURVEY.md 8d closed form). */
+double sta_flops_per_pair(const sta_handle* h, int H, int W);
+
+/* Bytes currently held by the internal workspace / by packed weights. */
+int64_t sta_workspace_bytes(const sta_handle* h);
+int64_t sta_weight_bytes(const sta_handle* h);
+
+/* Per-stage device timing (hipEvent) of the most recent sta_forward_pair when enabled:
+ * ms[0]=encode(both views) ms[1]=decode ms[2]=pose heads ms[3]=dpt heads.  Enabling inserts event
+ * records on the stream; reading synchronises on the last event. */
+int sta_enable_stage_timing(sta_handle* h, int on);
+int sta_get_stage_ms(sta_handle* h, float ms[4]);
+
+/* Time `iters` back-to-back launches of the dominant GEMM kernel (M x N x K, this handle's
+ * precision) with hipEvents on `stream`; returns average ms per launch in *ms_out. */
+int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, float* ms_out, void* stream);
+
+const char* sta_last_error(void);
+const char* sta_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STA_MI355_H */

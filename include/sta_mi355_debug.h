@@ -1,0 +1,58 @@
+/*
+ * sta_mi355_debug.h - kernel-level TEST entry points of libsta_mi355.so.
+ *
+ * Each function runs exactly one product kernel (the same template instantiation the product path
+ * launches) on fp32 device tensors so that tests/ can compare it with a plain fp32 reference of the
+ * same op (reference ops cited per function).  Nothing in the product path calls these.
+ * All pointers are device pointers unless noted; return 0 / negative + sta_last_error().
+ */
+#ifndef STA_MI355_DEBUG_H
+#define STA_MI355_DEBUG_H
+#include "sta_mi355.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* nn.Linear (+GELU/ReLU, +residual): out[M,N] = act(A[M,K] W[N,K]^T + bias) (+resid).
+ * act: 0 none, 1 erf-GELU, 2 ReLU.  via_f16 != 0 uses the fp16-plane epilogue (sta_blocks.py:73-79). */
+int sta_debug_gemm(sta_handle* h, const float* A, const float* W, const float* bias, int M, int N, int K,
+                   int act, int via_f16, const float* resid, float* out, void* stream);
+
+/* qkv = Linear(x); RoPE2D(q), RoPE2D(k) (sta_blocks.py:132-138, pos_embed.py:169-185).
+ * x [S*ntok,K], W [3C,K]; q,k out [S,C/64,ntok,64]; v out is the TRANSPOSED buffer
+ * [S*C/64*64, roundup(ntok,64)] exactly as the attention kernel consumes it. */
+int sta_debug_qkv_rope(sta_handle* h, const float* x, const float* W, const float* bias, int S, int ntok, int K, int C,
+                       int wp, int has_pose_tok, float* q, float* k, float* v, void* stream);
+
+/* softmax(q k^T / 8) v, K/V taken from sequence (s+kv_shift)%S (sta_blocks.py:143,201-205).
+ * q [S,heads,nq,64], k,v [S,heads,nk,64] -> out [S,nq,heads*64]. */
+int sta_debug_attention(sta_handle* h, const float* q, const float* k, const float* v, int S, int heads,
+                        int nq, int nk, int kv_shift, float* out, void* stream);
+
+/* nn.Conv2d 3x3 pad 1 stride 1|2 on NHWC data, weights in the reference [Co,Cin,3,3] layout;
+ * optional ReLU on the input, activation on the output, residual add (dpt_block.py:94-142). */
+int sta_debug_conv3x3(sta_handle* h, const float* x, const float* w, const float* bias, int n, int H, int W, int Cin, int Co,
+                      int stride, int relu_in, int act, const float* resid, float* out, void* stream);
+
+/* nn.ConvTranspose2d kernel=stride=k on NHWC data, weights [C,C,k,k] (dpt_block.py:369-390). */
+int sta_debug_convt(sta_handle* h, const float* x, const float* w, const float* bias, int n, int H, int W, int C, int k,
+                    float* out, void* stream);
+
+/* F.interpolate(scale_factor=2, bilinear, align_corners=True), NHWC, cropped to Hc x Wc. */
+int sta_debug_up2(sta_handle* h, const float* x, int n, int H, int W, int C, int Hc, int Wc, float* out, void* stream);
+
+/* nn.LayerNorm(eps) rows; out32 = direct fp32 output, out_planes = value carried by the fp16 planes. */
+int sta_debug_layernorm(sta_handle* h, const float* x, const float* g, const float* b, int M, int C, float eps,
+                        float* out32, float* out_planes, void* stream);
+
+/* head.4 (1x1 128->4) + postprocess (postprocess.py:10-62) on [npix,128] features. */
+int sta_debug_head_final(sta_handle* h, const float* x, const float* w, const float* bias, int64_t npix,
+                         float* pts, float* conf, void* stream);
+
+/* PoseHead_small.svd_orthogonalize (pose_head.py:38-57) of B row-major 3x3 matrices. */
+int sta_debug_svd_orthogonalize(sta_handle* h, const float* m, float* r, int B, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

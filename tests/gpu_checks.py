@@ -1,0 +1,271 @@
+"""GPU parity checks, shared by the pytest suite (tests/test_gpu_*.py) and the diagnostic runner
+(tests/gpu_diag.py).  Every check calls the HIP product kernels through the C ABI and compares
+with a plain fp32 torch/numpy reference of the same op (or with reference-derived goldens) and
+returns {metric_name: error}.  Nothing here runs the product on a CPU fallback: there is none."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from helpers import load_golden, rel_l2, max_rel, rope2d_ref, grid_pos
+from vista_slam_amd import _lib
+from vista_slam_amd import weights as W
+from vista_slam_amd.sta_frontend import STAFrontend, rope2d_inplace
+
+DEV = "cuda:0"
+_models = {}
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def model(cfg_name="tiny", qk_gain=1.0, precision="f16x3"):
+    """Cached frontends (weights are procedural, so (cfg, gain) identifies them)."""
+    key = (cfg_name, qk_gain)
+    if key not in _models:
+        cfg = W.TINY if cfg_name == "tiny" else W.FULL
+        m = STAFrontend(cfg, DEV, precision=precision)
+        m.load_procedural(seed=43, qk_gain=qk_gain)
+        _models[key] = m
+    m = _models[key]
+    m.set_precision(precision)
+    return m
+
+
+def drop_models():
+    _models.clear()
+    torch.cuda.empty_cache()
+
+
+def kernel_handle(precision):
+    m = model("tiny", 1.0, precision)
+    return m, m.lib, m._h
+
+
+# ------------------------------------------------------------------------------------------ kernels
+def check_gemm(precision, M=300, N=200, K=96, act=0, via_f16=0, resid=False, seed=0):
+    m, lib, h = kernel_handle(precision)
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn(M, K, generator=g) * 1.3
+    Wt = torch.randn(N, K, generator=g) * 0.1
+    b = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g) if resid else None
+    ref = A.double() @ Wt.double().T + b.double()
+    if act == 1:
+        ref = torch.nn.functional.gelu(ref)
+    elif act == 2:
+        ref = torch.relu(ref)
+    if resid:
+        ref = ref + R.double()
+    out = torch.empty(M, N, device=DEV)
+    Ad, Wd, bd = A.to(DEV), Wt.to(DEV), b.to(DEV)
+    Rd = R.to(DEV) if resid else None
+    _lib.check(lib.sta_debug_gemm(h, Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), M, N, K, act, via_f16,
+                                  Rd.data_ptr() if resid else None, out.data_ptr(), st()))
+    torch.cuda.synchronize()
+    return {"rel_l2": rel_l2(out.cpu().numpy(), ref.numpy()), "max_rel": max_rel(out.cpu().numpy(), ref.numpy())}
+
+
+def check_qkv_rope(precision, S=2, hp=3, wp=4, pose_tok=1, K=128, Cdim=128, seed=1):
+    m, lib, h = kernel_handle(precision)
+    g = torch.Generator().manual_seed(seed)
+    ntok = hp * wp + pose_tok
+    x = torch.randn(S * ntok, K, generator=g)
+    Wt = torch.randn(3 * Cdim, K, generator=g) * 0.1
+    b = torch.randn(3 * Cdim, generator=g) * 0.1
+    heads = Cdim // 64
+    npad = (ntok + 63) // 64 * 64
+    q = torch.empty(S, heads, ntok, 64, device=DEV)
+    k = torch.empty_like(q)
+    vt = torch.empty(S * heads * 64, npad, device=DEV)
+    _lib.check(lib.sta_debug_qkv_rope(h, x.to(DEV).data_ptr(), Wt.to(DEV).data_ptr(), b.to(DEV).data_ptr(), S, ntok, K, Cdim,
+                                      wp, pose_tok, q.data_ptr(), k.data_ptr(), vt.data_ptr(), st()))
+    torch.cuda.synchronize()
+    y = (x.double() @ Wt.double().T + b.double()).float().reshape(S, ntok, 3, heads, 64).permute(2, 0, 3, 1, 4).numpy()
+    pos = grid_pos(S, hp, wp, pose_tok=bool(pose_tok))
+    qr, kr, vr = rope2d_ref(y[0], pos), rope2d_ref(y[1], pos), y[2]
+    v = vt.cpu().numpy().reshape(S, heads, 64, npad)[..., :ntok].transpose(0, 1, 3, 2)
+    pad = vt.cpu().numpy().reshape(S, heads, 64, npad)[..., ntok:]
+    return {"q": max_rel(q.cpu().numpy(), qr), "k": max_rel(k.cpu().numpy(), kr), "v": max_rel(v, vr),
+            "vpad_abs": float(np.abs(pad).max()) if pad.size else 0.0}
+
+
+def check_attention(precision, S=2, heads=2, nq=197, nk=197, kv_shift=0, sharp=1.0, seed=2):
+    m, lib, h = kernel_handle(precision)
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(S, heads, nq, 64, generator=g) * sharp
+    k = torch.randn(S, heads, nk, 64, generator=g)
+    v = torch.randn(S, heads, nk, 64, generator=g)
+    idx = [(s + kv_shift) % S for s in range(S)]
+    a = (q.double() @ k[idx].double().transpose(-1, -2)) * 0.125
+    ref = (a.softmax(-1) @ v[idx].double()).permute(0, 2, 1, 3).reshape(S, nq, heads * 64)
+    out = torch.empty(S, nq, heads * 64, device=DEV)
+    _lib.check(lib.sta_debug_attention(h, q.to(DEV).data_ptr(), k.to(DEV).data_ptr(), v.to(DEV).data_ptr(), S, heads, nq, nk,
+                                       kv_shift, out.data_ptr(), st()))
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    return {"rel_l2": rel_l2(o, ref.numpy()), "max_rel": max_rel(o, ref.numpy()), "nan": float(np.isnan(o).sum())}
+
+
+def check_conv3(precision, n=2, H=7, W_=5, Cin=32, Co=48, stride=1, relu_in=0, act=0, resid=False, seed=3):
+    m, lib, h = kernel_handle(precision)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, Cin, H, W_, generator=g)
+    w = torch.randn(Co, Cin, 3, 3, generator=g) * 0.1
+    b = torch.randn(Co, generator=g)
+    xin = torch.relu(x) if relu_in else x
+    ref = torch.nn.functional.conv2d(xin.double(), w.double(), b.double(), stride=stride, padding=1)
+    if act == 2:
+        ref = torch.relu(ref)
+    R = torch.randn(ref.shape, generator=g) if resid else None
+    if resid:
+        ref = ref + R.double()
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    out = torch.empty(n, Ho, Wo, Co, device=DEV)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    Rd = R.permute(0, 2, 3, 1).contiguous().to(DEV) if resid else None
+    _lib.check(lib.sta_debug_conv3x3(h, xd.data_ptr(), w.to(DEV).data_ptr(), b.to(DEV).data_ptr(), n, H, W_, Cin, Co, stride,
+                                     relu_in, act, Rd.data_ptr() if resid else None, out.data_ptr(), st()))
+    torch.cuda.synchronize()
+    o = out.cpu().permute(0, 3, 1, 2).numpy()
+    return {"rel_l2": rel_l2(o, ref.numpy()), "max_rel": max_rel(o, ref.numpy())}
+
+
+def check_convt(precision, n=2, H=3, W_=5, Cdim=96, k=4, seed=4):
+    m, lib, h = kernel_handle(precision)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, Cdim, H, W_, generator=g)
+    w = torch.randn(Cdim, Cdim, k, k, generator=g) * 0.1
+    b = torch.randn(Cdim, generator=g)
+    ref = torch.nn.functional.conv_transpose2d(x.double(), w.double(), b.double(), stride=k)
+    out = torch.empty(n, H * k, W_ * k, Cdim, device=DEV)
+    _lib.check(lib.sta_debug_convt(h, x.permute(0, 2, 3, 1).contiguous().to(DEV).data_ptr(), w.to(DEV).data_ptr(),
+                                   b.to(DEV).data_ptr(), n, H, W_, Cdim, k, out.data_ptr(), st()))
+    torch.cuda.synchronize()
+    o = out.cpu().permute(0, 3, 1, 2).numpy()
+    return {"rel_l2": rel_l2(o, ref.numpy()), "max_rel": max_rel(o, ref.numpy())}
+
+
+def check_up2(precision, n=2, H=7, W_=5, Cdim=16, crop=None, seed=5):
+    m, lib, h = kernel_handle(precision)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, Cdim, H, W_, generator=g)
+    ref = torch.nn.functional.interpolate(x.double(), scale_factor=2, mode="bilinear", align_corners=True)
+    Hc, Wc = crop if crop else (2 * H, 2 * W_)
+    ref = ref[:, :, :Hc, :Wc]
+    out = torch.empty(n, Hc, Wc, Cdim, device=DEV)
+    _lib.check(lib.sta_debug_up2(h, x.permute(0, 2, 3, 1).contiguous().to(DEV).data_ptr(), n, H, W_, Cdim, Hc, Wc,
+                                 out.data_ptr(), st()))
+    torch.cuda.synchronize()
+    o = out.cpu().permute(0, 3, 1, 2).numpy()
+    return {"rel_l2": rel_l2(o, ref.numpy()), "max_rel": max_rel(o, ref.numpy())}
+
+
+def check_layernorm(precision, M=37, Cdim=768, seed=6):
+    m, lib, h = kernel_handle(precision)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, Cdim, generator=g) * 3 + 0.7
+    w = torch.randn(Cdim, generator=g)
+    b = torch.randn(Cdim, generator=g)
+    ref = torch.nn.functional.layer_norm(x.double(), (Cdim,), w.double(), b.double(), eps=1e-6).numpy()
+    o32 = torch.empty(M, Cdim, device=DEV)
+    op = torch.empty(M, Cdim, device=DEV)
+    _lib.check(lib.sta_debug_layernorm(h, x.to(DEV).data_ptr(), w.to(DEV).data_ptr(), b.to(DEV).data_ptr(), M, Cdim, 1e-6,
+                                       o32.data_ptr(), op.data_ptr(), st()))
+    torch.cuda.synchronize()
+    return {"f32": max_rel(o32.cpu().numpy(), ref), "planes": max_rel(op.cpu().numpy(), ref)}
+
+
+def check_ops_golden(precision):
+    """Single-op vectors produced by the reference's own modules (tests/golden/ops.npz)."""
+    m, lib, h = kernel_handle(precision)
+    g, _ = load_golden("ops")
+    res = {}
+    # RoPE2D in place (curope drop-in), tokens given as (B,H,N,D) -> kernel layout (B,N,H,D)
+    tok = dev(g["rope_tok"]).permute(0, 2, 1, 3).contiguous()
+    rope2d_inplace(tok, dev(g["rope_pos"]), 100.0, 1.0)
+    res["rope2d"] = max_rel(tok.permute(0, 2, 1, 3).cpu().numpy(), g["rope_out"])
+    # inverse rotation (fwd = -1) restores the input (curope backward, curope2d.py:24-29)
+    rope2d_inplace(tok, dev(g["rope_pos"]), 100.0, -1.0)
+    res["rope2d_roundtrip"] = max_rel(tok.permute(0, 2, 1, 3).cpu().numpy(), g["rope_tok"])
+    # LayerNorm eps 1e-6
+    M, Cd = g["ln_x"].shape
+    o32 = torch.empty(M, Cd, device=DEV); op = torch.empty(M, Cd, device=DEV)
+    _lib.check(lib.sta_debug_layernorm(h, dev(g["ln_x"]).data_ptr(), dev(g["ln_w"]).data_ptr(), dev(g["ln_b"]).data_ptr(),
+                                       M, Cd, 1e-6, o32.data_ptr(), op.data_ptr(), st()))
+    res["layernorm"] = max_rel(o32.cpu().numpy(), g["ln_out"])
+    # SVD orthogonalisation incl. reflection / near-singular inputs
+    B = g["svd_in"].shape[0]
+    r = torch.empty(B, 3, 3, device=DEV)
+    _lib.check(lib.sta_debug_svd_orthogonalize(h, dev(g["svd_in"]).data_ptr(), r.data_ptr(), B, st()))
+    res["svd_orth"] = float(np.abs(r.cpu().numpy() - g["svd_out"]).max())
+    # bilinear x2 align_corners, odd size: channels padded to 8
+    x = g["bilin_x"]
+    xp = np.zeros((1, 8, x.shape[2], x.shape[3]), np.float32); xp[:, :3] = x
+    out = torch.empty(1, 2 * x.shape[2], 2 * x.shape[3], 8, device=DEV)
+    _lib.check(lib.sta_debug_up2(h, dev(xp.transpose(0, 2, 3, 1)).data_ptr(), 1, x.shape[2], x.shape[3], 8,
+                                 2 * x.shape[2], 2 * x.shape[3], out.data_ptr(), st()))
+    res["bilinear"] = max_rel(out.cpu().numpy().transpose(0, 3, 1, 2)[:, :3], g["bilin_out"])
+    # postprocess through head_final: weights = identity on the first 4 channels
+    pin = g["post_in"]                       # [1,4,h,w]
+    npix = pin.shape[2] * pin.shape[3]
+    feat = np.zeros((npix, 128), np.float32); feat[:, :4] = pin[0].reshape(4, npix).T
+    w4 = np.zeros((4, 128), np.float32); w4[np.arange(4), np.arange(4)] = 1.0
+    pts = torch.empty(npix, 3, device=DEV); conf = torch.empty(npix, device=DEV)
+    _lib.check(lib.sta_debug_head_final(h, dev(feat).data_ptr(), dev(w4).data_ptr(), dev(np.zeros(4, np.float32)).data_ptr(),
+                                        npix, pts.data_ptr(), conf.data_ptr(), st()))
+    res["post_pts"] = max_rel(pts.cpu().numpy().reshape(pin.shape[2], pin.shape[3], 3), g["post_pts"][0])
+    res["post_conf"] = max_rel(conf.cpu().numpy().reshape(pin.shape[2], pin.shape[3]), g["post_conf"][0])
+    torch.cuda.synchronize()
+    return res
+
+
+# ------------------------------------------------------------------------------------------ end to end
+def run_golden_case(name, precision, taps=True):
+    """HIP forward on the procedural inputs of a golden case; returns {key: rel-L2 error}."""
+    g, meta = load_golden(name)
+    cfg_name = "tiny" if int(meta["cfg_enc_embed_dim"]) == W.TINY.enc_embed_dim else "full"
+    m = model(cfg_name, float(meta["qk_gain"]), precision)
+    cfg = m.cfg
+    H, W_, B, sub = int(meta["H"]), int(meta["W"]), int(meta["B"]), int(meta["sub"])
+    gen = W.smooth_images if int(meta["smooth"]) else W.synth_images
+    imgs = gen(2 * B, H, W_, seed=int(meta["seed"]), tag=0)
+    a, b = dev(imgs[:B]), dev(imgs[B:])
+    res = {}
+    main, supp = m.forward_pair(a, b)
+    torch.cuda.synchronize()
+    for side, o in (("main", main), ("supp", supp)):
+        pts = o["pts3d_pred"].cpu().numpy(); conf = o["conf"].cpu().numpy()
+        res[f"{side}_pts3d"] = rel_l2(pts[:, ::sub, ::sub], g[f"{side}_pts3d"])
+        res[f"{side}_conf"] = rel_l2(conf[:, ::sub, ::sub], g[f"{side}_conf"])
+        res[f"{side}_pose"] = rel_l2(o["relative_pose"].cpu().numpy(), g[f"{side}_pose"])
+        res[f"{side}_pose_conf"] = rel_l2(o["relative_pose_conf"].cpu().numpy(), g[f"{side}_pose_conf"])
+        res[f"{side}_pts3d_norm"] = abs(float(np.sqrt((pts.astype(np.float64) ** 2).sum(axis=(1, 2, 3)))[0]) / float(g[f"{side}_pts3d_l2"][0]) - 1.0)
+    # split entry points (what slam.py calls): encoder features + decoder hooks
+    ts = torch.tensor([[H, W_]] * B)
+    fa, pa = m._encode_image(a, ts, normalize=False)
+    fb, pb = m._encode_image(b, ts, normalize=False)
+    d1, d2 = m._decode_stereo(fa, fb, pa, pb)
+    torch.cuda.synchronize()
+    tsub = max(1, sub)
+    res["enc_feat_a"] = rel_l2(fa.cpu().numpy()[:, ::tsub], g["enc_feat_a"])
+    res["enc_feat_b"] = rel_l2(fb.cpu().numpy()[:, ::tsub], g["enc_feat_b"])
+    for hk in cfg.hooks[1:]:
+        res[f"dec1_hook{hk - 1}"] = rel_l2(d1[hk - 1].cpu().numpy()[:, ::tsub], g[f"dec1_hook{hk - 1}"])
+        res[f"dec2_hook{hk - 1}"] = rel_l2(d2[hk - 1].cpu().numpy()[:, ::tsub], g[f"dec2_hook{hk - 1}"])
+    # split heads == monolithic forward
+    pose = m.head_pose_s(d1[-1][:, 0, :])
+    hp = m.head_pts([fa] + [t[:, 1:, :] for t in d1], ts)
+    torch.cuda.synchronize()
+    res["split_pose_vs_golden"] = rel_l2(pose["pose"].cpu().numpy(), g["main_pose"])
+    res["split_pts_vs_golden"] = rel_l2(hp["pts3d"].cpu().numpy()[:, ::sub, ::sub], g["main_pts3d"])
+    if taps and "dec1_in" in g:
+        res["dec1_in"] = rel_l2(d1[0].cpu().numpy(), g["dec1_in"])
+        if "tap_enc_block0_0" in g:
+            pass
+    return res

@@ -1,0 +1,82 @@
+"""GPU: each hand-written HIP kernel (called through the C ABI debug entry points) against a plain
+fp32 reference of the same op.  Tolerances: f16x3 (2-term split, the default) must be fp32-class
+(1e-5); f16 (single product == TF32-class mantissa) 2e-3."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f16x3": 2e-5, "f16": 3e-3}
+PRECS = ["f16x3", "f16"]
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gpu_checks
+    return gpu_checks
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("kw", [dict(), dict(resid=True), dict(M=520, N=384, K=1024), dict(act=1, via_f16=1),
+                                dict(act=2, via_f16=1), dict(M=1, N=96, K=32), dict(M=129, N=129, K=64)])
+def test_gemm(G, prec, kw):
+    r = G.check_gemm(prec, **kw)
+    assert r["rel_l2"] < TOL[prec], r
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("kw", [dict(), dict(hp=14, wp=14, pose_tok=0, S=1), dict(hp=3, wp=5, pose_tok=1, S=3)])
+def test_qkv_rope(G, prec, kw):
+    r = G.check_qkv_rope(prec, **kw)
+    assert r["q"] < TOL[prec] and r["k"] < TOL[prec] and r["v"] < TOL[prec], r
+    assert r["vpad_abs"] == 0.0, "V^T padding must stay zero (0 * garbage = NaN otherwise)"
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("kw", [dict(), dict(kv_shift=1), dict(nq=70, nk=130, sharp=6.0),
+                                dict(S=1, heads=1, nq=769, nk=769, sharp=3.0), dict(nq=1, nk=1), dict(nq=64, nk=64),
+                                dict(nq=65, nk=129, sharp=10.0)])
+def test_attention(G, prec, kw):
+    r = G.check_attention(prec, **kw)
+    assert r["nan"] == 0, r
+    assert r["rel_l2"] < TOL[prec], r
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("kw", [dict(), dict(stride=2), dict(stride=2, H=6, W_=8),
+                                dict(relu_in=1, act=2, resid=True, Cin=96, Co=256, H=9, W_=12), dict(H=1, W_=1)])
+def test_conv3x3(G, prec, kw):
+    r = G.check_conv3(prec, **kw)
+    assert r["rel_l2"] < TOL[prec], r
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("kw", [dict(), dict(Cdim=192, k=2)])
+def test_convt(G, prec, kw):
+    r = G.check_convt(prec, **kw)
+    assert r["rel_l2"] < TOL[prec], r
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("kw", [dict(), dict(H=2, W_=3, crop=(3, 5)), dict(H=1, W_=1)])
+def test_up2(G, prec, kw):
+    r = G.check_up2(prec, **kw)
+    assert r["rel_l2"] < TOL[prec], r
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("C", [128, 768, 1024])
+def test_layernorm(G, prec, C):
+    r = G.check_layernorm(prec, Cdim=C)
+    assert r["f32"] < 1e-5, r
+    assert r["planes"] < TOL[prec], r
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_reference_op_goldens(G, prec):
+    """Vectors produced by the reference's own modules (RoPE2D, svd_orthogonalize, postprocess...)."""
+    r = G.check_ops_golden(prec)
+    assert r["rope2d"] < 1e-5 and r["rope2d_roundtrip"] < 1e-5, r
+    assert r["layernorm"] < 1e-5, r
+    assert r["svd_orth"] < 1e-5, r
+    assert r["bilinear"] < TOL[prec], r
+    assert r["post_pts"] < TOL[prec] * 5 and r["post_conf"] < TOL[prec] * 5, r

@@ -1,0 +1,72 @@
+"""GPU: end-to-end parity of the HIP STA forward (through the C ABI / STAFrontend shim) with
+golden vectors generated from the reference PyTorch model (oracle/gen_golden.py).
+
+north_star tolerance: 1e-3 relative (fp32) on pointmaps, confidence and pose.  Every case is run
+in the default precision (f16x3); the single-product fp16 mode is reported against a looser bound."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+KEYS_OUT = ["main_pts3d", "main_conf", "main_pose", "main_pose_conf", "supp_pts3d", "supp_conf", "supp_pose",
+            "supp_pose_conf", "split_pose_vs_golden", "split_pts_vs_golden"]
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gpu_checks
+    yield gpu_checks
+    gpu_checks.drop_models()
+
+
+@pytest.mark.parametrize("case", ["tiny_32x32_b1", "tiny_48x64_b2", "tiny_48x64_b2_sharp", "tiny_48x80_smooth_sharp"])
+def test_tiny_goldens_default_precision(G, case):
+    r = G.run_golden_case(case, "f16x3")
+    bad = {k: v for k, v in r.items() if v > TOL}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("case", ["tiny_32x32_b1", "tiny_48x64_b2_sharp"])
+def test_tiny_goldens_f16(G, case):
+    r = G.run_golden_case(case, "f16")
+    bad = {k: v for k, v in r.items() if v > 2e-2}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("case", ["full_224_b1", "full_384x512_b1"])
+def test_full_goldens_default_precision(G, case):
+    """Full-size model (438 M parameters) at the SLAM resolution and at the benchmark resolution."""
+    r = G.run_golden_case(case, "f16x3")
+    bad = {k: v for k, v in r.items() if v > TOL}
+    assert not bad, bad
+
+
+def test_full_sharp_attention_golden(G):
+    """Peaky-attention weight set: a wrong RoPE/softmax cannot hide under the tolerance."""
+    G.drop_models()
+    r = G.run_golden_case("full_224_b1_sharp", "f16x3")
+    bad = {k: v for k, v in r.items() if v > TOL}
+    assert not bad, bad
+
+
+def test_error_paths(G):
+    """Same failure behaviour as the reference: H,W % 16 (patch_embed.py:20-21), strict state_dict."""
+    import numpy as np
+    import torch
+    from vista_slam_amd import _lib
+    from vista_slam_amd import weights as W
+    from vista_slam_amd.sta_frontend import STAFrontend
+    m = G.model("tiny", 1.0, "f16x3")
+    with pytest.raises(AssertionError):
+        m._encode_image(torch.zeros(1, 3, 30, 32, device="cuda:0"), None, normalize=False)
+    with pytest.raises(AssertionError):
+        m.forward_pair(torch.zeros(1, 3, 64, 32, device="cuda:0"), torch.zeros(1, 3, 64, 32, device="cuda:0"))
+    fresh = STAFrontend(W.TINY, "cuda:0")
+    with pytest.raises(_lib.StaError, match="unexpected key"):
+        fresh._load_one("not.a.key", np.zeros(3, np.float32))
+    with pytest.raises(_lib.StaError, match="size mismatch"):
+        fresh._load_one("dec_norm.weight", np.zeros(7, np.float32))
+    with pytest.raises(_lib.StaError, match="missing key"):
+        fresh.load_state_dict({"dec_norm.weight": np.zeros(128, np.float32)})
+    with pytest.raises(_lib.StaError, match="not finalized"):
+        fresh._encode_image(torch.zeros(1, 3, 32, 32, device="cuda:0"), None, normalize=False)

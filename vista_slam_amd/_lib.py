@@ -1,0 +1,92 @@
+"""ctypes binding of libsta_mi355.so (the C-ABI declared in include/sta_mi355.h).
+
+There is NO fallback: if the HIP library is missing or fails to load, importing the product path
+raises.  (The CPU oracle under oracle/ is test infrastructure and is never imported from here.)
+"""
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libsta_mi355.so")
+
+STA_PREC_F16 = 1
+STA_PREC_F16X3 = 3
+PRECISIONS = {"f16": STA_PREC_F16, "f16x3": STA_PREC_F16X3}
+
+
+class StaConfig(C.Structure):
+    _fields_ = [("patch_size", C.c_int32), ("enc_embed_dim", C.c_int32), ("enc_depth", C.c_int32),
+                ("enc_num_heads", C.c_int32), ("dec_embed_dim", C.c_int32), ("dec_depth", C.c_int32),
+                ("dec_num_heads", C.c_int32), ("mlp_ratio", C.c_int32), ("rope_base", C.c_float),
+                ("ln_eps", C.c_float), ("precision", C.c_int32)]
+
+
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_fp = C.c_void_p   # device float* passed as integer address
+
+# name -> (restype, argtypes); mirrors include/sta_mi355.h and include/sta_mi355_debug.h
+SIGNATURES = {
+    "sta_default_config": (None, [C.POINTER(StaConfig)]),
+    "sta_create": (_i, [C.POINTER(StaConfig), _i, C.POINTER(_vp)]),
+    "sta_destroy": (_i, [_vp]),
+    "sta_set_precision": (_i, [_vp, _i]),
+    "sta_num_expected_tensors": (_i, [_vp]),
+    "sta_num_loaded_tensors": (_i, [_vp]),
+    "sta_load_tensor": (_i, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i, _i]),
+    "sta_finalize_weights": (_i, [_vp]),
+    "sta_encode": (_i, [_vp, _fp, _i, _i, _i, _fp, _vp]),
+    "sta_decode": (_i, [_vp, _fp, _fp, _i, _i, _i, C.POINTER(_vp), C.POINTER(_vp), _vp]),
+    "sta_head_pose": (_i, [_vp, _fp, _i, _i64, _fp, _fp, _vp]),
+    "sta_head_pts": (_i, [_vp, _fp, _i64, _fp, _i64, _fp, _i64, _fp, _i64, _i, _i, _i, _fp, _fp, _vp]),
+    "sta_forward_pair": (_i, [_vp, _fp, _fp, _i, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
+                              C.POINTER(_vp), _vp]),
+    "sta_rope2d_inplace": (_i, [_fp, _i64, _i64, _vp, _i, _i, _i, _i, _f, _f, _vp]),
+    "sta_flops_per_pair": (C.c_double, [_vp, _i, _i]),
+    "sta_workspace_bytes": (_i64, [_vp]),
+    "sta_weight_bytes": (_i64, [_vp]),
+    "sta_enable_stage_timing": (_i, [_vp, _i]),
+    "sta_get_stage_ms": (_i, [_vp, C.POINTER(_f)]),
+    "sta_bench_gemm": (_i, [_vp, _i, _i, _i, _i, C.POINTER(_f), _vp]),
+    "sta_last_error": (C.c_char_p, []),
+    "sta_version": (C.c_char_p, []),
+    # ---- debug / kernel-level test entry points
+    "sta_debug_gemm": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _vp]),
+    "sta_debug_qkv_rope": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _vp]),
+    "sta_debug_attention": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _vp]),
+    "sta_debug_conv3x3": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _fp, _fp, _vp]),
+    "sta_debug_convt": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _vp]),
+    "sta_debug_up2": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _i, _fp, _vp]),
+    "sta_debug_layernorm": (_i, [_vp, _fp, _fp, _fp, _i, _i, _f, _fp, _fp, _vp]),
+    "sta_debug_head_final": (_i, [_vp, _fp, _fp, _fp, _i64, _fp, _fp, _vp]),
+    "sta_debug_svd_orthogonalize": (_i, [_vp, _fp, _fp, _i, _vp]),
+}
+
+_lib = None
+
+
+class StaError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libsta_mi355.so and bind every exported symbol; raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise StaError(
+            f"{LIB_PATH} not found: the MI355X STA frontend has no CPU fallback. "
+            "Build it with `python -m vista_slam_amd.build` (needs hipcc) or `__graft_entry__.build()`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().sta_last_error()
+        raise StaError((msg or b"unknown error").decode())

@@ -1,0 +1,48 @@
+"""Build the gfx950 C-ABI library in-tree with hipcc (no torch, no cmake).
+
+    python -m vista_slam_amd.build          # -> vista_slam_amd/libsta_mi355.so
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libsta_mi355.so")
+SOURCES = ["sta_api.hip"]
+DEPS = ["sta_api.hip", "sta_debug.inc", "gemm.h", "attention.h", "elementwise.h", "sta_common.h",
+        os.path.join("..", "..", "include", "sta_mi355.h"), os.path.join("..", "..", "include", "sta_mi355_debug.h")]
+
+
+def hipcc_path():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+
+
+def build_lib(force=False, verbose=True):
+    if not force and not is_stale():
+        return LIB
+    hipcc = hipcc_path()
+    if hipcc is None:
+        raise RuntimeError("hipcc not found: cannot build libsta_mi355.so (ROCm toolchain required)")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_lib(force="--force" in sys.argv)
+    print(LIB)

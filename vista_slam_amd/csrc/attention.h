@@ -1,0 +1,236 @@
+// Flash-style fused attention for gfx950, head_dim 64, fp16 MFMA / fp32 softmax.
+//
+// Replaces xformers memory_efficient_attention (sta_blocks.py:143) and the naive
+// softmax(QK^T*scale)V of CrossAttention (sta_blocks.py:201-205) - the N'xN' score matrix is
+// never materialised.
+//
+// Layout (written by the QKV GEMM epilogue): Q,K [S, heads, npad, 64] fp16 planes (RoPE already
+// applied), V^T [S, heads, 64, npad] fp16 planes.  Output O planes [S*nq, ldo], col = head*64+d.
+//
+// One block = 4 waves = 128 query rows of one (sequence, head); each wave owns 32 queries.
+// The score tile is computed TRANSPOSED (S^T = K Q^T, O^T = V^T P^T) so that every lane owns one
+// query column: row max / row sum are in-lane reductions plus one lane^32 exchange, the online
+// softmax rescale is a per-lane scalar, and the P^T B-operand of the second MFMA is built from the
+// accumulator registers without any cross-lane traffic (the key permutation implied by the
+// accumulator layout is applied to the V^T A-operand instead: two ds_read_b64 per fragment).
+// K/V tiles (64 keys) are double-buffered in LDS with XOR-swizzled chunks.
+// Cross attention = same kernel with kv_shift selecting the other view's K/V.
+#pragma once
+#include "sta_common.h"
+
+struct AttnParams {
+    const f16* Q_hi; const f16* Q_lo; const f16* K_hi; const f16* K_lo; const f16* Vt_hi; const f16* Vt_lo;
+    f16* O_hi; f16* O_lo; int ldo;
+    int S, heads, nq, nk, npad;
+    int kv_shift;            // K/V come from sequence (s + kv_shift) % S
+    float scale_log2e;       // head_dim^-0.5 * log2(e)
+};
+
+#define ATT_KV 64
+#define ATT_TILE_BYTES (64 * 128)   // 64 rows x 64 fp16
+
+template <bool SPLIT>
+constexpr int attn_smem_bytes() { return 2 * (SPLIT ? 4 : 2) * ATT_TILE_BYTES; }
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NPL = SPLIT ? 2 : 1;
+    constexpr int STAGE = 2 * NPL * ATT_TILE_BYTES;   // K planes then V^T planes
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int s = blockIdx.z, h = blockIdx.y;
+    const int skv = (s + p.kv_shift) % p.S;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+
+    const size_t qoff = (size_t)(s * p.heads + h) * p.npad * 64;
+    const size_t koff = (size_t)(skv * p.heads + h) * p.npad * 64;
+    const size_t voff = (size_t)(skv * p.heads + h) * 64 * p.npad;
+
+    // ---- Q fragments (B operand: col = query, 8 consecutive d per lane-half per k-step)
+    half8 qf_hi[4], qf_lo[4];
+    {
+        int qrow = q0 + l31; if (qrow > p.nq - 1) qrow = p.nq - 1;
+        const f16* qp = p.Q_hi + qoff + (size_t)qrow * 64 + lhi * 8;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { H8 t; t.u = ldg16(qp + kk * 16); qf_hi[kk] = t.h; }
+        if (SPLIT) {
+            const f16* ql = p.Q_lo + qoff + (size_t)qrow * 64 + lhi * 8;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) { H8 t; t.u = ldg16(ql + kk * 16); qf_lo[kk] = t.h; }
+        }
+    }
+
+    // ---- staging assignment: 2 x 16 B chunks of K and of V^T per plane per tile
+    int st_row[2], st_ch[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { int c = tid + 256 * i; st_row[i] = c >> 3; st_ch[i] = c & 7; }
+    uint4 rk_hi[2], rk_lo[2], rv_hi[2], rv_lo[2];
+    auto load_tile = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            size_t ko = koff + (size_t)(kv0 + st_row[i]) * 64 + st_ch[i] * 8;
+            size_t vo = voff + (size_t)st_row[i] * p.npad + kv0 + st_ch[i] * 8;
+            rk_hi[i] = ldg16(p.K_hi + ko);
+            rv_hi[i] = ldg16(p.Vt_hi + vo);
+            if (SPLIT) { rk_lo[i] = ldg16(p.K_lo + ko); rv_lo[i] = ldg16(p.Vt_lo + vo); }
+        }
+    };
+    auto store_tile = [&](int stage) {
+        char* sK = smem + stage * STAGE;
+        char* sV = sK + NPL * ATT_TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int r = st_row[i], ch = st_ch[i];
+            int ko = r * 128 + ((ch ^ ((r >> 1) & 7)) << 4);
+            *reinterpret_cast<uint4*>(sK + ko) = rk_hi[i];
+            if (SPLIT) *reinterpret_cast<uint4*>(sK + ATT_TILE_BYTES + ko) = rk_lo[i];
+            int sw = (r >> 1) & 15;
+            int v0 = r * 128 + (((2 * ch) ^ sw) << 3);
+            int v1 = r * 128 + (((2 * ch + 1) ^ sw) << 3);
+            *reinterpret_cast<uint2*>(sV + v0) = make_uint2(rv_hi[i].x, rv_hi[i].y);
+            *reinterpret_cast<uint2*>(sV + v1) = make_uint2(rv_hi[i].z, rv_hi[i].w);
+            if (SPLIT) {
+                *reinterpret_cast<uint2*>(sV + ATT_TILE_BYTES + v0) = make_uint2(rv_lo[i].x, rv_lo[i].y);
+                *reinterpret_cast<uint2*>(sV + ATT_TILE_BYTES + v1) = make_uint2(rv_lo[i].z, rv_lo[i].w);
+            }
+        }
+    };
+
+    floatx16 oacc[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (p.nk + ATT_KV - 1) / ATT_KV;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int it = 0; it < ntiles; ++it) {
+        const int cur = it & 1;
+        const int kv0 = it * ATT_KV;
+        if (it + 1 < ntiles) load_tile(kv0 + ATT_KV);
+        const char* sK = smem + cur * STAGE;
+        const char* sV = sK + NPL * ATT_TILE_BYTES;
+
+        // ---- S^T = K Q^T  (rows = keys, cols = queries)
+        floatx16 sacc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[t][r] = 0.f;
+            const int key = t * 32 + l31;
+            const int ksw = (key >> 1) & 7;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                int off = key * 128 + (((kk * 2 + lhi) ^ ksw) << 4);
+                half8 kf = *reinterpret_cast<const half8*>(sK + off);
+                if (SPLIT) {
+                    half8 kl = *reinterpret_cast<const half8*>(sK + ATT_TILE_BYTES + off);
+                    sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qf_hi[kk], sacc[t], 0, 0, 0);
+                    sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf_lo[kk], sacc[t], 0, 0, 0);
+                }
+                sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf_hi[kk], sacc[t], 0, 0, 0);
+            }
+        }
+
+        // ---- online softmax (per lane = one query; this lane holds 32 of the tile's 64 keys)
+        const bool tail = kv0 + ATT_KV > p.nk;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sv = sacc[t][r] * p.scale_log2e;
+                if (tail) {
+                    int key = kv0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    if (key >= p.nk) sv = -INFINITY;
+                }
+                sacc[t][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pv = exp2f(sacc[t][r] - m_new);
+                sacc[t][r] = pv;
+                psum += pv;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+
+        // ---- O^T += V^T P^T   (k index of the MFMA = 8*lhi + j  <->  key t*32 + 16w + 8(j>>2) + 4lhi + (j&3))
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                half8 pb_hi, pb_lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float pv = sacc[t][8 * w + j];
+                    f16 ph = (f16)pv;
+                    pb_hi[j] = ph;
+                    if (SPLIT) pb_lo[j] = (f16)(pv - (float)ph);
+                }
+                const int c0 = t * 8 + w * 4 + lhi;
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const int drow = d * 32 + l31;
+                    const int sw = (drow >> 1) & 15;
+                    const int o0 = drow * 128 + ((c0 ^ sw) << 3);
+                    const int o1 = drow * 128 + (((c0 + 2) ^ sw) << 3);
+                    H8 vf;
+                    uint2 a = *reinterpret_cast<const uint2*>(sV + o0);
+                    uint2 b = *reinterpret_cast<const uint2*>(sV + o1);
+                    vf.u = make_uint4(a.x, a.y, b.x, b.y);
+                    if (SPLIT) {
+                        H8 vl;
+                        uint2 al = *reinterpret_cast<const uint2*>(sV + ATT_TILE_BYTES + o0);
+                        uint2 bl = *reinterpret_cast<const uint2*>(sV + ATT_TILE_BYTES + o1);
+                        vl.u = make_uint4(al.x, al.y, bl.x, bl.y);
+                        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl.h, pb_hi, oacc[d], 0, 0, 0);
+                        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf.h, pb_lo, oacc[d], 0, 0, 0);
+                    }
+                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf.h, pb_hi, oacc[d], 0, 0, 0);
+                }
+            }
+
+        if (it + 1 < ntiles) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane owns query q, d = dt*32 + (r&3) + 8*(r>>2) + 4*lhi
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + l31;
+    if (q < p.nq) {
+        const size_t ob = (size_t)(s * p.nq + q) * p.ldo + h * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                H4 oh, ol;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = oacc[d][g * 4 + e] * inv;
+                    if (SPLIT) split_f16(v, oh.e[e], ol.e[e]); else oh.e[e] = to_f16_sat(v);
+                }
+                const int dcol = d * 32 + 8 * g + 4 * lhi;
+                *reinterpret_cast<uint2*>(p.O_hi + ob + dcol) = oh.u;
+                if (SPLIT) *reinterpret_cast<uint2*>(p.O_lo + ob + dcol) = ol.u;
+            }
+    }
+}

@@ -1,0 +1,394 @@
+// HBM-bound helper kernels of the STA path (gfx950): LayerNorm -> fp16 planes, patch gather,
+// token/plane conversion, bilinear x2 (align_corners), final 1x1 conv + pointmap postprocess,
+// pose head (MLP + 3x3 polar rotation), curope-compatible in-place RoPE, weight repacking.
+// All reductions are wave64 shuffles; all loads/stores are 8-16 B per lane.
+#pragma once
+#include "sta_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm (eps inside sqrt, affine) over fp32 rows -> fp16 hi/lo planes; up to two affine sets
+// from one read of x (decoder norm1 + norm_y share their input: sta_blocks.py:226-229).
+// One wave per row, C <= 1024, C % 4 == 0.
+struct LnParams {
+    const float* x; int ldx; int M; int C; float eps;
+    const float* g1; const float* b1; f16* o1_hi; f16* o1_lo;
+    const float* g2; const float* b2; f16* o2_hi; f16* o2_lo;   // optional (g2 == nullptr)
+    float* o32; int ldo32;                                       // optional fp32 output with set 1
+};
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const float* xr = p.x + (size_t)row * p.ldx;
+    float4 v[4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int idx = (i * 64 + lane) * 4;
+        if (idx < p.C) {
+            v[i] = *reinterpret_cast<const float4*>(xr + idx);
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mean = wave_sum(sum) / (float)p.C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int idx = (i * 64 + lane) * 4;
+        if (idx < p.C) {
+            float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            sq += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)p.C + p.eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int idx = (i * 64 + lane) * 4;
+        if (idx < p.C) {
+            float n[4] = {(v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd};
+            {
+                float4 g = *reinterpret_cast<const float4*>(p.g1 + idx);
+                float4 b = *reinterpret_cast<const float4*>(p.b1 + idx);
+                float y[4] = {n[0] * g.x + b.x, n[1] * g.y + b.y, n[2] * g.z + b.z, n[3] * g.w + b.w};
+                if (p.o32) *reinterpret_cast<float4*>(p.o32 + (size_t)row * p.ldo32 + idx) = make_float4(y[0], y[1], y[2], y[3]);
+                if (p.o1_hi) {
+                    H4 h, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e]); else h.e[e] = to_f16_sat(y[e]); }
+                    *reinterpret_cast<uint2*>(p.o1_hi + (size_t)row * p.C + idx) = h.u;
+                    if (SPLIT) *reinterpret_cast<uint2*>(p.o1_lo + (size_t)row * p.C + idx) = l.u;
+                }
+            }
+            if (p.g2) {
+                float4 g = *reinterpret_cast<const float4*>(p.g2 + idx);
+                float4 b = *reinterpret_cast<const float4*>(p.b2 + idx);
+                float y[4] = {n[0] * g.x + b.x, n[1] * g.y + b.y, n[2] * g.z + b.z, n[3] * g.w + b.w};
+                H4 h, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e]); else h.e[e] = to_f16_sat(y[e]); }
+                *reinterpret_cast<uint2*>(p.o2_hi + (size_t)row * p.C + idx) = h.u;
+                if (SPLIT) *reinterpret_cast<uint2*>(p.o2_lo + (size_t)row * p.C + idx) = l.u;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 rows [nb, rows, C] (batch stride bstride floats) -> contiguous fp16 planes [nb*rows, C].
+template <bool SPLIT>
+__global__ void rows_to_planes_kernel(const float* x, int64_t bstride, int rows, int C, int64_t total4,
+                                      f16* o_hi, f16* o_lo, int64_t obstride /* output batch stride in rows; 0 = rows */) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    const int c4 = C / 4;
+    for (; i < total4; i += step) {
+        int64_t r = i / c4; int c = (int)(i - r * c4) * 4;
+        int64_t b = r / rows; int rr = (int)(r - b * rows);
+        float4 v = *reinterpret_cast<const float4*>(x + b * bstride + (int64_t)rr * C + c);
+        float y[4] = {v.x, v.y, v.z, v.w};
+        H4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e]); else h.e[e] = to_f16_sat(y[e]); }
+        const int64_t orow = obstride ? b * obstride + rr : r;
+        *reinterpret_cast<uint2*>(o_hi + orow * C + c) = h.u;
+        if (SPLIT) *reinterpret_cast<uint2*>(o_lo + orow * C + c) = l.u;
+    }
+}
+
+// planes [nb, rows(+pad), C] -> fp32 [nb, rows, C]  (test/debug taps only)
+__global__ void planes_to_f32_kernel(const f16* hi, const f16* lo, int64_t ibstride_rows, int rows, int C,
+                                     int64_t total, float* out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += step) {
+        int64_t r = i / C; int c = (int)(i - r * C);
+        int64_t b = r / rows; int rr = (int)(r - b * rows);
+        int64_t src = ((ibstride_rows ? b * ibstride_rows + rr : r)) * C + c;
+        float v = (float)hi[src]; if (lo) v += (float)lo[src];
+        out[i] = v;
+    }
+}
+
+// fp32 V [nb, rows, 64] -> transposed planes Vt [nb, 64, npad]  (test/debug only)
+__global__ void pack_vt_kernel(const float* v, int nb, int rows, int npad, f16* hi, f16* lo) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)nb * rows * 64;
+    if (i >= total) return;
+    int d = (int)(i % 64); int64_t t = i / 64; int r = (int)(t % rows); int64_t b = t / rows;
+    f16 h, l; split_f16(v[i], h, l);
+    int64_t o = (b * 64 + d) * npad + r;
+    hi[o] = h; if (lo) lo[o] = l;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Patch gather for the 16x16/16 patch-embed conv == GEMM (patch_embed.py:17-27):
+// img NCHW fp32 [n,3,H,W] -> planes [n*hp*wp, 768], K order (c, ky, kx) == conv weight flatten.
+// One thread = one (token, c, ky) row of 16 pixels (64 B in, 32 B out per plane).
+template <bool SPLIT>
+__global__ void patch_gather_kernel(const float* img, int n, int H, int W, f16* o_hi, f16* o_lo) {
+    const int hp = H / 16, wp = W / 16;
+    const int64_t total = (int64_t)n * hp * wp * 48;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += step) {
+        int ck = (int)(i % 48); int64_t tok = i / 48;
+        int c = ck / 16, ky = ck % 16;
+        int px = (int)(tok % wp); int64_t t2 = tok / wp; int py = (int)(t2 % hp); int b = (int)(t2 / hp);
+        const float* src = img + (((int64_t)b * 3 + c) * H + py * 16 + ky) * W + px * 16;
+        H8 h0, h1, l0, l1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 v = *reinterpret_cast<const float4*>(src + q * 4);
+            float y[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f16 hh, ll;
+                if (SPLIT) split_f16(y[e], hh, ll); else { hh = to_f16_sat(y[e]); ll = (f16)0; }
+                int k = q * 4 + e;
+                if (k < 8) { h0.e[k] = hh; l0.e[k] = ll; } else { h1.e[k - 8] = hh; l1.e[k - 8] = ll; }
+            }
+        }
+        size_t o = (size_t)tok * 768 + ck * 16;
+        *reinterpret_cast<uint4*>(o_hi + o) = h0.u; *reinterpret_cast<uint4*>(o_hi + o + 8) = h1.u;
+        if (SPLIT) { *reinterpret_cast<uint4*>(o_lo + o) = l0.u; *reinterpret_cast<uint4*>(o_lo + o + 8) = l1.u; }
+    }
+}
+
+// x[s, 0, :] = token  (pose token prepend, sta_model.py:206-213)
+__global__ void fill_pose_token_kernel(float* x, int S, int ntok, int D, const float* tok) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < S * D) { int s = i / D, d = i - s * D; x[(size_t)s * ntok * D + d] = tok[d]; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bilinear x2 upsample, align_corners=True (dpt_block.py:215-216,320), NHWC fp16 planes.
+// Output may be cropped to (Hc,Wc) <= (2Hi,2Wi) (dpt_head.py:58); interpolation ratios always use
+// the full (2Hi,2Wi) grid.  One thread = 8 channels of one output pixel.
+template <bool SPLIT>
+__global__ void bilinear_up2_kernel(const f16* i_hi, const f16* i_lo, int n, int Hi, int Wi, int C,
+                                    int Hc, int Wc, f16* o_hi, f16* o_lo) {
+    const int c8 = C / 8;
+    const int64_t total = (int64_t)n * Hc * Wc * c8;
+    const float ry = Hi > 1 ? (float)(Hi - 1) / (float)(2 * Hi - 1) : 0.f;
+    const float rx = Wi > 1 ? (float)(Wi - 1) / (float)(2 * Wi - 1) : 0.f;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += step) {
+        int c = (int)(i % c8) * 8; int64_t t = i / c8;
+        int x = (int)(t % Wc); t /= Wc; int y = (int)(t % Hc); int b = (int)(t / Hc);
+        float sy = ry * y, sx = rx * x;
+        int y0 = (int)sy, x0 = (int)sx;
+        int y1 = y0 + (y0 < Hi - 1), x1 = x0 + (x0 < Wi - 1);
+        float fy = sy - y0, fx = sx - x0;
+        const size_t base = (size_t)b * Hi * Wi;
+        const size_t o00 = ((base + (size_t)y0 * Wi + x0) * C) + c, o01 = ((base + (size_t)y0 * Wi + x1) * C) + c;
+        const size_t o10 = ((base + (size_t)y1 * Wi + x0) * C) + c, o11 = ((base + (size_t)y1 * Wi + x1) * C) + c;
+        H8 a, b_, c_, d; a.u = ldg16(i_hi + o00); b_.u = ldg16(i_hi + o01); c_.u = ldg16(i_hi + o10); d.u = ldg16(i_hi + o11);
+        H8 al, bl, cl, dl;
+        if (SPLIT) { al.u = ldg16(i_lo + o00); bl.u = ldg16(i_lo + o01); cl.u = ldg16(i_lo + o10); dl.u = ldg16(i_lo + o11); }
+        H8 oh, ol;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v00 = (float)a.e[e], v01 = (float)b_.e[e], v10 = (float)c_.e[e], v11 = (float)d.e[e];
+            if (SPLIT) { v00 += (float)al.e[e]; v01 += (float)bl.e[e]; v10 += (float)cl.e[e]; v11 += (float)dl.e[e]; }
+            // same association as ATen upsample_bilinear2d: h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)
+            float top = (1.f - fx) * v00 + fx * v01;
+            float bot = (1.f - fx) * v10 + fx * v11;
+            float v = (1.f - fy) * top + fy * bot;
+            if (SPLIT) split_f16(v, oh.e[e], ol.e[e]); else oh.e[e] = to_f16_sat(v);
+        }
+        size_t o = (((size_t)b * Hc + y) * Wc + x) * C + c;
+        *reinterpret_cast<uint4*>(o_hi + o) = oh.u;
+        if (SPLIT) *reinterpret_cast<uint4*>(o_lo + o) = ol.u;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Final 1x1 conv 128 -> 4 (dpt_block.py:323) fused with the pointmap / confidence activations
+// (postprocess.py:10-62, modes ('exp',-inf,inf) and ('exp',1,inf)):
+//   pts = xyz / max(|xyz|,1e-8) * expm1(|xyz|),  conf = 1 + exp(c)
+// Input planes [npix, 128] (ReLU already applied by the producing conv).  16 lanes per pixel.
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void head_final_kernel(const f16* i_hi, const f16* i_lo, int64_t npix,
+                                                         const float* w /*[4][128]*/, const float* bias /*[4]*/,
+                                                         float* pts, float* conf) {
+    const int sub = threadIdx.x & 15;
+    int64_t pix = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int64_t step = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    float wv[4][8];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wv[o][e] = w[o * 128 + sub * 8 + e];
+    const float b0 = bias[0], b1 = bias[1], b2 = bias[2], b3 = bias[3];
+    const int64_t npix_r = (npix + 3) / 4 * 4;   // keep whole waves in the shuffle
+    for (; pix < npix_r; pix += step) {
+        const bool ok = pix < npix;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            H8 a; a.u = ldg16(i_hi + pix * 128 + sub * 8);
+            H8 al; if (SPLIT) al.u = ldg16(i_lo + pix * 128 + sub * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = (float)a.e[e]; if (SPLIT) v += (float)al.e[e];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) acc[o] += v * wv[o][e];
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            acc[o] += __shfl_xor(acc[o], 1); acc[o] += __shfl_xor(acc[o], 2);
+            acc[o] += __shfl_xor(acc[o], 4); acc[o] += __shfl_xor(acc[o], 8);
+        }
+        if (ok && sub == 0) {
+            float x = acc[0] + b0, y = acc[1] + b1, z = acc[2] + b2, c = acc[3] + b3;
+            float d = sqrtf(x * x + y * y + z * z);
+            float sc = expm1f(d) / fmaxf(d, 1e-8f);
+            pts[pix * 3 + 0] = x * sc; pts[pix * 3 + 1] = y * sc; pts[pix * 3 + 2] = z * sc;
+            conf[pix] = 1.0f + expf(c);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pose head (heads/pose_head.py:109-120): MLP 768->512->512->512 (ReLU), fc_t(3), fc_rot(9),
+// fc_conf(1)+sigmoid, rotation = closest SO(3) matrix to the row-normalised 3x3 (pose_head.py:38-57
+// computes the same matrix through torch.svd: R = V diag(1,1,det) U^T).  fp32 VALU (1.85 MFLOP/sample,
+// latency-only; must not run in half: lu/svd fail in half in the reference too).  One block/sample.
+struct PoseParams {
+    const float* tok; int64_t tok_stride; int D; int Hd;
+    const float *w0, *b0, *w1, *b1, *w2, *b2, *wt, *bt, *wr, *br, *wc, *bc;
+    float* pose; float* conf;
+};
+
+__device__ inline void jacobi_eig3(double A[3][3], double V[3][3]) {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = (i == j);
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        if (off < 1e-40) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (fabs(A[p][q]) < 1e-300) continue;
+                double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) { double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq; }
+                for (int k = 0; k < 3; ++k) { double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk; }
+                for (int k = 0; k < 3; ++k) { double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq; }
+            }
+    }
+}
+
+// R = closest rotation to M (3x3): M = L S W^T  ->  R = L diag(1,1,det(L W^T)) W^T, realised with
+// cross products so that it stays well defined when the smallest singular value vanishes.
+__device__ inline void nearest_rotation(const double M[3][3], double R[3][3]) {
+    double B[3][3], W[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += M[k][i] * M[k][j]; B[i][j] = s; }
+    jacobi_eig3(B, W);
+    int idx[3] = {0, 1, 2};
+    double ev[3] = {B[0][0], B[1][1], B[2][2]};
+    for (int a = 0; a < 2; ++a) for (int b = a + 1; b < 3; ++b) if (ev[idx[b]] > ev[idx[a]]) { int t = idx[a]; idx[a] = idx[b]; idx[b] = t; }
+    double w0[3], w1[3], l0[3], l1[3];
+    for (int k = 0; k < 3; ++k) { w0[k] = W[k][idx[0]]; w1[k] = W[k][idx[1]]; }
+    for (int i = 0; i < 3; ++i) { l0[i] = 0; l1[i] = 0; for (int k = 0; k < 3; ++k) { l0[i] += M[i][k] * w0[k]; l1[i] += M[i][k] * w1[k]; } }
+    double n0 = sqrt(l0[0] * l0[0] + l0[1] * l0[1] + l0[2] * l0[2]);
+    for (int i = 0; i < 3; ++i) l0[i] /= n0;
+    double dp = l0[0] * l1[0] + l0[1] * l1[1] + l0[2] * l1[2];
+    for (int i = 0; i < 3; ++i) l1[i] -= dp * l0[i];
+    double n1 = sqrt(l1[0] * l1[0] + l1[1] * l1[1] + l1[2] * l1[2]);
+    for (int i = 0; i < 3; ++i) l1[i] /= n1;
+    double l2[3] = {l0[1] * l1[2] - l0[2] * l1[1], l0[2] * l1[0] - l0[0] * l1[2], l0[0] * l1[1] - l0[1] * l1[0]};
+    double w2[3] = {w0[1] * w1[2] - w0[2] * w1[1], w0[2] * w1[0] - w0[0] * w1[2], w0[0] * w1[1] - w0[1] * w1[0]};
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[i][j] = l0[i] * w0[j] + l1[i] * w1[j] + l2[i] * w2[j];
+}
+
+__global__ __launch_bounds__(256) void pose_head_kernel(const PoseParams p) {
+    __shared__ float bufA[1024];
+    __shared__ float bufB[1024];
+    __shared__ float outv[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < p.D; i += 256) bufA[i] = p.tok[(size_t)b * p.tok_stride + i];
+    __syncthreads();
+    auto layer = [&](const float* w, const float* bias, const float* in, float* out, int K, int N, bool relu) {
+        for (int n = wave; n < N; n += 4) {
+            const float* wr = w + (size_t)n * K;
+            float s = 0.f;
+            for (int k = lane; k < K; k += 64) s += wr[k] * in[k];
+            s = wave_sum(s);
+            if (lane == 0) { s += bias[n]; out[n] = relu ? fmaxf(s, 0.f) : s; }
+        }
+        __syncthreads();
+    };
+    layer(p.w0, p.b0, bufA, bufB, p.D, p.Hd, true);
+    layer(p.w1, p.b1, bufB, bufA, p.Hd, p.Hd, true);
+    layer(p.w2, p.b2, bufA, bufB, p.Hd, p.Hd, true);
+    layer(p.wt, p.bt, bufB, outv, p.Hd, 3, false);
+    layer(p.wr, p.br, bufB, outv + 3, p.Hd, 9, false);
+    layer(p.wc, p.bc, bufB, outv + 12, p.Hd, 1, false);
+    if (tid == 0) {
+        // m (3x3 row-major from fc_rot) -> normalise rows -> R = nearest rotation of normalised m
+        double M[3][3], R[3][3];
+        for (int i = 0; i < 3; ++i) {
+            float a = outv[3 + i * 3], c = outv[4 + i * 3], d = outv[5 + i * 3];
+            float nrm = fmaxf(sqrtf(a * a + c * c + d * d), 1e-12f);   // F.normalize eps
+            M[i][0] = a / nrm; M[i][1] = c / nrm; M[i][2] = d / nrm;
+        }
+        nearest_rotation(M, R);
+        float* o = p.pose + (size_t)b * 16;
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) o[i * 4 + j] = (float)R[i][j]; o[i * 4 + 3] = outv[i]; }
+        o[12] = 0.f; o[13] = 0.f; o[14] = 0.f; o[15] = 1.f;
+        p.conf[b] = 1.0f / (1.0f + expf(-outv[12]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// curope-compatible in-place 2-D RoPE on fp32 tokens (B,N,Hh,D) (kernels.cu:17-82): one thread per
+// (token, head, pair); accurate sinf/cosf/powf (the reference CUDA build uses fast-math variants).
+__global__ void rope2d_inplace_kernel(float* tok, int64_t sb, int64_t sn, const int64_t* pos,
+                                      int B, int N, int Hh, int D, float base, float fwd) {
+    const int Q = D / 4;
+    const int64_t total = (int64_t)B * N * Hh * 2 * Q;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int d = (int)(i % Q); int64_t t = i / Q;
+    int xy = (int)(t % 2); t /= 2;
+    int h = (int)(t % Hh); t /= Hh;
+    int n = (int)(t % N); int b = (int)(t / N);
+    float* base_p = tok + b * sb + n * sn + (int64_t)h * D + xy * 2 * Q;
+    const float pp = (float)pos[((int64_t)b * N + n) * 2 + xy];
+    const float ang = fwd * pp / powf(base, (float)d / (float)Q);
+    const float c = cosf(ang), s = sinf(ang);
+    const float u = base_p[d], v = base_p[d + Q];
+    base_p[d] = u * c - v * s;
+    base_p[d + Q] = v * c + u * s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight repack: fp32 source -> fp16 hi/lo planes with an index permutation.
+//   mode 0: identity ([N,K] linear weights, patch-embed conv flatten)
+//   mode 1: conv [Co,Ci,kh,kw] -> [Co][kh][kw][Ci]
+//   mode 2: transposed conv [Ci,Co,k,k] -> [(dy*k+dx)*Co+co][Ci]
+__global__ void repack_weight_kernel(const float* src, f16* hi, f16* lo, int64_t total, int mode,
+                                     int d0, int d1, int d2, int d3) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += step) {
+        int64_t si = i;
+        if (mode == 1) {          // dst index i = ((co*kh + ky)*kw + kx)*Ci + ci ; src [co][ci][ky][kx]
+            int ci = (int)(i % d1); int64_t t = i / d1; int kx = (int)(t % d3); t /= d3; int ky = (int)(t % d2); int co = (int)(t / d2);
+            si = (((int64_t)co * d1 + ci) * d2 + ky) * d3 + kx;
+        } else if (mode == 2) {   // dst i = ((dy*k+dx)*Co + co)*Ci + ci ; src [ci][co][dy][dx], d0=Ci d1=Co d2=d3=k
+            int ci = (int)(i % d0); int64_t t = i / d0; int co = (int)(t % d1); t /= d1; int dx = (int)(t % d3); int dy = (int)(t / d3);
+            si = (((int64_t)ci * d1 + co) * d2 + dy) * d3 + dx;
+        }
+        f16 h, l; split_f16(src[si], h, l);
+        hi[i] = h; lo[i] = l;
+    }
+}
+
+__global__ void expand_bias_kernel(const float* b, float* out, int cout, int reps) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cout * reps) out[i] = b[i % cout];
+}

@@ -1,0 +1,295 @@
+// MFMA GEMM / implicit-GEMM convolution for gfx950.
+//
+//   C[M,N] = epilogue( A[M,K] * W[N,K]^T + bias[N] )
+//
+// * v_mfma_f32_32x32x16_f16, fp32 accumulate.  SPLIT=true issues three products per tile step
+//   (Ah*Wh + Al*Wh + Ah*Wl) on 2-term fp16 splits of both operands: fp32-class accuracy at 1/3
+//   of the fp16 MFMA rate (gfx950 has no TF32/XF32 MFMA; the reference runs TF32).
+// * 128x128x32 block tile, 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles (64 accumulator regs).
+// * A and W are both K-contiguous, staged global -> registers -> LDS (double-buffered, one barrier
+//   per K step); LDS rows are 64 B with the 16-B chunk index XOR-swizzled by (row>>2)&3 so the
+//   fragment ds_read_b128 is bank-conflict free.
+// * A loader variants: dense rows, or 3x3 implicit-GEMM gather over an NHWC image (pad 1,
+//   stride 1/2, optional ReLU on load).
+// * Epilogues: fp32 (+bias, +residual, row remap), fp16 planes (+bias, GELU/ReLU, up to two
+//   residual plane sets), QKV (+bias, 2-D RoPE via lane shuffle, head-major Q/K and transposed V),
+//   transposed-conv pixel scatter.
+//
+// Replaces: every nn.Linear / nn.Conv2d / nn.ConvTranspose2d on the STA path
+// (sta_blocks.py:73-79,132,146,193-195,207; dpt_block.py:20-77,94-112,178-186,316-324,356-410)
+// and the curope rotary kernel (pos_embed/curope/kernels.cu:17-82) fused into the QK epilogue.
+#pragma once
+#include "sta_common.h"
+
+enum { A_DENSE = 0, A_CONV3 = 1 };
+enum { EPI_F32 = 0, EPI_F16 = 1, EPI_QKV = 2, EPI_CONVT = 3 };
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
+
+struct GemmParams {
+    // ---- A operand
+    const f16* A_hi; const f16* A_lo; int lda;          // dense [M, lda]
+    int Hi, Wi, Cin, Ho, Wo, cstride, relu_in;           // conv3x3: NHWC [nimg,Hi,Wi,Cin] -> [nimg,Ho,Wo,*]
+    // ---- B operand (weights, [N,K] planes) and bias
+    const f16* B_hi; const f16* B_lo; const float* bias;
+    int M, N, K;
+    // ---- EPI_F32
+    float* C32; int ldc; const float* resid; int ldr;
+    int rows_in, rows_out, row_off;                      // out_row = (m/rows_in)*rows_out + row_off + m%rows_in
+    // ---- EPI_F16
+    f16* C_hi; f16* C_lo; int ldc16; int act;
+    const f16* R1_hi; const f16* R1_lo; const f16* R2_hi; const f16* R2_lo;
+    // ---- EPI_QKV
+    f16* Q_hi; f16* Q_lo; f16* K_hi; f16* K_lo; f16* Vt_hi; f16* Vt_lo;
+    int nq, nk, nv, ntok, npad, heads, wp, has_pose_tok;
+    const float* rope_tab;                               // [(pos+1)][16][2] cos,sin ; pos = -1 .. P-1
+    // ---- EPI_CONVT
+    int ct_k, ct_cout, ct_h, ct_w;
+};
+
+#define GEMM_BM 128
+#define GEMM_BN 128
+#define GEMM_BK 32
+#define GEMM_TILE_BYTES (128 * 64)   // one 128 x 32 fp16 tile
+
+template <bool SPLIT>
+constexpr int gemm_smem_bytes() { return 2 * (SPLIT ? 4 : 2) * GEMM_TILE_BYTES; }
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+    return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
+}
+
+__device__ __forceinline__ uint4 relu_pair_hi(uint4 hi, uint4& lo) {
+    // relu on (hi+lo): the sign of hi decides (hi==0 implies lo==0).
+    H8 a, b; a.u = hi; b.u = lo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        bool neg = a.e[i] < (f16)0;
+        a.e[i] = neg ? (f16)0 : a.e[i];
+        b.e[i] = neg ? (f16)0 : b.e[i];
+    }
+    lo = b.u;
+    return a.u;
+}
+
+template <bool SPLIT, int AMODE, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NPL = SPLIT ? 2 : 1;
+    constexpr int STAGE = 2 * NPL * GEMM_TILE_BYTES;     // A planes then B planes
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    // ---- tile coordinates: N tiles fastest inside a group of 8 M tiles so that blocks that are
+    // co-resident share A rows / W rows in L2 (XCD-level locality comes from the group size).
+    const int tiles_n = (p.N + GEMM_BN - 1) / GEMM_BN;
+    const int bid = blockIdx.x;
+    const int bm = bid / tiles_n, bn = bid % tiles_n;
+    const int m0 = bm * GEMM_BM, n0 = bn * GEMM_BN;
+
+    // ---- per-thread staging assignment: 2 chunks (16 B) of A and of B per plane per K tile
+    int a_row[2], a_kc[2];
+    const f16* a_ptr_hi[2]; const f16* a_ptr_lo[2];
+    const f16* b_ptr_hi[2]; const f16* b_ptr_lo[2];
+    int cv_img[2], cv_y[2], cv_x[2]; bool cv_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int c = tid + 256 * i;
+        int row = c >> 2, kc = c & 3;
+        a_row[i] = row; a_kc[i] = kc;
+        int gm = m0 + row;
+        if (AMODE == A_DENSE) {
+            int gmc = gm < p.M ? gm : p.M - 1;
+            a_ptr_hi[i] = p.A_hi + (size_t)gmc * p.lda + kc * 8;
+            a_ptr_lo[i] = SPLIT ? p.A_lo + (size_t)gmc * p.lda + kc * 8 : nullptr;
+        } else {
+            cv_ok[i] = gm < p.M;
+            int gmc = cv_ok[i] ? gm : 0;
+            int hw = p.Ho * p.Wo;
+            cv_img[i] = gmc / hw;
+            int rem = gmc - cv_img[i] * hw;
+            cv_y[i] = (rem / p.Wo) * p.cstride - 1;
+            cv_x[i] = (rem % p.Wo) * p.cstride - 1;
+            a_ptr_hi[i] = nullptr; a_ptr_lo[i] = nullptr;
+        }
+        int gn = n0 + row;
+        int gnc = gn < p.N ? gn : p.N - 1;
+        b_ptr_hi[i] = p.B_hi + (size_t)gnc * p.K + kc * 8;
+        b_ptr_lo[i] = SPLIT ? p.B_lo + (size_t)gnc * p.K + kc * 8 : nullptr;
+    }
+
+    uint4 ra_hi[2], ra_lo[2], rb_hi[2], rb_lo[2];
+    const int nkt = p.K / GEMM_BK;
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * GEMM_BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (AMODE == A_DENSE) {
+                ra_hi[i] = ldg16(a_ptr_hi[i] + k0);
+                if (SPLIT) ra_lo[i] = ldg16(a_ptr_lo[i] + k0);
+            } else {
+                int tap = k0 / p.Cin;
+                int c0 = k0 - tap * p.Cin;
+                int ky = tap / 3, kx = tap - ky * 3;
+                int yi = cv_y[i] + ky, xi = cv_x[i] + kx;
+                bool ok = cv_ok[i] && yi >= 0 && yi < p.Hi && xi >= 0 && xi < p.Wi;
+                uint4 z = make_uint4(0, 0, 0, 0);
+                ra_hi[i] = z; if (SPLIT) ra_lo[i] = z;
+                if (ok) {
+                    size_t off = ((size_t)(cv_img[i] * p.Hi + yi) * p.Wi + xi) * p.Cin + c0 + a_kc[i] * 8;
+                    ra_hi[i] = ldg16(p.A_hi + off);
+                    if (SPLIT) ra_lo[i] = ldg16(p.A_lo + off);
+                    if (p.relu_in) {
+                        uint4 lo = SPLIT ? ra_lo[i] : z;
+                        ra_hi[i] = relu_pair_hi(ra_hi[i], lo);
+                        if (SPLIT) ra_lo[i] = lo;
+                    }
+                }
+            }
+            rb_hi[i] = ldg16(b_ptr_hi[i] + k0);
+            if (SPLIT) rb_lo[i] = ldg16(b_ptr_lo[i] + k0);
+        }
+    };
+    auto store_tile = [&](int stage) {
+        char* sA = smem + stage * STAGE;
+        char* sB = sA + NPL * GEMM_TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int off = lds_off(a_row[i], a_kc[i]);
+            *reinterpret_cast<uint4*>(sA + off) = ra_hi[i];
+            if (SPLIT) *reinterpret_cast<uint4*>(sA + GEMM_TILE_BYTES + off) = ra_lo[i];
+            *reinterpret_cast<uint4*>(sB + off) = rb_hi[i];
+            if (SPLIT) *reinterpret_cast<uint4*>(sB + GEMM_TILE_BYTES + off) = rb_lo[i];
+        }
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        const char* sA = smem + cur * STAGE;
+        const char* sB = sA + NPL * GEMM_TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 a_hi[2], a_lo[2], b_hi[2], b_lo[2];
+            const int chunk = ks * 2 + lhi;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                int ra = wm * 64 + t * 32 + l31;
+                int rb = wn * 64 + t * 32 + l31;
+                a_hi[t] = *reinterpret_cast<const half8*>(sA + lds_off(ra, chunk));
+                b_hi[t] = *reinterpret_cast<const half8*>(sB + lds_off(rb, chunk));
+                if (SPLIT) {
+                    a_lo[t] = *reinterpret_cast<const half8*>(sA + GEMM_TILE_BYTES + lds_off(ra, chunk));
+                    b_lo[t] = *reinterpret_cast<const half8*>(sB + GEMM_TILE_BYTES + lds_off(rb, chunk));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (SPLIT) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nkt) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ epilogue
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+        const bool col_ok = col < p.N;
+        const float bv = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
+
+        // wave-uniform QKV segment decode (64-wide wave span never straddles a head / segment)
+        int seg = 0, head = 0, dcol = 0;
+        if (EPI == EPI_QKV) {
+            int cbase = n0 + wn * 64;
+            int cc = cbase;
+            if (cbase >= p.nq + p.nk) { seg = 2; cc = cbase - p.nq - p.nk; }
+            else if (cbase >= p.nq) { seg = 1; cc = cbase - p.nq; }
+            head = cc >> 6;
+            dcol = j * 32 + l31;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const bool ok = col_ok && row < p.M;
+                float v = acc[i][j][r] + bv;
+                if (EPI == EPI_F32) {
+                    if (ok) {
+                        int orow = row;
+                        if (p.rows_in > 0) orow = (row / p.rows_in) * p.rows_out + p.row_off + row % p.rows_in;
+                        if (p.resid) v += p.resid[(size_t)orow * p.ldr + col];
+                        p.C32[(size_t)orow * p.ldc + col] = v;
+                    }
+                } else if (EPI == EPI_F16) {
+                    if (ok) {
+                        if (p.act == ACT_GELU) v = gelu_erf(v);
+                        else if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                        size_t o = (size_t)row * p.ldc16 + col;
+                        if (p.R1_hi) { v += (float)p.R1_hi[o]; if (SPLIT) v += (float)p.R1_lo[o]; }
+                        if (p.R2_hi) { v += (float)p.R2_hi[o]; if (SPLIT) v += (float)p.R2_lo[o]; }
+                        if (SPLIT) { f16 h, l; split_f16(v, h, l); p.C_hi[o] = h; p.C_lo[o] = l; }
+                        else p.C_hi[o] = to_f16_sat(v);
+                    }
+                } else if (EPI == EPI_QKV) {
+                    const int rowc = row < p.M ? row : p.M - 1;
+                    const int s = rowc / p.ntok, t = rowc - s * p.ntok;
+                    if (seg < 2) {
+                        int tt = p.has_pose_tok ? t - 1 : t;
+                        int py = tt < 0 ? -1 : tt / p.wp;
+                        int px = tt < 0 ? -1 : tt - (tt / p.wp) * p.wp;
+                        int pos = (j == 0 ? py : px) + 1;
+                        const float2 cs = *reinterpret_cast<const float2*>(p.rope_tab + ((size_t)pos * 16 + (lane & 15)) * 2);
+                        float other = __shfl_xor(v, 16);
+                        v = (lane & 16) ? (v * cs.x + other * cs.y) : (v * cs.x - other * cs.y);
+                        if (ok) {
+                            size_t o = ((size_t)(s * p.heads + head) * p.npad + t) * 64 + dcol;
+                            f16* dh = seg == 0 ? p.Q_hi : p.K_hi;
+                            f16* dl = seg == 0 ? p.Q_lo : p.K_lo;
+                            if (SPLIT) { f16 h, l; split_f16(v, h, l); dh[o] = h; dl[o] = l; }
+                            else dh[o] = to_f16_sat(v);
+                        }
+                    } else if (ok) {
+                        size_t o = ((size_t)(s * p.heads + head) * 64 + dcol) * p.npad + t;
+                        if (SPLIT) { f16 h, l; split_f16(v, h, l); p.Vt_hi[o] = h; p.Vt_lo[o] = l; }
+                        else p.Vt_hi[o] = to_f16_sat(v);
+                    }
+                } else {  // EPI_CONVT
+                    if (ok) {
+                        int g = col / p.ct_cout, co = col - g * p.ct_cout;
+                        int dy = g / p.ct_k, dx = g - dy * p.ct_k;
+                        int hw = p.ct_h * p.ct_w;
+                        int img = row / hw, rem = row - img * hw;
+                        int y = rem / p.ct_w, x = rem - y * p.ct_w;
+                        size_t o = (((size_t)img * (p.ct_h * p.ct_k) + (y * p.ct_k + dy)) * (p.ct_w * p.ct_k) + (x * p.ct_k + dx)) * p.ct_cout + co;
+                        if (SPLIT) { f16 h, l; split_f16(v, h, l); p.C_hi[o] = h; p.C_lo[o] = l; }
+                        else p.C_hi[o] = to_f16_sat(v);
+                    }
+                }
+            }
+        }
+    }
+}

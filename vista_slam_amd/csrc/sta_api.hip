@@ -1,0 +1,922 @@
+// C-ABI implementation of the MI355X STA frontend (see include/sta_mi355.h).
+// Host orchestration only: every FLOP runs in the hand-written gfx950 kernels of gemm.h,
+// attention.h and elementwise.h.  No torch, no BLAS, no CPU fallback.
+#include "../../include/sta_mi355.h"
+#include "gemm.h"
+#include "attention.h"
+#include "elementwise.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[1024] = "";
+static int set_err(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    return -1;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return set_err("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define CHK(x) do { int r_ = (x); if (r_ != 0) return r_; } while (0)
+#define REQUIRE(c, ...) do { if (!(c)) return set_err(__VA_ARGS__); } while (0)
+
+// ------------------------------------------------------------------------------------------ types
+struct Planes { f16* hi = nullptr; f16* lo = nullptr; };
+struct Lin { Planes w; float* bias = nullptr; int N = 0, K = 0; };
+struct LNp { float* g = nullptr; float* b = nullptr; };
+struct EncBlk { LNp n1, n2; Lin qkv, proj, fc1, fc2; };
+struct DecBlk { LNp n1, n2, n3, ny; Lin qkv, proj, cq, ckv, cproj, fc1, fc2; };
+struct RCU { Lin c1, c2; };
+struct Refine { Lin out; RCU u1, u2; };
+struct F32Lin { float* w = nullptr; float* b = nullptr; };
+
+enum SlotKind { SK_F32, SK_W_ID, SK_W_CONV, SK_W_CONVT, SK_B_CONVT, SK_DROP };
+struct Slot {
+    std::vector<int64_t> shape;
+    SlotKind kind = SK_DROP;
+    float* dst32 = nullptr;          // SK_F32 / SK_B_CONVT destination (+offset applied)
+    f16* dst_hi = nullptr; f16* dst_lo = nullptr;   // packed destination (+row offset applied)
+    int reps = 1;                    // SK_B_CONVT: k*k
+    bool loaded = false;
+};
+
+struct sta_handle {
+    sta_config cfg;
+    int device = 0;
+    int prec = STA_PREC_F16X3;
+    bool finalized = false;
+    std::unordered_map<std::string, Slot> slots;
+    int n_loaded = 0;
+    std::vector<void*> allocs;
+    int64_t weight_bytes = 0;
+    // weights
+    Lin patch; std::vector<EncBlk> enc; Lin dec_embed; float* pose_tok = nullptr;
+    std::vector<DecBlk> dec; LNp dec_norm;
+    Lin act0_0, act0_1, act1_0, act1_1, act2_0, act3_0, act3_1;
+    Lin rn[4]; Refine ref[4];      // ref[0] = refinenet1 ... ref[3] = refinenet4
+    Lin head0, head2; F32Lin head4;
+    F32Lin pm0, pm1, pm2, pt, pr, pc;
+    // staging + workspace
+    float* stage = nullptr; int64_t stage_elems = 0;
+    char* ws = nullptr; int64_t ws_cap = 0;
+    // rope table
+    float* rope_tab = nullptr; int rope_P = 0;
+    // timing
+    bool timing = false; hipEvent_t ev[5]; bool ev_ok = false;
+    bool dry = false;   // planning pass: run the orchestration without launching to size the workspace
+};
+
+static int dalloc(sta_handle* h, void** p, int64_t bytes) {
+    HIPCHK(hipMalloc(p, (size_t)(bytes > 0 ? bytes : 16)));
+    h->allocs.push_back(*p);
+    h->weight_bytes += bytes;
+    return 0;
+}
+
+struct Bump {
+    char* base; int64_t cap; int64_t off = 0; bool overflow = false; int64_t peak = 0;
+    void* take(int64_t bytes) {
+        int64_t a = (off + 255) & ~int64_t(255);
+        off = a + bytes;
+        if (off > peak) peak = off;
+        if (off > cap) { overflow = true; return base; }
+        return base + a;
+    }
+    void rewind(int64_t mark) { off = mark; }
+    Planes planes(int64_t elems, bool split) {
+        Planes p; p.hi = (f16*)take(elems * 2); p.lo = split ? (f16*)take(elems * 2) : nullptr; return p;
+    }
+};
+
+static int ensure_ws(sta_handle* h, int64_t bytes) {
+    if (bytes <= h->ws_cap) return 0;
+    HIPCHK(hipDeviceSynchronize());
+    if (h->ws) HIPCHK(hipFree(h->ws));
+    h->ws = nullptr; h->ws_cap = 0;
+    int64_t want = bytes + (bytes >> 3) + (1 << 20);
+    HIPCHK(hipMalloc((void**)&h->ws, (size_t)want));
+    h->ws_cap = want;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ schema
+static int make_lin(sta_handle* h, Lin& L, int N, int K, bool bias = true) {
+    L.N = N; L.K = K;
+    CHK(dalloc(h, (void**)&L.w.hi, (int64_t)N * K * 2));
+    CHK(dalloc(h, (void**)&L.w.lo, (int64_t)N * K * 2));
+    if (bias) CHK(dalloc(h, (void**)&L.bias, (int64_t)N * 4));
+    return 0;
+}
+static int make_ln(sta_handle* h, LNp& n, int C) {
+    CHK(dalloc(h, (void**)&n.g, C * 4)); CHK(dalloc(h, (void**)&n.b, C * 4)); return 0;
+}
+static void slot_w(sta_handle* h, const std::string& name, std::vector<int64_t> shape, SlotKind k, Lin& L, int row_off = 0) {
+    Slot s; s.shape = std::move(shape); s.kind = k;
+    s.dst_hi = L.w.hi + (int64_t)row_off * L.K; s.dst_lo = L.w.lo + (int64_t)row_off * L.K;
+    h->slots[name] = s;
+}
+static void slot_f32(sta_handle* h, const std::string& name, std::vector<int64_t> shape, float* dst) {
+    Slot s; s.shape = std::move(shape); s.kind = SK_F32; s.dst32 = dst; h->slots[name] = s;
+}
+static void slot_drop(sta_handle* h, const std::string& name, std::vector<int64_t> shape) {
+    Slot s; s.shape = std::move(shape); s.kind = SK_DROP; h->slots[name] = s;
+}
+static int reg_linear(sta_handle* h, const std::string& name, Lin& L, int N, int K) {
+    CHK(make_lin(h, L, N, K));
+    slot_w(h, name + ".weight", {N, K}, SK_W_ID, L);
+    slot_f32(h, name + ".bias", {N}, L.bias);
+    return 0;
+}
+static int reg_ln(sta_handle* h, const std::string& name, LNp& n, int C) {
+    CHK(make_ln(h, n, C));
+    slot_f32(h, name + ".weight", {C}, n.g); slot_f32(h, name + ".bias", {C}, n.b);
+    return 0;
+}
+// conv weight [Co,Ci,k,k] -> packed [Co][k][k][Ci]
+static int reg_conv(sta_handle* h, const std::string& name, Lin& L, int Co, int Ci, int k, bool bias) {
+    CHK(make_lin(h, L, Co, Ci * k * k, bias));
+    slot_w(h, name + ".weight", {Co, Ci, k, k}, k == 1 ? SK_W_ID : SK_W_CONV, L);
+    if (bias) slot_f32(h, name + ".bias", {Co}, L.bias);
+    return 0;
+}
+static int reg_convt(sta_handle* h, const std::string& name, Lin& L, int C, int k) {
+    CHK(make_lin(h, L, k * k * C, C));
+    slot_w(h, name + ".weight", {C, C, k, k}, SK_W_CONVT, L);
+    Slot s; s.shape = {C}; s.kind = SK_B_CONVT; s.dst32 = L.bias; s.reps = k * k;
+    h->slots[name + ".bias"] = s;
+    return 0;
+}
+static int reg_f32lin(sta_handle* h, const std::string& name, F32Lin& L, int N, int K, std::vector<int64_t> wshape) {
+    CHK(dalloc(h, (void**)&L.w, (int64_t)N * K * 4)); CHK(dalloc(h, (void**)&L.b, N * 4));
+    slot_f32(h, name + ".weight", std::move(wshape), L.w); slot_f32(h, name + ".bias", {N}, L.b);
+    return 0;
+}
+
+static int build_schema(sta_handle* h) {
+    const sta_config& c = h->cfg;
+    const int E = c.enc_embed_dim, D = c.dec_embed_dim, P = c.patch_size, R = c.mlp_ratio;
+    char nm[256];
+    CHK(dalloc(h, (void**)&h->pose_tok, D * 4));
+    slot_f32(h, "init_pose_token", {1, 1, D}, h->pose_tok);
+    CHK(make_lin(h, h->patch, E, 3 * P * P));
+    slot_w(h, "patch_embed.proj.weight", {E, 3, P, P}, SK_W_ID, h->patch);
+    slot_f32(h, "patch_embed.proj.bias", {E}, h->patch.bias);
+    h->enc.resize(c.enc_depth);
+    for (int i = 0; i < c.enc_depth; ++i) {
+        EncBlk& b = h->enc[i];
+        snprintf(nm, sizeof nm, "enc_blocks.%d.", i); std::string p(nm);
+        CHK(reg_ln(h, p + "norm1", b.n1, E));
+        CHK(reg_linear(h, p + "attn.qkv", b.qkv, 3 * E, E));
+        CHK(reg_linear(h, p + "attn.proj", b.proj, E, E));
+        CHK(reg_ln(h, p + "norm2", b.n2, E));
+        CHK(reg_linear(h, p + "mlp.fc1", b.fc1, R * E, E));
+        CHK(reg_linear(h, p + "mlp.fc2", b.fc2, E, R * E));
+    }
+    slot_drop(h, "enc_norm.weight", {E}); slot_drop(h, "enc_norm.bias", {E});   // never applied (sta_model.py:259,267)
+    CHK(reg_linear(h, "decoder_embed", h->dec_embed, D, E));
+    h->dec.resize(c.dec_depth);
+    for (int i = 0; i < c.dec_depth; ++i) {
+        DecBlk& b = h->dec[i];
+        snprintf(nm, sizeof nm, "dec_block.%d.", i); std::string p(nm);
+        CHK(reg_ln(h, p + "norm1", b.n1, D));
+        CHK(reg_linear(h, p + "attn.qkv", b.qkv, 3 * D, D));
+        CHK(reg_linear(h, p + "attn.proj", b.proj, D, D));
+        CHK(reg_linear(h, p + "cross_attn.projq", b.cq, D, D));
+        // projk + projv packed as one [2D, D] GEMM
+        CHK(make_lin(h, b.ckv, 2 * D, D));
+        slot_w(h, p + "cross_attn.projk.weight", {D, D}, SK_W_ID, b.ckv, 0);
+        slot_f32(h, p + "cross_attn.projk.bias", {D}, b.ckv.bias);
+        slot_w(h, p + "cross_attn.projv.weight", {D, D}, SK_W_ID, b.ckv, D);
+        slot_f32(h, p + "cross_attn.projv.bias", {D}, b.ckv.bias + D);
+        CHK(reg_linear(h, p + "cross_attn.proj", b.cproj, D, D));
+        CHK(reg_ln(h, p + "norm2", b.n2, D));
+        CHK(reg_ln(h, p + "norm3", b.n3, D));
+        CHK(reg_linear(h, p + "mlp.fc1", b.fc1, R * D, D));
+        CHK(reg_linear(h, p + "mlp.fc2", b.fc2, D, R * D));
+        CHK(reg_ln(h, p + "norm_y", b.ny, D));
+    }
+    CHK(reg_ln(h, "dec_norm", h->dec_norm, D));
+    const std::string dp = "downstream_head_pts.dpt.";
+    const int F = 256, L0 = 96, L1 = 192, L2 = 384, L3 = 768, LD[4] = {L0, L1, L2, L3};
+    for (int k = 0; k < 4; ++k) {
+        snprintf(nm, sizeof nm, "scratch.layer%d_rn", k + 1);
+        CHK(reg_conv(h, dp + nm, h->rn[k], F, LD[k], 3, false));
+        snprintf(nm, sizeof nm, "scratch.layer_rn.%d.weight", k);       // alias of the same tensor (dpt_block.py:70-75)
+        slot_drop(h, dp + nm, {F, LD[k], 3, 3});
+    }
+    for (int r = 1; r <= 4; ++r) {
+        Refine& rf = h->ref[r - 1];
+        snprintf(nm, sizeof nm, "scratch.refinenet%d.", r); std::string p = dp + nm;
+        CHK(reg_conv(h, p + "out_conv", rf.out, F, F, 1, true));
+        if (r == 4) {   // refinenet4.resConfUnit1 is never executed (single-input fusion, dpt_block.py:196-204)
+            for (const char* cn : {"conv1", "conv2"}) {
+                slot_drop(h, p + "resConfUnit1." + cn + ".weight", {F, F, 3, 3});
+                slot_drop(h, p + "resConfUnit1." + cn + ".bias", {F});
+            }
+        } else {
+            CHK(reg_conv(h, p + "resConfUnit1.conv1", rf.u1.c1, F, F, 3, true));
+            CHK(reg_conv(h, p + "resConfUnit1.conv2", rf.u1.c2, F, F, 3, true));
+        }
+        CHK(reg_conv(h, p + "resConfUnit2.conv1", rf.u2.c1, F, F, 3, true));
+        CHK(reg_conv(h, p + "resConfUnit2.conv2", rf.u2.c2, F, F, 3, true));
+    }
+    CHK(reg_conv(h, dp + "head.0", h->head0, F / 2, F, 3, true));
+    CHK(reg_conv(h, dp + "head.2", h->head2, 128, F / 2, 3, true));
+    CHK(reg_f32lin(h, dp + "head.4", h->head4, 4, 128, {4, 128, 1, 1}));
+    CHK(reg_conv(h, dp + "act_postprocess.0.0", h->act0_0, L0, E, 1, true));
+    CHK(reg_convt(h, dp + "act_postprocess.0.1", h->act0_1, L0, 4));
+    CHK(reg_conv(h, dp + "act_postprocess.1.0", h->act1_0, L1, D, 1, true));
+    CHK(reg_convt(h, dp + "act_postprocess.1.1", h->act1_1, L1, 2));
+    CHK(reg_conv(h, dp + "act_postprocess.2.0", h->act2_0, L2, D, 1, true));
+    CHK(reg_conv(h, dp + "act_postprocess.3.0", h->act3_0, L3, D, 1, true));
+    CHK(reg_conv(h, dp + "act_postprocess.3.1", h->act3_1, L3, L3, 3, true));
+    const int Hd = 512;
+    CHK(reg_f32lin(h, "head_pose_s.mlp.0", h->pm0, Hd, D, {Hd, D}));
+    CHK(reg_f32lin(h, "head_pose_s.mlp.2", h->pm1, Hd, Hd, {Hd, Hd}));
+    CHK(reg_f32lin(h, "head_pose_s.mlp.4", h->pm2, Hd, Hd, {Hd, Hd}));
+    CHK(reg_f32lin(h, "head_pose_s.fc_t", h->pt, 3, Hd, {3, Hd}));
+    CHK(reg_f32lin(h, "head_pose_s.fc_conf.0", h->pc, 1, Hd, {1, Hd}));
+    CHK(reg_f32lin(h, "head_pose_s.fc_rot", h->pr, 9, Hd, {9, Hd}));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ API: lifecycle
+extern "C" void sta_default_config(sta_config* c) {
+    c->patch_size = 16; c->enc_embed_dim = 1024; c->enc_depth = 24; c->enc_num_heads = 16;
+    c->dec_embed_dim = 768; c->dec_depth = 12; c->dec_num_heads = 12; c->mlp_ratio = 4;
+    c->rope_base = 100.0f; c->ln_eps = 1e-6f; c->precision = STA_PREC_F16X3;
+}
+
+extern "C" const char* sta_last_error(void) { return g_err; }
+extern "C" const char* sta_version(void) { return "sta_mi355 0.1 (gfx950)"; }
+
+extern "C" int sta_create(const sta_config* cfg, int device, sta_handle** out) {
+    REQUIRE(cfg && out, "sta_create: null argument");
+    REQUIRE(cfg->patch_size == 16, "patch_size must be 16");
+    REQUIRE(cfg->enc_embed_dim == 64 * cfg->enc_num_heads, "encoder head_dim must be 64");
+    REQUIRE(cfg->dec_embed_dim == 64 * cfg->dec_num_heads, "decoder head_dim must be 64");
+    REQUIRE(cfg->enc_embed_dim % 128 == 0 && cfg->enc_embed_dim <= 1024, "enc_embed_dim must be a multiple of 128, <= 1024");
+    REQUIRE(cfg->dec_embed_dim % 128 == 0 && cfg->dec_embed_dim <= 1024, "dec_embed_dim must be a multiple of 128, <= 1024");
+    REQUIRE(cfg->dec_depth > 9, "dec_depth must be > 9 (heads/dpt_head.py:102)");
+    REQUIRE(cfg->precision == STA_PREC_F16 || cfg->precision == STA_PREC_F16X3, "unknown precision %d", cfg->precision);
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    REQUIRE(device >= 0 && device < ndev, "device %d out of range (%d visible)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, "this library is built for gfx950 only, device reports %s", prop.gcnArchName);
+    sta_handle* h = new sta_handle();
+    h->cfg = *cfg; h->device = device; h->prec = cfg->precision;
+    if (build_schema(h) != 0) { sta_destroy(h); return -1; }
+    h->stage_elems = (int64_t)cfg->mlp_ratio * cfg->enc_embed_dim * cfg->enc_embed_dim;
+    int64_t big = (int64_t)768 * 768 * 9;
+    if (big > h->stage_elems) h->stage_elems = big;
+    if (hipMalloc((void**)&h->stage, (size_t)h->stage_elems * 4) != hipSuccess) { sta_destroy(h); return set_err("staging alloc failed"); }
+    // dynamic LDS opt-in (64 KB for split tiles)
+    hipFuncSetAttribute((const void*)gemm_kernel<true, A_DENSE, EPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_smem_bytes<true>());
+    *out = h;
+    return 0;
+}
+
+extern "C" int sta_destroy(sta_handle* h) {
+    if (!h) return 0;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    for (void* p : h->allocs) hipFree(p);
+    if (h->stage) hipFree(h->stage);
+    if (h->ws) hipFree(h->ws);
+    if (h->rope_tab) hipFree(h->rope_tab);
+    if (h->ev_ok) for (auto& e : h->ev) hipEventDestroy(e);
+    delete h;
+    return 0;
+}
+
+extern "C" int sta_set_precision(sta_handle* h, int precision) {
+    REQUIRE(h, "null handle");
+    REQUIRE(precision == STA_PREC_F16 || precision == STA_PREC_F16X3, "unknown precision %d", precision);
+    h->prec = precision;
+    return 0;
+}
+extern "C" int sta_num_expected_tensors(const sta_handle* h) { return h ? (int)h->slots.size() : -1; }
+extern "C" int sta_num_loaded_tensors(const sta_handle* h) { return h ? h->n_loaded : -1; }
+extern "C" int64_t sta_workspace_bytes(const sta_handle* h) { return h ? h->ws_cap : -1; }
+extern "C" int64_t sta_weight_bytes(const sta_handle* h) { return h ? h->weight_bytes : -1; }
+
+extern "C" int sta_load_tensor(sta_handle* h, const char* name, const void* host_ptr,
+                               const int64_t* shape, int ndim, int dtype) {
+    REQUIRE(h && name && host_ptr && shape, "sta_load_tensor: null argument");
+    REQUIRE(dtype == STA_DTYPE_F32, "only fp32 source tensors are supported");
+    HIPCHK(hipSetDevice(h->device));
+    auto it = h->slots.find(name);
+    REQUIRE(it != h->slots.end(), "unexpected key in state_dict: %s", name);
+    Slot& s = it->second;
+    REQUIRE((int)s.shape.size() == ndim, "size mismatch for %s: ndim %d vs expected %d", name, ndim, (int)s.shape.size());
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        REQUIRE(shape[i] == s.shape[i], "size mismatch for %s: dim %d is %lld, expected %lld", name, i, (long long)shape[i], (long long)s.shape[i]);
+        n *= shape[i];
+    }
+    if (s.kind != SK_DROP) {
+        REQUIRE(n <= h->stage_elems, "tensor %s too large for staging", name);
+        if (s.kind == SK_F32) {
+            HIPCHK(hipMemcpy(s.dst32, host_ptr, (size_t)n * 4, hipMemcpyHostToDevice));
+        } else {
+            HIPCHK(hipMemcpy(h->stage, host_ptr, (size_t)n * 4, hipMemcpyHostToDevice));
+            int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
+            if (s.kind == SK_B_CONVT) {
+                int tot = (int)n * s.reps;
+                expand_bias_kernel<<<(tot + 255) / 256, 256>>>(h->stage, s.dst32, (int)n, s.reps);
+            } else {
+                int mode = s.kind == SK_W_ID ? 0 : (s.kind == SK_W_CONV ? 1 : 2);
+                int d0 = (int)s.shape[0], d1 = ndim > 1 ? (int)s.shape[1] : 1, d2 = ndim > 2 ? (int)s.shape[2] : 1, d3 = ndim > 3 ? (int)s.shape[3] : 1;
+                repack_weight_kernel<<<blocks, 256>>>(h->stage, s.dst_hi, s.dst_lo, n, mode, d0, d1, d2, d3);
+            }
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipDeviceSynchronize());
+        }
+    }
+    if (!s.loaded) { s.loaded = true; h->n_loaded++; }
+    return 0;
+}
+
+extern "C" int sta_finalize_weights(sta_handle* h) {
+    REQUIRE(h, "null handle");
+    for (auto& kv : h->slots)
+        REQUIRE(kv.second.loaded, "missing key in state_dict: %s", kv.first.c_str());
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    h->finalized = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ launch helpers
+template <int AMODE, int EPI>
+static int launch_gemm(sta_handle* h, const GemmParams& p, hipStream_t st) {
+    REQUIRE(p.K % GEMM_BK == 0, "GEMM K=%d must be a multiple of %d", p.K, GEMM_BK);
+    REQUIRE(p.M > 0 && p.N > 0, "empty GEMM");
+    if (AMODE == A_CONV3) REQUIRE(p.Cin % GEMM_BK == 0, "conv Cin=%d must be a multiple of %d", p.Cin, GEMM_BK);
+    if (h->dry) return 0;
+    int tm = (p.M + GEMM_BM - 1) / GEMM_BM, tn = (p.N + GEMM_BN - 1) / GEMM_BN;
+    dim3 grid((unsigned)(tm * tn));
+    if (h->prec == STA_PREC_F16X3) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipFuncSetAttribute((const void*)gemm_kernel<true, AMODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_smem_bytes<true>());
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((gemm_kernel<true, AMODE, EPI>), grid, dim3(256), gemm_smem_bytes<true>(), st, p);
+    } else {
+        hipLaunchKernelGGL((gemm_kernel<false, AMODE, EPI>), grid, dim3(256), gemm_smem_bytes<false>(), st, p);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static GemmParams gp_dense(const Planes& A, int lda, const Lin& W, int M) {
+    GemmParams p; memset(&p, 0, sizeof p);
+    p.A_hi = A.hi; p.A_lo = A.lo; p.lda = lda;
+    p.B_hi = W.w.hi; p.B_lo = W.w.lo; p.bias = W.bias;
+    p.M = M; p.N = W.N; p.K = W.K;
+    return p;
+}
+
+// out fp32 = A*W^T + bias (+resid), optional row remap
+static int gemm_f32(sta_handle* h, const Planes& A, const Lin& W, int M, float* out, int ldc,
+                    const float* resid, hipStream_t st, int rows_in = 0, int rows_out = 0, int row_off = 0) {
+    GemmParams p = gp_dense(A, W.K, W, M);
+    p.C32 = out; p.ldc = ldc; p.resid = resid; p.ldr = ldc;
+    p.rows_in = rows_in; p.rows_out = rows_out; p.row_off = row_off;
+    return launch_gemm<A_DENSE, EPI_F32>(h, p, st);
+}
+static int gemm_f16(sta_handle* h, const Planes& A, const Lin& W, int M, const Planes& out, int act, hipStream_t st) {
+    GemmParams p = gp_dense(A, W.K, W, M);
+    p.C_hi = out.hi; p.C_lo = out.lo; p.ldc16 = W.N; p.act = act;
+    return launch_gemm<A_DENSE, EPI_F16>(h, p, st);
+}
+struct QKVOut { Planes q, k, vt; int npad; };
+static int gemm_qkv(sta_handle* h, const Planes& A, const Lin& W, int M, int nq, int nk, int nv,
+                    const QKVOut& o, int ntok, int heads, int wp, int has_pose, hipStream_t st) {
+    GemmParams p = gp_dense(A, W.K, W, M);
+    p.Q_hi = o.q.hi; p.Q_lo = o.q.lo; p.K_hi = o.k.hi; p.K_lo = o.k.lo; p.Vt_hi = o.vt.hi; p.Vt_lo = o.vt.lo;
+    p.nq = nq; p.nk = nk; p.nv = nv; p.ntok = ntok; p.npad = o.npad; p.heads = heads; p.wp = wp; p.has_pose_tok = has_pose;
+    p.rope_tab = h->rope_tab;
+    REQUIRE(nq + nk + nv == W.N, "qkv segment mismatch");
+    return launch_gemm<A_DENSE, EPI_QKV>(h, p, st);
+}
+static int gemm_convt(sta_handle* h, const Planes& A, const Lin& W, int nimg, int hh, int ww, int k, int cout,
+                      const Planes& out, hipStream_t st) {
+    GemmParams p = gp_dense(A, W.K, W, nimg * hh * ww);
+    p.C_hi = out.hi; p.C_lo = out.lo; p.ct_k = k; p.ct_cout = cout; p.ct_h = hh; p.ct_w = ww;
+    return launch_gemm<A_DENSE, EPI_CONVT>(h, p, st);
+}
+// 3x3 conv, pad 1, NHWC planes
+static int conv3(sta_handle* h, const Planes& in, int nimg, int Hi, int Wi, int Cin, const Lin& W, int stride,
+                 bool relu_in, int act, const Planes& out, const Planes* r1, const Planes* r2, hipStream_t st) {
+    GemmParams p; memset(&p, 0, sizeof p);
+    p.A_hi = in.hi; p.A_lo = in.lo;
+    p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.cstride = stride; p.relu_in = relu_in ? 1 : 0;
+    p.Ho = (Hi + 2 - 3) / stride + 1; p.Wo = (Wi + 2 - 3) / stride + 1;
+    p.B_hi = W.w.hi; p.B_lo = W.w.lo; p.bias = W.bias;
+    p.M = nimg * p.Ho * p.Wo; p.N = W.N; p.K = W.K;
+    REQUIRE(W.K == 9 * Cin, "conv weight K mismatch");
+    p.C_hi = out.hi; p.C_lo = out.lo; p.ldc16 = W.N; p.act = act;
+    if (r1) { p.R1_hi = r1->hi; p.R1_lo = r1->lo; }
+    if (r2) { p.R2_hi = r2->hi; p.R2_lo = r2->lo; }
+    return launch_gemm<A_CONV3, EPI_F16>(h, p, st);
+}
+
+static int run_ln(sta_handle* h, const float* x, int M, int C, const LNp& a, const Planes& oa,
+                  const LNp* b, const Planes* ob, float* o32, hipStream_t st) {
+    if (h->dry) return 0;
+    LnParams p; memset(&p, 0, sizeof p);
+    p.x = x; p.ldx = C; p.M = M; p.C = C; p.eps = h->cfg.ln_eps;
+    p.g1 = a.g; p.b1 = a.b; p.o1_hi = oa.hi; p.o1_lo = oa.lo;
+    if (b) { p.g2 = b->g; p.b2 = b->b; p.o2_hi = ob->hi; p.o2_lo = ob->lo; }
+    p.o32 = o32; p.ldo32 = C;
+    dim3 grid((M + 3) / 4);
+    if (h->prec == STA_PREC_F16X3) hipLaunchKernelGGL(ln_kernel<true>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(ln_kernel<false>, grid, dim3(256), 0, st, p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int run_attn(sta_handle* h, const QKVOut& qkv, const Planes& out, int ldo, int S, int heads,
+                    int nq, int nk, int kv_shift, hipStream_t st) {
+    if (h->dry) return 0;
+    AttnParams p; memset(&p, 0, sizeof p);
+    p.Q_hi = qkv.q.hi; p.Q_lo = qkv.q.lo; p.K_hi = qkv.k.hi; p.K_lo = qkv.k.lo; p.Vt_hi = qkv.vt.hi; p.Vt_lo = qkv.vt.lo;
+    p.O_hi = out.hi; p.O_lo = out.lo; p.ldo = ldo;
+    p.S = S; p.heads = heads; p.nq = nq; p.nk = nk; p.npad = qkv.npad; p.kv_shift = kv_shift;
+    p.scale_log2e = 0.125f * 1.44269504088896340736f;
+    dim3 grid((nq + 127) / 128, heads, S);
+    if (h->prec == STA_PREC_F16X3) {
+        static bool attr_done = false;
+        if (!attr_done) { hipFuncSetAttribute((const void*)attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_smem_bytes<true>()); attr_done = true; }
+        hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), attn_smem_bytes<true>(), st, p);
+    } else {
+        hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), attn_smem_bytes<false>(), st, p);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int run_rows_to_planes(sta_handle* h, const float* x, int64_t bstride, int nb, int rows, int C, const Planes& o, hipStream_t st, int64_t obstride = 0) {
+    if (h->dry) return 0;
+    int64_t total4 = (int64_t)nb * rows * C / 4;
+    int blocks = (int)((total4 + 255) / 256); if (blocks > 8192) blocks = 8192;
+    if (h->prec == STA_PREC_F16X3) hipLaunchKernelGGL(rows_to_planes_kernel<true>, dim3(blocks), dim3(256), 0, st, x, bstride, rows, C, total4, o.hi, o.lo, obstride);
+    else hipLaunchKernelGGL(rows_to_planes_kernel<false>, dim3(blocks), dim3(256), 0, st, x, bstride, rows, C, total4, o.hi, o.lo, obstride);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int run_up2(sta_handle* h, const Planes& in, int n, int Hi, int Wi, int C, int Hc, int Wc, const Planes& out, hipStream_t st) {
+    if (h->dry) return 0;
+    int64_t total = (int64_t)n * Hc * Wc * (C / 8);
+    int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
+    if (h->prec == STA_PREC_F16X3) hipLaunchKernelGGL(bilinear_up2_kernel<true>, dim3(blocks), dim3(256), 0, st, in.hi, in.lo, n, Hi, Wi, C, Hc, Wc, out.hi, out.lo);
+    else hipLaunchKernelGGL(bilinear_up2_kernel<false>, dim3(blocks), dim3(256), 0, st, in.hi, in.lo, n, Hi, Wi, C, Hc, Wc, out.hi, out.lo);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int ensure_rope(sta_handle* h, int P) {
+    if (P <= h->rope_P && h->rope_tab) return 0;
+    // cos/sin of pos * base^(-d/16), pos = -1 .. P-1, fp32 like the reference python path (pos_embed.py:127-146)
+    std::vector<float> tab((size_t)(P + 1) * 32);
+    for (int pi = 0; pi <= P; ++pi)
+        for (int d = 0; d < 16; ++d) {
+            float inv_freq = 1.0f / powf(h->cfg.rope_base, (float)d / 16.0f);
+            float f = (float)(pi - 1) * inv_freq;
+            tab[((size_t)pi * 16 + d) * 2 + 0] = cosf(f);
+            tab[((size_t)pi * 16 + d) * 2 + 1] = sinf(f);
+        }
+    HIPCHK(hipDeviceSynchronize());
+    if (h->rope_tab) HIPCHK(hipFree(h->rope_tab));
+    HIPCHK(hipMalloc((void**)&h->rope_tab, tab.size() * 4));
+    HIPCHK(hipMemcpy(h->rope_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    h->rope_P = P;
+    return 0;
+}
+
+static inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------ encoder
+// imgs: nsets pointers of B images each -> feat [nsets*B, N, E] (fp32, caller memory = residual stream)
+static int encode_impl(sta_handle* h, Bump& ws, const float* const* imgs, int nsets, int B, int H, int W,
+                       float* feat, hipStream_t st) {
+    const sta_config& c = h->cfg;
+    const bool split = h->prec == STA_PREC_F16X3;
+    const int E = c.enc_embed_dim, Hh = c.enc_num_heads, hp = H / 16, wp = W / 16, N = hp * wp;
+    const int n = nsets * B, M = n * N, npad = rup(N, 64);
+    Planes patches = ws.planes((int64_t)M * 768, split);
+    Planes lnp = ws.planes((int64_t)M * E, split);
+    Planes ao = ws.planes((int64_t)M * E, split);
+    Planes f1 = ws.planes((int64_t)M * E * c.mlp_ratio, split);
+    QKVOut qkv; qkv.npad = npad;
+    int64_t hsz = (int64_t)n * Hh * npad * 64;
+    qkv.q = ws.planes(hsz, split); qkv.k = ws.planes(hsz, split); qkv.vt = ws.planes(hsz, split);
+    if (h->dry) return 0;
+    REQUIRE(!ws.overflow, "internal: encode workspace overflow");
+    HIPCHK(hipMemsetAsync(qkv.vt.hi, 0, hsz * 2, st));
+    if (split) HIPCHK(hipMemsetAsync(qkv.vt.lo, 0, hsz * 2, st));
+    for (int sidx = 0; sidx < nsets; ++sidx) {
+        Planes dst = patches; dst.hi += (int64_t)sidx * B * N * 768; if (split) dst.lo += (int64_t)sidx * B * N * 768;
+        int64_t total = (int64_t)B * N * 48;
+        int blocks = (int)((total + 255) / 256);
+        if (split) hipLaunchKernelGGL(patch_gather_kernel<true>, dim3(blocks), dim3(256), 0, st, imgs[sidx], B, H, W, dst.hi, dst.lo);
+        else hipLaunchKernelGGL(patch_gather_kernel<false>, dim3(blocks), dim3(256), 0, st, imgs[sidx], B, H, W, dst.hi, dst.lo);
+        HIPCHK(hipGetLastError());
+    }
+    CHK(gemm_f32(h, patches, h->patch, M, feat, E, nullptr, st));
+    for (int i = 0; i < c.enc_depth; ++i) {
+        const EncBlk& b = h->enc[i];
+        CHK(run_ln(h, feat, M, E, b.n1, lnp, nullptr, nullptr, nullptr, st));
+        CHK(gemm_qkv(h, lnp, b.qkv, M, E, E, E, qkv, N, Hh, wp, 0, st));
+        CHK(run_attn(h, qkv, ao, E, n, Hh, N, N, 0, st));
+        CHK(gemm_f32(h, ao, b.proj, M, feat, E, feat, st));
+        CHK(run_ln(h, feat, M, E, b.n2, lnp, nullptr, nullptr, nullptr, st));
+        CHK(gemm_f16(h, lnp, b.fc1, M, f1, ACT_GELU, st));
+        CHK(gemm_f32(h, f1, b.fc2, M, feat, E, feat, st));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ decoder
+// x: fp32 [2B, N+1, D] residual stream (workspace or caller).  hook(i, x) is called after layer i
+// (i = 0: decoder input) through the `want` table: want1[i]/want2[i] destination or NULL.
+static int decode_impl(sta_handle* h, Bump& ws, const float* feat1, const float* feat2, int B, int hp, int wp,
+                       float* x, float* const* want1, float* const* want2, hipStream_t st) {
+    const sta_config& c = h->cfg;
+    const bool split = h->prec == STA_PREC_F16X3;
+    const int E = c.enc_embed_dim, D = c.dec_embed_dim, Hh = c.dec_num_heads;
+    const int N = hp * wp, Np = N + 1, S = 2 * B, M = S * Np, npad = rup(Np, 64);
+    Planes fp = ws.planes((int64_t)S * N * E, split);
+    Planes a1 = ws.planes((int64_t)M * D, split);
+    Planes ay = ws.planes((int64_t)M * D, split);
+    Planes ao = ws.planes((int64_t)M * D, split);
+    Planes f1 = ws.planes((int64_t)M * D * c.mlp_ratio, split);
+    QKVOut qkv; qkv.npad = npad;
+    int64_t hsz = (int64_t)S * Hh * npad * 64;
+    qkv.q = ws.planes(hsz, split); qkv.k = ws.planes(hsz, split); qkv.vt = ws.planes(hsz, split);
+    if (h->dry) return 0;
+    REQUIRE(!ws.overflow, "internal: decode workspace overflow");
+    HIPCHK(hipMemsetAsync(qkv.vt.hi, 0, hsz * 2, st));
+    if (split) HIPCHK(hipMemsetAsync(qkv.vt.lo, 0, hsz * 2, st));
+
+    Planes fp2 = fp; fp2.hi += (int64_t)B * N * E; if (split) fp2.lo += (int64_t)B * N * E;
+    CHK(run_rows_to_planes(h, feat1, (int64_t)N * E, B, N, E, fp, st));
+    CHK(run_rows_to_planes(h, feat2, (int64_t)N * E, B, N, E, fp2, st));
+    CHK(gemm_f32(h, fp, h->dec_embed, S * N, x, D, nullptr, st, N, Np, 1));
+    hipLaunchKernelGGL(fill_pose_token_kernel, dim3((S * D + 255) / 256), dim3(256), 0, st, x, S, Np, D, h->pose_tok);
+    HIPCHK(hipGetLastError());
+    const size_t half_bytes = (size_t)B * Np * D * 4;
+    auto emit = [&](int idx) -> int {
+        if (want1 && want1[idx]) HIPCHK(hipMemcpyAsync(want1[idx], x, half_bytes, hipMemcpyDeviceToDevice, st));
+        if (want2 && want2[idx]) HIPCHK(hipMemcpyAsync(want2[idx], x + (size_t)B * Np * D, half_bytes, hipMemcpyDeviceToDevice, st));
+        return 0;
+    };
+    CHK(emit(0));
+    for (int i = 0; i < c.dec_depth; ++i) {
+        const DecBlk& b = h->dec[i];
+        // norm1(x) and norm_y(x) from one read: y of one side == x of the other (sta_model.py:231-235)
+        CHK(run_ln(h, x, M, D, b.n1, a1, &b.ny, &ay, nullptr, st));
+        CHK(gemm_qkv(h, a1, b.qkv, M, D, D, D, qkv, Np, Hh, wp, 1, st));
+        CHK(run_attn(h, qkv, ao, D, S, Hh, Np, Np, 0, st));
+        CHK(gemm_f32(h, ao, b.proj, M, x, D, x, st));
+        CHK(run_ln(h, x, M, D, b.n2, a1, nullptr, nullptr, nullptr, st));
+        CHK(gemm_qkv(h, a1, b.cq, M, D, 0, 0, qkv, Np, Hh, wp, 1, st));
+        CHK(gemm_qkv(h, ay, b.ckv, M, 0, D, D, qkv, Np, Hh, wp, 1, st));
+        CHK(run_attn(h, qkv, ao, D, S, Hh, Np, Np, B, st));
+        CHK(gemm_f32(h, ao, b.cproj, M, x, D, x, st));
+        CHK(run_ln(h, x, M, D, b.n3, a1, nullptr, nullptr, nullptr, st));
+        CHK(gemm_f16(h, a1, b.fc1, M, f1, ACT_GELU, st));
+        CHK(gemm_f32(h, f1, b.fc2, M, x, D, x, st));
+        if (i + 1 < c.dec_depth) {
+            CHK(emit(i + 1));
+        } else {   // final_x[-1] = dec_norm(final_x[-1])  (sta_model.py:241-242)
+            Planes none;
+            if (want1 && want1[i + 1]) CHK(run_ln(h, x, B * Np, D, h->dec_norm, none, nullptr, nullptr, want1[i + 1], st));
+            if (want2 && want2[i + 1]) CHK(run_ln(h, x + (size_t)B * Np * D, B * Np, D, h->dec_norm, none, nullptr, nullptr, want2[i + 1], st));
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ pose head
+static int pose_impl(sta_handle* h, const float* tok, int B, int64_t stride, float* pose, float* conf, hipStream_t st) {
+    if (h->dry) return 0;
+    PoseParams p;
+    p.tok = tok; p.tok_stride = stride; p.D = h->cfg.dec_embed_dim; p.Hd = 512;
+    p.w0 = h->pm0.w; p.b0 = h->pm0.b; p.w1 = h->pm1.w; p.b1 = h->pm1.b; p.w2 = h->pm2.w; p.b2 = h->pm2.b;
+    p.wt = h->pt.w; p.bt = h->pt.b; p.wr = h->pr.w; p.br = h->pr.b; p.wc = h->pc.w; p.bc = h->pc.b;
+    p.pose = pose; p.conf = conf;
+    hipLaunchKernelGGL(pose_head_kernel, dim3(B), dim3(256), 0, st, p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ DPT head
+struct RcuTmp { Planes t, y; };
+static int run_rcu(sta_handle* h, const Planes& x, int n, int Hh, int Ww, const RCU& u, const Planes& tmp,
+                   const Planes& out, const Planes* extra, hipStream_t st) {
+    // out = x + conv2(relu(conv1(relu(x)))) [+ extra]   (dpt_block.py:121-142, 196-204)
+    CHK(conv3(h, x, n, Hh, Ww, 256, u.c1, 1, true, ACT_RELU, tmp, nullptr, nullptr, st));
+    CHK(conv3(h, tmp, n, Hh, Ww, 256, u.c2, 1, false, ACT_NONE, out, &x, extra, st));
+    return 0;
+}
+
+// outputs: first nA images -> (ptsA, confA), remaining -> (ptsB, confB)
+static int dpt_impl(sta_handle* h, Bump& ws, const float* enc, int64_t enc_bs,
+                    const float* h1, int64_t h1_bs, const float* h2, int64_t h2_bs, const float* h3, int64_t h3_bs,
+                    int n, int H, int W, float* ptsA, float* confA, int nA, float* ptsB, float* confB, hipStream_t st) {
+    const sta_config& c = h->cfg;
+    const bool split = h->prec == STA_PREC_F16X3;
+    const int E = c.enc_embed_dim, D = c.dec_embed_dim, hp = H / 16, wp = W / 16, N = hp * wp;
+    const int M = n * N;
+    Planes t0 = ws.planes((int64_t)M * E, split), t1 = ws.planes((int64_t)M * D, split);
+    Planes t2 = ws.planes((int64_t)M * D, split), t3 = ws.planes((int64_t)M * D, split);
+    CHK(run_rows_to_planes(h, enc, enc_bs, n, N, E, t0, st));
+    CHK(run_rows_to_planes(h, h1, h1_bs, n, N, D, t1, st));
+    CHK(run_rows_to_planes(h, h2, h2_bs, n, N, D, t2, st));
+    CHK(run_rows_to_planes(h, h3, h3_bs, n, N, D, t3, st));
+    // act_postprocess (dpt_block.py:356-410)
+    Planes a0 = ws.planes((int64_t)M * 96, split), l0 = ws.planes((int64_t)M * 16 * 96, split);
+    Planes a1 = ws.planes((int64_t)M * 192, split), l1 = ws.planes((int64_t)M * 4 * 192, split);
+    Planes l2 = ws.planes((int64_t)M * 384, split);
+    Planes a3 = ws.planes((int64_t)M * 768, split);
+    const int h3s = (hp - 1) / 2 + 1, w3s = (wp - 1) / 2 + 1;
+    Planes l3 = ws.planes((int64_t)n * h3s * w3s * 768, split);
+    REQUIRE(!ws.overflow, "internal: dpt workspace overflow (stage 1)");
+    CHK(gemm_f16(h, t0, h->act0_0, M, a0, ACT_NONE, st));
+    CHK(gemm_convt(h, a0, h->act0_1, n, hp, wp, 4, 96, l0, st));
+    CHK(gemm_f16(h, t1, h->act1_0, M, a1, ACT_NONE, st));
+    CHK(gemm_convt(h, a1, h->act1_1, n, hp, wp, 2, 192, l1, st));
+    CHK(gemm_f16(h, t2, h->act2_0, M, l2, ACT_NONE, st));
+    CHK(gemm_f16(h, t3, h->act3_0, M, a3, ACT_NONE, st));
+    CHK(conv3(h, a3, n, hp, wp, 768, h->act3_1, 2, false, ACT_NONE, l3, nullptr, nullptr, st));
+    // layer_rn (3x3, no bias) -> 256 channels at 4x, 2x, 1x, 1/2x
+    const int Hs[4] = {4 * hp, 2 * hp, hp, h3s}, Ws[4] = {4 * wp, 2 * wp, wp, w3s};
+    const int Cs[4] = {96, 192, 384, 768};
+    Planes lin[4] = {l0, l1, l2, l3}, r[4];
+    for (int k = 0; k < 4; ++k) {
+        r[k] = ws.planes((int64_t)n * Hs[k] * Ws[k] * 256, split);
+        REQUIRE(!ws.overflow, "internal: dpt workspace overflow (rn)");
+        CHK(conv3(h, lin[k], n, Hs[k], Ws[k], Cs[k], h->rn[k], 1, false, ACT_NONE, r[k], nullptr, nullptr, st));
+    }
+    // refinenet4 .. refinenet1.  out_conv (1x1) commutes with the bilinear upsample (both linear, the
+    // interpolation weights sum to 1), so it runs BEFORE the x2 upsample at 1/4 of the FLOPs.
+    Planes path;   // upsampled output of the previous stage
+    int ph = 0, pw = 0;
+    for (int k = 3; k >= 0; --k) {
+        const Refine& rf = h->ref[k];
+        const int hh = Hs[k], ww = Ws[k];
+        const int64_t el = (int64_t)n * hh * ww * 256;
+        Planes tmp = ws.planes(el, split), cur = r[k];
+        if (k < 3) {
+            REQUIRE(ph == hh && pw == ww, "internal: refinenet size mismatch %dx%d vs %dx%d", ph, pw, hh, ww);
+            Planes sum = ws.planes(el, split);
+            REQUIRE(!ws.overflow, "internal: dpt workspace overflow (fusion)");
+            CHK(run_rcu(h, r[k], n, hh, ww, rf.u1, tmp, sum, &path, st));   // path + RCU1(layer)
+            cur = sum;
+        }
+        Planes y = ws.planes(el, split), z = ws.planes(el, split);
+        REQUIRE(!ws.overflow, "internal: dpt workspace overflow (rcu2)");
+        CHK(run_rcu(h, cur, n, hh, ww, rf.u2, tmp, y, nullptr, st));
+        CHK(gemm_f16(h, y, rf.out, n * hh * ww, z, ACT_NONE, st));
+        // upsample x2 (align_corners) ; refinenet4 output is cropped to the layers[2] size (dpt_head.py:58)
+        int oh = 2 * hh, ow = 2 * ww;
+        if (k == 3) { if (oh > Hs[2]) oh = Hs[2]; if (ow > Ws[2]) ow = Ws[2]; }
+        Planes up = ws.planes((int64_t)n * oh * ow * 256, split);
+        REQUIRE(!ws.overflow, "internal: dpt workspace overflow (up)");
+        CHK(run_up2(h, z, n, hh, ww, 256, oh, ow, up, st));
+        path = up; ph = oh; pw = ow;
+    }
+    // head: 3x3 256->128, up x2, 3x3 128->128 + ReLU, 1x1 128->4 + postprocess (dpt_block.py:316-324)
+    Planes h0 = ws.planes((int64_t)n * ph * pw * 128, split);
+    Planes h0u = ws.planes((int64_t)n * H * W * 128, split);
+    Planes h2o = ws.planes((int64_t)n * H * W * 128, split);
+    REQUIRE(!ws.overflow, "internal: dpt workspace overflow (head)");
+    REQUIRE(2 * ph == H && 2 * pw == W, "internal: head size mismatch");
+    CHK(conv3(h, path, n, ph, pw, 256, h->head0, 1, false, ACT_NONE, h0, nullptr, nullptr, st));
+    CHK(run_up2(h, h0, n, ph, pw, 128, H, W, h0u, st));
+    CHK(conv3(h, h0u, n, H, W, 128, h->head2, 1, false, ACT_RELU, h2o, nullptr, nullptr, st));
+    for (int part = 0; part < 2 && !h->dry; ++part) {
+        int i0 = part == 0 ? 0 : nA, cnt = part == 0 ? (nA < n ? nA : n) : n - nA;
+        if (cnt <= 0) continue;
+        float* pp = part == 0 ? ptsA : ptsB; float* cp = part == 0 ? confA : confB;
+        int64_t npix = (int64_t)cnt * H * W;
+        const f16* ih = h2o.hi + (int64_t)i0 * H * W * 128;
+        const f16* il = split ? h2o.lo + (int64_t)i0 * H * W * 128 : nullptr;
+        int blocks = (int)((npix * 16 + 255) / 256); if (blocks > 16384) blocks = 16384;
+        if (split) hipLaunchKernelGGL(head_final_kernel<true>, dim3(blocks), dim3(256), 0, st, ih, il, npix, h->head4.w, h->head4.b, pp, cp);
+        else hipLaunchKernelGGL(head_final_kernel<false>, dim3(blocks), dim3(256), 0, st, ih, il, npix, h->head4.w, h->head4.b, pp, cp);
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ API: compute
+static int check_ready(sta_handle* h, int B, int H, int W) {
+    REQUIRE(h, "null handle");
+    REQUIRE(h->finalized, "weights not finalized (call sta_finalize_weights)");
+    REQUIRE(B > 0, "batch must be positive");
+    REQUIRE(H % 16 == 0 && W % 16 == 0 && H > 0 && W > 0, "Input image size (%dx%d) is not a multiple of patch size (16)", H, W);
+    REQUIRE(W >= H, "img should be in landscape mode, but got W=%d H=%d", W, H);
+    HIPCHK(hipSetDevice(h->device));
+    return 0;
+}
+
+// Two-pass execution: a dry planning pass sizes the workspace exactly (same allocation sequence,
+// no launches), then the real pass runs.  Steady state: the plan fits, nothing is allocated.
+template <class F>
+static int plan_and_run(sta_handle* h, F&& body) {
+    h->dry = true;
+    Bump plan{nullptr, INT64_MAX};
+    int r = body(plan);
+    h->dry = false;
+    if (r != 0) return r;
+    CHK(ensure_ws(h, plan.peak + 4096));
+    Bump ws{h->ws, h->ws_cap};
+    return body(ws);
+}
+
+extern "C" int sta_encode(sta_handle* h, const float* img_dev, int B, int H, int W, float* feat_dev, void* stream) {
+    CHK(check_ready(h, B, H, W));
+    REQUIRE(img_dev && feat_dev, "null device pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int hp = H / 16, wp = W / 16;
+    CHK(ensure_rope(h, hp > wp ? hp : wp));
+    const float* imgs[1] = {img_dev};
+    return plan_and_run(h, [&](Bump& ws) { return encode_impl(h, ws, imgs, 1, B, H, W, feat_dev, st); });
+}
+
+extern "C" int sta_decode(sta_handle* h, const float* feat1, const float* feat2, int B, int hp, int wp,
+                          float* const* out1, float* const* out2, void* stream) {
+    CHK(check_ready(h, B, hp * 16, wp * 16));
+    REQUIRE(feat1 && feat2, "null device pointer");
+    hipStream_t st = (hipStream_t)stream;
+    CHK(ensure_rope(h, hp > wp ? hp : wp));
+    const int N = hp * wp, D = h->cfg.dec_embed_dim;
+    const int64_t xbytes = (int64_t)2 * B * (N + 1) * D * 4;
+    return plan_and_run(h, [&](Bump& ws) {
+        float* x = (float*)ws.take(xbytes);
+        return decode_impl(h, ws, feat1, feat2, B, hp, wp, x, out1, out2, st);
+    });
+}
+
+extern "C" int sta_head_pose(sta_handle* h, const float* tok, int B, int64_t tok_stride, float* pose, float* conf, void* stream) {
+    REQUIRE(h && h->finalized, "handle not ready");
+    REQUIRE(tok && pose && conf && B > 0, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    return pose_impl(h, tok, B, tok_stride, pose, conf, (hipStream_t)stream);
+}
+
+extern "C" int sta_head_pts(sta_handle* h, const float* enc_feat, int64_t enc_bstride,
+                            const float* hook1, int64_t hook1_bstride, const float* hook2, int64_t hook2_bstride,
+                            const float* hook3, int64_t hook3_bstride, int B, int H, int W,
+                            float* pts, float* conf, void* stream) {
+    CHK(check_ready(h, B, H, W));
+    REQUIRE(enc_feat && hook1 && hook2 && hook3 && pts && conf, "null device pointer");
+    hipStream_t st = (hipStream_t)stream;
+    return plan_and_run(h, [&](Bump& ws) {
+        return dpt_impl(h, ws, enc_feat, enc_bstride, hook1, hook1_bstride, hook2, hook2_bstride, hook3, hook3_bstride,
+                        B, H, W, pts, conf, B, nullptr, nullptr, st);
+    });
+}
+
+extern "C" int sta_forward_pair(sta_handle* h, const float* img_a, const float* img_b, int B, int H, int W,
+                                float* const pts[2], float* const conf[2], float* const pose[2], float* const pose_conf[2],
+                                void* stream) {
+    CHK(check_ready(h, B, H, W));
+    REQUIRE(img_a && img_b && pts && conf && pose && pose_conf, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const sta_config& c = h->cfg;
+    const int hp = H / 16, wp = W / 16, N = hp * wp, Np = N + 1, E = c.enc_embed_dim, D = c.dec_embed_dim, S = 2 * B;
+    CHK(ensure_rope(h, hp > wp ? hp : wp));
+    const int64_t feat_b = (int64_t)S * N * E * 4, x_b = (int64_t)S * Np * D * 4;
+    if (h->timing && !h->ev_ok) { for (auto& e : h->ev) HIPCHK(hipEventCreate(&e)); h->ev_ok = true; }
+    const int dd = c.dec_depth;
+    const int hidx[3] = {dd * 2 / 4, dd * 3 / 4, dd};   // hooks [d/2+1, 3d/4+1, d+1] - 1 (dpt_head.py:112)
+    return plan_and_run(h, [&](Bump& ws) -> int {
+        const bool rec = h->timing && !h->dry;
+        float* feat = (float*)ws.take(feat_b);
+        float* x = (float*)ws.take(x_b);
+        float* hk[3] = {(float*)ws.take(x_b), (float*)ws.take(x_b), (float*)ws.take(x_b)};
+        const int64_t mark = ws.off;
+        if (rec) HIPCHK(hipEventRecord(h->ev[0], st));
+        const float* imgs[2] = {img_a, img_b};
+        CHK(encode_impl(h, ws, imgs, 2, B, H, W, feat, st));
+        if (rec) HIPCHK(hipEventRecord(h->ev[1], st));
+        ws.rewind(mark);
+        std::vector<float*> w1(dd + 1, nullptr), w2(dd + 1, nullptr);
+        for (int k = 0; k < 3; ++k) { w1[hidx[k]] = hk[k]; w2[hidx[k]] = hk[k] + (size_t)B * Np * D; }
+        CHK(decode_impl(h, ws, feat, feat + (size_t)B * N * E, B, hp, wp, x, w1.data(), w2.data(), st));
+        if (rec) HIPCHK(hipEventRecord(h->ev[2], st));
+        // pose heads read token 0 of the dec_norm'ed last layer (sta_model.py:273,277)
+        CHK(pose_impl(h, hk[2], B, (int64_t)Np * D, pose[0], pose_conf[0], st));
+        CHK(pose_impl(h, hk[2] + (size_t)B * Np * D, B, (int64_t)Np * D, pose[1], pose_conf[1], st));
+        if (rec) HIPCHK(hipEventRecord(h->ev[3], st));
+        ws.rewind(mark);
+        CHK(dpt_impl(h, ws, feat, (int64_t)N * E, hk[0] + D, (int64_t)Np * D, hk[1] + D, (int64_t)Np * D, hk[2] + D, (int64_t)Np * D,
+                     S, H, W, pts[0], conf[0], B, pts[1], conf[1], st));
+        if (rec) HIPCHK(hipEventRecord(h->ev[4], st));
+        return 0;
+    });
+}
+
+extern "C" int sta_enable_stage_timing(sta_handle* h, int on) { REQUIRE(h, "null handle"); h->timing = on != 0; return 0; }
+extern "C" int sta_get_stage_ms(sta_handle* h, float ms[4]) {
+    REQUIRE(h && h->ev_ok, "stage timing not recorded");
+    HIPCHK(hipEventSynchronize(h->ev[4]));
+    for (int i = 0; i < 4; ++i) HIPCHK(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+    return 0;
+}
+
+extern "C" int sta_rope2d_inplace(float* tokens_dev, int64_t stride_b, int64_t stride_n, const int64_t* pos_dev,
+                                  int B, int N, int Hh, int D, float base, float fwd, void* stream) {
+    REQUIRE(tokens_dev && pos_dev, "null device pointer");
+    REQUIRE(D % 4 == 0, "token dim must be multiple of 4");
+    int64_t total = (int64_t)B * N * Hh * (D / 2);
+    hipLaunchKernelGGL(rope2d_inplace_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       tokens_dev, stride_b, stride_n, pos_dev, B, N, Hh, D, base, fwd);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ FLOPs + GEMM bench
+extern "C" double sta_flops_per_pair(const sta_handle* h, int H, int W) {
+    if (!h) return 0;
+    const sta_config& c = h->cfg;
+    const double E = c.enc_embed_dim, D = c.dec_embed_dim, R = c.mlp_ratio;
+    const double hp = H / 16, wp = W / 16, N = hp * wp, Np = N + 1;
+    // per block: qkv 6NE^2 + proj 2NE^2 + mlp 4R NE^2  (R=4 -> 24 N E^2)
+    double f_enc = 2 * N * 768 * E + c.enc_depth * ((8 + 4 * R) * N * E * E + 4 * N * N * E);
+    double f_dec = 4 * N * E * D + 2.0 * c.dec_depth * ((16 + 4 * R) * Np * D * D + 8 * Np * Np * D);
+    // DPT: reference op placement (out_conv after the upsample), per view
+    auto conv = [](double hh, double ww, double ci, double co, double k) { return 2.0 * hh * ww * ci * co * k * k; };
+    double h3 = floor((hp - 1) / 2) + 1, w3 = floor((wp - 1) / 2) + 1;
+    double f = 0;
+    f += conv(hp, wp, E, 96, 1) + 2.0 * hp * wp * 96 * 96 * 16;
+    f += conv(hp, wp, D, 192, 1) + 2.0 * hp * wp * 192 * 192 * 4;
+    f += conv(hp, wp, D, 384, 1);
+    f += conv(hp, wp, D, 768, 1) + conv(h3, w3, 768, 768, 3);
+    f += conv(4 * hp, 4 * wp, 96, 256, 3) + conv(2 * hp, 2 * wp, 192, 256, 3) + conv(hp, wp, 384, 256, 3) + conv(h3, w3, 768, 256, 3);
+    f += 2 * conv(h3, w3, 256, 256, 3) + conv(hp, wp, 256, 256, 1);
+    f += 4 * conv(hp, wp, 256, 256, 3) + conv(2 * hp, 2 * wp, 256, 256, 1);
+    f += 4 * conv(2 * hp, 2 * wp, 256, 256, 3) + conv(4 * hp, 4 * wp, 256, 256, 1);
+    f += 4 * conv(4 * hp, 4 * wp, 256, 256, 3) + conv(8 * hp, 8 * wp, 256, 256, 1);
+    f += conv(8 * hp, 8 * wp, 256, 128, 3) + conv(16 * hp, 16 * wp, 128, 128, 3) + conv(16 * hp, 16 * wp, 128, 4, 1);
+    double f_pose = 2.0 * (D * 512 + 2 * 512 * 512 + 512 * 13);
+    return 2 * f_enc + f_dec + 2 * f + 2 * f_pose;
+}
+
+__global__ void fill_rand_f16_kernel(f16* p, int64_t n, uint32_t seed, float scale) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) {
+        uint32_t x = (uint32_t)i * 0x9E3779B1u + seed;
+        x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+        p[i] = (f16)(((float)(x >> 8) * (2.0f / 16777216.0f) - 1.0f) * scale);
+    }
+}
+
+extern "C" int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, float* ms_out, void* stream) {
+    REQUIRE(h && ms_out && iters > 0, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const bool split = h->prec == STA_PREC_F16X3;
+    int64_t bytes = ((int64_t)M * K + (int64_t)N * K) * 4 + (int64_t)M * N * 4 + N * 4 + (1 << 16);
+    CHK(ensure_ws(h, bytes));
+    h->dry = false;
+    Bump ws{h->ws, h->ws_cap};
+    Planes A = ws.planes((int64_t)M * K, true);
+    Lin Wt; Wt.N = N; Wt.K = K; Wt.w = ws.planes((int64_t)N * K, true);
+    Wt.bias = (float*)ws.take((int64_t)N * 4);
+    float* C = (float*)ws.take((int64_t)M * N * 4);
+    REQUIRE(!ws.overflow, "internal: bench workspace overflow");
+    hipLaunchKernelGGL(fill_rand_f16_kernel, dim3(2048), dim3(256), 0, st, A.hi, (int64_t)M * K, 1u, 1.0f);
+    hipLaunchKernelGGL(fill_rand_f16_kernel, dim3(2048), dim3(256), 0, st, A.lo, (int64_t)M * K, 2u, 4.8e-4f);
+    hipLaunchKernelGGL(fill_rand_f16_kernel, dim3(2048), dim3(256), 0, st, Wt.w.hi, (int64_t)N * K, 3u, 0.03f);
+    hipLaunchKernelGGL(fill_rand_f16_kernel, dim3(2048), dim3(256), 0, st, Wt.w.lo, (int64_t)N * K, 4u, 1.5e-5f);
+    HIPCHK(hipMemsetAsync(Wt.bias, 0, (size_t)N * 4, st));
+    if (!split) { A.lo = nullptr; }
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) CHK(gemm_f32(h, A, Wt, M, C, N, nullptr, st));
+    HIPCHK(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) CHK(gemm_f32(h, A, Wt, M, C, N, nullptr, st));
+    HIPCHK(hipEventRecord(e1, st));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / iters;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return 0;
+}
+
+#include "sta_debug.inc"

@@ -1,0 +1,41 @@
+// Shared device helpers for the MI355X (gfx950 / CDNA4) STA frontend kernels.
+// Wave = 64 lanes everywhere; no CUDA/other-arch paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 f16;
+typedef f16 half8 __attribute__((ext_vector_type(8)));
+typedef f16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+#define STA_F16_MAX 65504.0f
+
+// 2-term fp16 split: x ~= hi + lo with |lo| <= ulp(hi)/2  (~21 significant bits while lo is a
+// normal fp16, absolute floor 2^-25 below that).  Saturates instead of producing inf.
+__device__ __forceinline__ void split_f16(float x, f16& hi, f16& lo) {
+    x = fminf(fmaxf(x, -STA_F16_MAX), STA_F16_MAX);
+    hi = (f16)x;
+    lo = (f16)(x - (float)hi);
+}
+__device__ __forceinline__ f16 to_f16_sat(float x) {
+    return (f16)fminf(fmaxf(x, -STA_F16_MAX), STA_F16_MAX);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// exact-erf GELU (nn.GELU default, sta_blocks.py:60)
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ uint2 ldg8(const void* p) { return *reinterpret_cast<const uint2*>(p); }
+
+union H8 { uint4 u; half8 h; f16 e[8]; };
+union H4 { uint2 u; half4 h; f16 e[4]; };

@@ -1,0 +1,307 @@
+"""`STAFrontend`: the reference's Python call surface over the MI355X C-ABI library.
+
+Mirrors `SymmetricTwoViewAssociation` (vista_slam/sta_model/sta_model.py) as consumed by
+`OnlineSLAM` (vista_slam/slam.py:95-106,144,162,165,179-180): constructor with the reference
+defaults, `load_state_dict(strict=True)`, `.to()`, `.eval()`, `.parameters()`, and the four split
+entry points `_encode_image`, `_decode_stereo`, `head_pose_s`, `head_pts`, plus the monolithic
+`forward(views, loop_num)` (sta_model.py:247-291) and a batched `forward_pair(img_a, img_b)`.
+
+torch is used ONLY for device memory and streams (tensor allocation, `.data_ptr()`,
+`torch.cuda.current_stream()`); every FLOP runs in libsta_mi355.so.  There is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, List, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import weights as W
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class STAFrontend:
+    def __init__(self, cfg: W.STAConfig = W.FULL, device: str | torch.device = "cuda:0",
+                 precision: str = "f16x3", img_size=(224, 224)):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.StaError("STAFrontend needs a ROCm GPU (MI355X / gfx950); there is no CPU fallback")
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.StaError("STAFrontend only runs on a cuda(=ROCm) device")
+        self.img_size = img_size
+        self.dec_depth = cfg.dec_depth
+        self.dec_embed_dim = cfg.dec_embed_dim
+        self.enc_embed_dim = cfg.enc_embed_dim
+        self.patch_size = cfg.patch_size
+        self.training = False
+        c = _lib.StaConfig(cfg.patch_size, cfg.enc_embed_dim, cfg.enc_depth, cfg.enc_num_heads,
+                           cfg.dec_embed_dim, cfg.dec_depth, cfg.dec_num_heads, cfg.mlp_ratio,
+                           cfg.rope_base, cfg.ln_eps, _lib.PRECISIONS[precision])
+        h = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else 0
+        _lib.check(self.lib.sta_create(C.byref(c), idx, C.byref(h)))
+        self._h = h
+        self._finalized = False
+        self._pos_cache: Dict[tuple, torch.Tensor] = {}
+        self.precision = precision
+
+    # ------------------------------------------------------------------ nn.Module-like surface
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                self.lib.sta_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def to(self, device):
+        if torch.device(device).type != "cuda":
+            raise _lib.StaError("STAFrontend lives on the GPU it was created on")
+        return self
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("inference-only frontend (training is out of scope)")
+        return self
+
+    def parameters(self) -> Iterable[torch.Tensor]:
+        """Shape-only views (meta tensors) so `sum(p.numel() ...)` (slam.py:46) works."""
+        seen = set()
+        for name, shape, _k, _f in W.schema(self.cfg):
+            src = W._alias_of(name)
+            if src in seen:
+                continue
+            seen.add(src)
+            yield torch.empty(shape, device="meta")
+
+    def set_precision(self, precision: str):
+        _lib.check(self.lib.sta_set_precision(self._h, _lib.PRECISIONS[precision]))
+        self.precision = precision
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, state: Dict[str, "torch.Tensor | np.ndarray"], strict: bool = True):
+        if not strict:
+            raise NotImplementedError("only strict=True is supported (slam.py:100)")
+        for name, t in state.items():
+            self._load_one(name, t)
+        _lib.check(self.lib.sta_finalize_weights(self._h))   # raises on missing keys
+        self._finalized = True
+        return self
+
+    def _load_one(self, name: str, t):
+        if isinstance(t, torch.Tensor):
+            t = t.detach().to("cpu", torch.float32).contiguous().numpy()
+        a = np.ascontiguousarray(t, dtype=np.float32)
+        shape = (C.c_int64 * a.ndim)(*a.shape)
+        _lib.check(self.lib.sta_load_tensor(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim, 0))
+
+    def load_procedural(self, seed: int = 43, qk_gain: float = 1.0):
+        """Stream the deterministic procedural weights (vista_slam_amd.weights) into the library."""
+        for name, a in W.generate(self.cfg, seed=seed, qk_gain=qk_gain, reuse_buffer=True):
+            self._load_one(name, a)
+        _lib.check(self.lib.sta_finalize_weights(self._h))
+        self._finalized = True
+        return self
+
+    # ------------------------------------------------------------------ helpers
+    def _positions(self, B: int, hp: int, wp: int) -> torch.Tensor:
+        """(y,x) patch positions, int64 [B,N,2] (PositionGetter, sta_blocks.py:241-247)."""
+        key = (hp, wp)
+        if key not in self._pos_cache:
+            y = torch.arange(hp, device=self.device)
+            x = torch.arange(wp, device=self.device)
+            self._pos_cache[key] = torch.cartesian_prod(y, x)
+        return self._pos_cache[key].view(1, hp * wp, 2).expand(B, -1, 2).clone()
+
+    def _f32(self, t: torch.Tensor) -> torch.Tensor:
+        if t.device != self.device:
+            t = t.to(self.device)
+        if t.dtype != torch.float32:
+            t = t.float()
+        return t
+
+    @staticmethod
+    def _check_hw(H: int, W_: int, P: int = 16):
+        assert H % P == 0, f"Input image height ({H}) is not a multiple of patch size ({P})."
+        assert W_ % P == 0, f"Input image width ({W_}) is not a multiple of patch size ({P})."
+        assert W_ >= H, f"img should be in landscape mode, but got W={W_} H={H}"
+
+    # ------------------------------------------------------------------ split entry points
+    def _encode_image(self, image: torch.Tensor, true_shape=None, normalize: bool = True):
+        if normalize:
+            raise NotImplementedError("enc_norm is never applied on the SLAM/forward path "
+                                      "(sta_model.py:259,267; slam.py:144); normalize=True is unsupported")
+        image = self._f32(image).contiguous()
+        B, Cc, H, W_ = image.shape
+        assert Cc == 3
+        self._check_hw(H, W_, self.patch_size)
+        hp, wp = H // 16, W_ // 16
+        feat = torch.empty(B, hp * wp, self.cfg.enc_embed_dim, device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.sta_encode(self._h, image.data_ptr(), B, H, W_, feat.data_ptr(), _stream_ptr()))
+        return feat, self._positions(B, hp, wp)
+
+    def _grid_from_pos(self, pos: torch.Tensor, N: int):
+        """Recover the (hp, wp) patch grid; positions are the cartesian (y,x) grid by construction."""
+        cand = [(hp, wp) for (hp, wp) in self._pos_cache if hp * wp == N]
+        if len(cand) == 1:
+            return cand[0]
+        mx = pos[0].max(dim=0).values.tolist()     # rare path (ambiguous / foreign positions): one D2H sync
+        hp, wp = int(mx[0]) + 1, int(mx[1]) + 1
+        assert hp * wp == N, "positions are not a full (y,x) grid"
+        return hp, wp
+
+    def _decode_stereo(self, feat1: torch.Tensor, feat2: torch.Tensor, pose1: torch.Tensor, pose2: torch.Tensor,
+                       layers: Sequence[int] | None = None):
+        """Returns two lists of dec_depth+1 tensors [B, N+1, D] like the reference.  `layers`
+        (extension) restricts which list entries are materialised (others are None)."""
+        feat1 = self._f32(feat1).contiguous()
+        feat2 = self._f32(feat2).contiguous()
+        B, N, E = feat1.shape
+        assert feat2.shape == feat1.shape and E == self.cfg.enc_embed_dim
+        hp, wp = self._grid_from_pos(pose1, N)
+        L = self.cfg.dec_depth + 1
+        want = range(L) if layers is None else layers
+        D = self.cfg.dec_embed_dim
+        out1: List[torch.Tensor | None] = [None] * L
+        out2: List[torch.Tensor | None] = [None] * L
+        p1 = (C.c_void_p * L)()
+        p2 = (C.c_void_p * L)()
+        for i in want:
+            out1[i] = torch.empty(B, N + 1, D, device=self.device, dtype=torch.float32)
+            out2[i] = torch.empty(B, N + 1, D, device=self.device, dtype=torch.float32)
+            p1[i] = out1[i].data_ptr()
+            p2[i] = out2[i].data_ptr()
+        _lib.check(self.lib.sta_decode(self._h, feat1.data_ptr(), feat2.data_ptr(), B, hp, wp, p1, p2, _stream_ptr()))
+        return out1, out2
+
+    def head_pose_s(self, pose_token: torch.Tensor):
+        tok = self._f32(pose_token)
+        B, D = tok.shape
+        assert D == self.cfg.dec_embed_dim
+        if tok.stride(1) != 1:
+            tok = tok.contiguous()
+        pose = torch.empty(B, 4, 4, device=self.device, dtype=torch.float32)
+        conf = torch.empty(B, device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.sta_head_pose(self._h, tok.data_ptr(), B, tok.stride(0) if B > 1 else D,
+                                          pose.data_ptr(), conf.data_ptr(), _stream_ptr()))
+        return {"pose": pose, "conf": conf}
+
+    def _rows(self, t: torch.Tensor, N: int, Cdim: int) -> torch.Tensor:
+        t = self._f32(t)
+        assert t.shape[1] == N and t.shape[2] == Cdim, f"bad token tensor shape {tuple(t.shape)}"
+        if t.stride(2) != 1 or t.stride(1) != Cdim:
+            t = t.contiguous()
+        return t
+
+    def head_pts(self, decout: Sequence[torch.Tensor], true_shape):
+        """decout = [enc_feat] + [tok[:,1:,:] for tok in dec_list] (14 entries for depth 12);
+        only the hooks [0, d/2+1, 3d/4+1, d+1] are read (dpt_head.py:112)."""
+        ts = true_shape
+        if isinstance(ts, torch.Tensor):
+            assert bool((ts[0:1] == ts).all()), "true_shape must be all identical"
+            H, W_ = int(ts[0, 0]), int(ts[0, 1])
+        else:
+            H, W_ = int(ts[0][0]), int(ts[0][1])
+        self._check_hw(H, W_)
+        hooks = self.cfg.hooks
+        N = (H // 16) * (W_ // 16)
+        enc = self._rows(decout[hooks[0]], N, self.cfg.enc_embed_dim)
+        hk = [self._rows(decout[i], N, self.cfg.dec_embed_dim) for i in hooks[1:]]
+        B = enc.shape[0]
+        pts = torch.empty(B, H, W_, 3, device=self.device, dtype=torch.float32)
+        conf = torch.empty(B, H, W_, device=self.device, dtype=torch.float32)
+
+        def bs(t):
+            return t.stride(0) if B > 1 else t.shape[1] * t.shape[2]
+        _lib.check(self.lib.sta_head_pts(self._h, enc.data_ptr(), bs(enc), hk[0].data_ptr(), bs(hk[0]),
+                                         hk[1].data_ptr(), bs(hk[1]), hk[2].data_ptr(), bs(hk[2]),
+                                         B, H, W_, pts.data_ptr(), conf.data_ptr(), _stream_ptr()))
+        return {"pts3d": pts, "conf": conf}
+
+    # ------------------------------------------------------------------ monolithic paths
+    def forward_pair(self, img_a: torch.Tensor, img_b: torch.Tensor):
+        """Batched two-view forward == forward({'main_view':a,'neighbor_views':[b],'loop_views':[]}).
+        Returns (main, support) dicts with pts3d_pred, conf, relative_pose, relative_pose_conf."""
+        img_a = self._f32(img_a).contiguous()
+        img_b = self._f32(img_b).contiguous()
+        assert img_a.shape == img_b.shape
+        B, Cc, H, W_ = img_a.shape
+        assert Cc == 3
+        self._check_hw(H, W_)
+        outs = []
+        arrs = [(C.c_void_p * 2)() for _ in range(4)]
+        for k in range(2):
+            o = {"pts3d_pred": torch.empty(B, H, W_, 3, device=self.device, dtype=torch.float32),
+                 "conf": torch.empty(B, H, W_, device=self.device, dtype=torch.float32),
+                 "relative_pose": torch.empty(B, 4, 4, device=self.device, dtype=torch.float32),
+                 "relative_pose_conf": torch.empty(B, device=self.device, dtype=torch.float32)}
+            outs.append(o)
+            for a, key in zip(arrs, ("pts3d_pred", "conf", "relative_pose", "relative_pose_conf")):
+                a[k] = o[key].data_ptr()
+        _lib.check(self.lib.sta_forward_pair(self._h, img_a.data_ptr(), img_b.data_ptr(), B, H, W_,
+                                             arrs[0], arrs[1], arrs[2], arrs[3], _stream_ptr()))
+        return outs[0], outs[1]
+
+    def forward(self, views: dict, loop_num: int = 0):
+        main_view = views["main_view"]
+        support = list(views["neighbor_views"]) + list(views["loop_views"])   # eval: all loop views (sta_model.py:252-255)
+        main_res, supp_res = [], []
+        for v in support:
+            m, s = self.forward_pair(main_view["img"], v["img"])
+            main_res.append(m)
+            supp_res.append(s)
+        return {"main_views": main_res, "support_views": supp_res}
+
+    __call__ = forward
+
+    # ------------------------------------------------------------------ introspection
+    def flops_per_pair(self, H: int, W_: int) -> float:
+        return float(self.lib.sta_flops_per_pair(self._h, H, W_))
+
+    def enable_stage_timing(self, on: bool = True):
+        _lib.check(self.lib.sta_enable_stage_timing(self._h, int(on)))
+
+    def stage_ms(self):
+        ms = (C.c_float * 4)()
+        _lib.check(self.lib.sta_get_stage_ms(self._h, ms))
+        return dict(zip(("encode", "decode", "pose", "dpt"), [float(x) for x in ms]))
+
+    def bench_gemm(self, M: int, N: int, K: int, iters: int = 20) -> float:
+        ms = C.c_float()
+        _lib.check(self.lib.sta_bench_gemm(self._h, M, N, K, iters, C.byref(ms), _stream_ptr()))
+        return float(ms.value)
+
+    def workspace_bytes(self) -> int:
+        return int(self.lib.sta_workspace_bytes(self._h))
+
+
+def rope2d_inplace(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: float = 1.0):
+    """curope.rope_2d drop-in (pos_embed/curope/curope.cpp:49-65): tokens (B,N,H,D) fp32 CUDA view with
+    stride(3)==1 and stride(2)==D, positions (B,N,2) int64 contiguous; rotates in place."""
+    lib = _lib.load()
+    assert tokens.dim() == 4, "tokens must have 4 dimensions"
+    assert positions.dim() == 3, "positions must have 3 dimensions"
+    assert tokens.size(0) == positions.size(0), "batch size differs between tokens & positions"
+    assert tokens.size(1) == positions.size(1), "seq_length differs between tokens & positions"
+    assert positions.size(2) == 2, "positions.shape[2] must be equal to 2"
+    assert tokens.is_cuda and positions.is_cuda, "tokens and positions must be on the GPU"
+    assert tokens.dtype == torch.float32 and positions.dtype == torch.int64
+    B, N, Hh, D = tokens.shape
+    assert tokens.stride(3) == 1 and tokens.stride(2) == D, "tokens are not contiguous"
+    assert positions.is_contiguous(), "positions are not contiguous"
+    assert D % 4 == 0, "token dim must be multiple of 4"
+    _lib.check(lib.sta_rope2d_inplace(tokens.data_ptr(), tokens.stride(0), tokens.stride(1), positions.data_ptr(),
+                                      B, N, Hh, D, float(base), float(fwd), _stream_ptr()))
+    return tokens
