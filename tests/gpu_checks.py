@@ -83,7 +83,8 @@ def check_qkv_rope(precision, S=2, hp=3, wp=4, pose_tok=1, K=128, Cdim=128, seed
     q = torch.empty(S, heads, ntok, 64, device=DEV)
     k = torch.empty_like(q)
     vt = torch.empty(S * heads * 64, npad, device=DEV)
-    _lib.check(lib.sta_debug_qkv_rope(h, x.to(DEV).data_ptr(), Wt.to(DEV).data_ptr(), b.to(DEV).data_ptr(), S, ntok, K, Cdim,
+    xd, Wd, bd = x.to(DEV), Wt.to(DEV), b.to(DEV)      # keep device inputs alive across the call
+    _lib.check(lib.sta_debug_qkv_rope(h, xd.data_ptr(), Wd.data_ptr(), bd.data_ptr(), S, ntok, K, Cdim,
                                       wp, pose_tok, q.data_ptr(), k.data_ptr(), vt.data_ptr(), st()))
     torch.cuda.synchronize()
     y = (x.double() @ Wt.double().T + b.double()).float().reshape(S, ntok, 3, heads, 64).permute(2, 0, 3, 1, 4).numpy()
@@ -105,7 +106,8 @@ def check_attention(precision, S=2, heads=2, nq=197, nk=197, kv_shift=0, sharp=1
     a = (q.double() @ k[idx].double().transpose(-1, -2)) * 0.125
     ref = (a.softmax(-1) @ v[idx].double()).permute(0, 2, 1, 3).reshape(S, nq, heads * 64)
     out = torch.empty(S, nq, heads * 64, device=DEV)
-    _lib.check(lib.sta_debug_attention(h, q.to(DEV).data_ptr(), k.to(DEV).data_ptr(), v.to(DEV).data_ptr(), S, heads, nq, nk,
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    _lib.check(lib.sta_debug_attention(h, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), S, heads, nq, nk,
                                        kv_shift, out.data_ptr(), st()))
     torch.cuda.synchronize()
     o = out.cpu().numpy()
@@ -129,7 +131,8 @@ def check_conv3(precision, n=2, H=7, W_=5, Cin=32, Co=48, stride=1, relu_in=0, a
     out = torch.empty(n, Ho, Wo, Co, device=DEV)
     xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
     Rd = R.permute(0, 2, 3, 1).contiguous().to(DEV) if resid else None
-    _lib.check(lib.sta_debug_conv3x3(h, xd.data_ptr(), w.to(DEV).data_ptr(), b.to(DEV).data_ptr(), n, H, W_, Cin, Co, stride,
+    wd, bd = w.to(DEV), b.to(DEV)
+    _lib.check(lib.sta_debug_conv3x3(h, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), n, H, W_, Cin, Co, stride,
                                      relu_in, act, Rd.data_ptr() if resid else None, out.data_ptr(), st()))
     torch.cuda.synchronize()
     o = out.cpu().permute(0, 3, 1, 2).numpy()
@@ -144,8 +147,8 @@ def check_convt(precision, n=2, H=3, W_=5, Cdim=96, k=4, seed=4):
     b = torch.randn(Cdim, generator=g)
     ref = torch.nn.functional.conv_transpose2d(x.double(), w.double(), b.double(), stride=k)
     out = torch.empty(n, H * k, W_ * k, Cdim, device=DEV)
-    _lib.check(lib.sta_debug_convt(h, x.permute(0, 2, 3, 1).contiguous().to(DEV).data_ptr(), w.to(DEV).data_ptr(),
-                                   b.to(DEV).data_ptr(), n, H, W_, Cdim, k, out.data_ptr(), st()))
+    xd, wd, bd = x.permute(0, 2, 3, 1).contiguous().to(DEV), w.to(DEV), b.to(DEV)
+    _lib.check(lib.sta_debug_convt(h, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), n, H, W_, Cdim, k, out.data_ptr(), st()))
     torch.cuda.synchronize()
     o = out.cpu().permute(0, 3, 1, 2).numpy()
     return {"rel_l2": rel_l2(o, ref.numpy()), "max_rel": max_rel(o, ref.numpy())}
@@ -159,8 +162,8 @@ def check_up2(precision, n=2, H=7, W_=5, Cdim=16, crop=None, seed=5):
     Hc, Wc = crop if crop else (2 * H, 2 * W_)
     ref = ref[:, :, :Hc, :Wc]
     out = torch.empty(n, Hc, Wc, Cdim, device=DEV)
-    _lib.check(lib.sta_debug_up2(h, x.permute(0, 2, 3, 1).contiguous().to(DEV).data_ptr(), n, H, W_, Cdim, Hc, Wc,
-                                 out.data_ptr(), st()))
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    _lib.check(lib.sta_debug_up2(h, xd.data_ptr(), n, H, W_, Cdim, Hc, Wc, out.data_ptr(), st()))
     torch.cuda.synchronize()
     o = out.cpu().permute(0, 3, 1, 2).numpy()
     return {"rel_l2": rel_l2(o, ref.numpy()), "max_rel": max_rel(o, ref.numpy())}
@@ -175,7 +178,8 @@ def check_layernorm(precision, M=37, Cdim=768, seed=6):
     ref = torch.nn.functional.layer_norm(x.double(), (Cdim,), w.double(), b.double(), eps=1e-6).numpy()
     o32 = torch.empty(M, Cdim, device=DEV)
     op = torch.empty(M, Cdim, device=DEV)
-    _lib.check(lib.sta_debug_layernorm(h, x.to(DEV).data_ptr(), w.to(DEV).data_ptr(), b.to(DEV).data_ptr(), M, Cdim, 1e-6,
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    _lib.check(lib.sta_debug_layernorm(h, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), M, Cdim, 1e-6,
                                        o32.data_ptr(), op.data_ptr(), st()))
     torch.cuda.synchronize()
     return {"f32": max_rel(o32.cpu().numpy(), ref), "planes": max_rel(op.cpu().numpy(), ref)}
@@ -188,27 +192,31 @@ def check_ops_golden(precision):
     res = {}
     # RoPE2D in place (curope drop-in), tokens given as (B,H,N,D) -> kernel layout (B,N,H,D)
     tok = dev(g["rope_tok"]).permute(0, 2, 1, 3).contiguous()
-    rope2d_inplace(tok, dev(g["rope_pos"]), 100.0, 1.0)
+    rpos = dev(g["rope_pos"])
+    rope2d_inplace(tok, rpos, 100.0, 1.0)
     res["rope2d"] = max_rel(tok.permute(0, 2, 1, 3).cpu().numpy(), g["rope_out"])
     # inverse rotation (fwd = -1) restores the input (curope backward, curope2d.py:24-29)
-    rope2d_inplace(tok, dev(g["rope_pos"]), 100.0, -1.0)
+    rope2d_inplace(tok, rpos, 100.0, -1.0)
     res["rope2d_roundtrip"] = max_rel(tok.permute(0, 2, 1, 3).cpu().numpy(), g["rope_tok"])
     # LayerNorm eps 1e-6
     M, Cd = g["ln_x"].shape
     o32 = torch.empty(M, Cd, device=DEV); op = torch.empty(M, Cd, device=DEV)
-    _lib.check(lib.sta_debug_layernorm(h, dev(g["ln_x"]).data_ptr(), dev(g["ln_w"]).data_ptr(), dev(g["ln_b"]).data_ptr(),
+    lx, lw, lb = dev(g["ln_x"]), dev(g["ln_w"]), dev(g["ln_b"])
+    _lib.check(lib.sta_debug_layernorm(h, lx.data_ptr(), lw.data_ptr(), lb.data_ptr(),
                                        M, Cd, 1e-6, o32.data_ptr(), op.data_ptr(), st()))
     res["layernorm"] = max_rel(o32.cpu().numpy(), g["ln_out"])
     # SVD orthogonalisation incl. reflection / near-singular inputs
     B = g["svd_in"].shape[0]
     r = torch.empty(B, 3, 3, device=DEV)
-    _lib.check(lib.sta_debug_svd_orthogonalize(h, dev(g["svd_in"]).data_ptr(), r.data_ptr(), B, st()))
+    sv = dev(g["svd_in"])
+    _lib.check(lib.sta_debug_svd_orthogonalize(h, sv.data_ptr(), r.data_ptr(), B, st()))
     res["svd_orth"] = float(np.abs(r.cpu().numpy() - g["svd_out"]).max())
     # bilinear x2 align_corners, odd size: channels padded to 8
     x = g["bilin_x"]
     xp = np.zeros((1, 8, x.shape[2], x.shape[3]), np.float32); xp[:, :3] = x
     out = torch.empty(1, 2 * x.shape[2], 2 * x.shape[3], 8, device=DEV)
-    _lib.check(lib.sta_debug_up2(h, dev(xp.transpose(0, 2, 3, 1)).data_ptr(), 1, x.shape[2], x.shape[3], 8,
+    xpd = dev(xp.transpose(0, 2, 3, 1))
+    _lib.check(lib.sta_debug_up2(h, xpd.data_ptr(), 1, x.shape[2], x.shape[3], 8,
                                  2 * x.shape[2], 2 * x.shape[3], out.data_ptr(), st()))
     res["bilinear"] = max_rel(out.cpu().numpy().transpose(0, 3, 1, 2)[:, :3], g["bilin_out"])
     # postprocess through head_final: weights = identity on the first 4 channels
@@ -217,7 +225,8 @@ def check_ops_golden(precision):
     feat = np.zeros((npix, 128), np.float32); feat[:, :4] = pin[0].reshape(4, npix).T
     w4 = np.zeros((4, 128), np.float32); w4[np.arange(4), np.arange(4)] = 1.0
     pts = torch.empty(npix, 3, device=DEV); conf = torch.empty(npix, device=DEV)
-    _lib.check(lib.sta_debug_head_final(h, dev(feat).data_ptr(), dev(w4).data_ptr(), dev(np.zeros(4, np.float32)).data_ptr(),
+    fd, w4d, b4d = dev(feat), dev(w4), dev(np.zeros(4, np.float32))
+    _lib.check(lib.sta_debug_head_final(h, fd.data_ptr(), w4d.data_ptr(), b4d.data_ptr(),
                                         npix, pts.data_ptr(), conf.data_ptr(), st()))
     res["post_pts"] = max_rel(pts.cpu().numpy().reshape(pin.shape[2], pin.shape[3], 3), g["post_pts"][0])
     res["post_conf"] = max_rel(conf.cpu().numpy().reshape(pin.shape[2], pin.shape[3]), g["post_conf"][0])

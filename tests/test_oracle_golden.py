@@ -1,0 +1,80 @@
+"""CPU: pin the oracle (oracle/sta_oracle.py + sta_oracle_ops.c) against golden vectors generated
+from the REFERENCE PyTorch model (oracle/gen_golden.py imports /root/reference in the build container).
+The reference ships no tests of its own, so these fixtures are the pin."""
+import numpy as np
+import pytest
+
+from helpers import load_golden, rel_l2, max_rel
+from oracle import sta_oracle as O
+from vista_slam_amd import weights as W
+
+TOL = 2e-5          # fp32 reduction-order noise floor of the full forward (default weights)
+TOL_SHARP = 2e-4    # peaky-attention sets amplify fp32 noise (oracle vs reference, both fp32)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    return load_golden("ops")[0]
+
+
+def test_rope2d(ops):
+    assert max_rel(O.rope2d(ops["rope_tok"], ops["rope_pos"], 100.0), ops["rope_out"]) < 2e-6
+
+
+def test_layernorm_gelu(ops):
+    assert max_rel(O.layernorm(ops["ln_x"], ops["ln_w"], ops["ln_b"], 1e-6), ops["ln_out"]) < 2e-6
+    assert max_rel(O.gelu(ops["gelu_x"]), ops["gelu_out"]) < 2e-6
+
+
+@pytest.mark.parametrize("k", [4, 2])
+def test_conv_transpose(ops, k):
+    y = O.conv_transpose2d(ops[f"convt{k}_x"], ops[f"convt{k}_w"], ops[f"convt{k}_b"], k)
+    assert max_rel(y, ops[f"convt{k}_out"]) < 2e-6
+
+
+@pytest.mark.parametrize("tag", ["odd", "even"])
+def test_conv3x3_stride2(ops, tag):
+    y = O.conv2d(ops[f"conv3s2_{tag}_x"], ops[f"conv3s2_{tag}_w"], ops[f"conv3s2_{tag}_b"], 2, 1)
+    assert y.shape == ops[f"conv3s2_{tag}_out"].shape
+    assert max_rel(y, ops[f"conv3s2_{tag}_out"]) < 2e-6
+
+
+def test_bilinear_align_corners(ops):
+    assert max_rel(O.bilinear_up2(ops["bilin_x"]), ops["bilin_out"]) < 2e-6
+
+
+def test_svd_orthogonalize_incl_reflection(ops):
+    r = O.svd_orthogonalize(ops["svd_in"])
+    assert np.abs(r - ops["svd_out"]).max() < 5e-6
+    assert np.allclose(np.linalg.det(r.astype(np.float64)), 1.0, atol=1e-5)
+
+
+def test_postprocess(ops):
+    pts, conf = O.postprocess(ops["post_in"])
+    assert max_rel(pts, ops["post_pts"]) < 2e-6 and max_rel(conf, ops["post_conf"]) < 2e-6
+    assert np.all(pts[0, 0, 0] == 0)            # zero-norm pixel: clip(1e-8) path
+
+
+@pytest.mark.parametrize("case", ["tiny_32x32_b1", "tiny_48x64_b2", "tiny_48x64_b2_sharp", "tiny_48x80_smooth_sharp"])
+def test_forward_vs_reference_golden(case):
+    g, meta = load_golden(case)
+    H, W_, B = int(meta["H"]), int(meta["W"]), int(meta["B"])
+    sd = W.state_dict(W.TINY, seed=int(meta["seed"]), qk_gain=float(meta["qk_gain"]))
+    gen = W.smooth_images if int(meta["smooth"]) else W.synth_images
+    imgs = gen(2 * B, H, W_, seed=int(meta["seed"]), tag=0)
+    r = O.forward_pair(W.TINY, sd, imgs[:B], imgs[B:])
+    tol = TOL_SHARP if float(meta["qk_gain"]) != 1.0 else TOL
+    errs = {}
+    for side in ("main", "supp"):
+        errs[f"{side}_pts3d"] = rel_l2(r[side]["pts3d"], g[f"{side}_pts3d"])
+        errs[f"{side}_conf"] = rel_l2(r[side]["conf"], g[f"{side}_conf"])
+        errs[f"{side}_pose"] = rel_l2(r[side]["pose"], g[f"{side}_pose"])
+        errs[f"{side}_pose_conf"] = rel_l2(r[side]["pose_conf"], g[f"{side}_pose_conf"])
+    errs["enc_feat_a"] = rel_l2(r["enc_feat_a"], g["enc_feat_a"])
+    for hk in W.TINY.hooks[1:]:
+        errs[f"dec1_hook{hk - 1}"] = rel_l2(r["dec1"][hk - 1], g[f"dec1_hook{hk - 1}"])
+        errs[f"dec2_hook{hk - 1}"] = rel_l2(r["dec2"][hk - 1], g[f"dec2_hook{hk - 1}"])
+    bad = {k: v for k, v in errs.items() if v > tol}
+    assert not bad, bad
+    if "tap_dpt_path1_0" in g:        # intermediate taps (tiny_32x32_b1): decoder input
+        assert rel_l2(r["dec1"][0], g["dec1_in"]) < TOL
