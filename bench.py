@@ -1,0 +1,155 @@
+#!/usr/bin/env python
+"""bench.py - STA two-view image-pairs/sec on synthetic 512x384 RGB pairs (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole hot path (2 x encode + decode + 2 x pose head + 2 x DPT head,
+sta_model.py:247-291) over a batch of 8 synthetic image pairs per GPU, inputs resident in HBM.
+Pairs are independent units: ranks process disjoint pairs (weak scaling); the only exchange is one
+RCCL all-gather per step of the compact per-pair outputs a SLAM consumer reads (pose 4x4, pose
+confidence, depth = pts[...,2] and the confidence map; slam.py:165-185).
+
+Prints ONE JSON line on rank 0 with the throughput, the roofline of the dominant kernel (live HIP
+event timing of every launch of gemm_kernel<.., dense, fp32-epilogue> inside the timed region) and
+a CPU baseline (the oracle restatement timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W_, PAIRS_PER_GPU = 384, 512, 8
+PEAK_F16_MFMA_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def cpu_baseline():
+    """Oracle (port of the reference algorithm, fp32, OpenMP) on the host cores: one 224x224 pair
+    (BASELINE config 1 shape) - a bounded sample (~10-30 s) of the same per-pair workload."""
+    import numpy as np  # noqa: F401
+    from oracle import sta_oracle as O
+    from vista_slam_amd import weights as Wt
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    sd = Wt.state_dict(Wt.FULL, seed=43)
+    imgs = Wt.synth_images(2, 224, 224, seed=43, tag=0)
+    t0 = time.perf_counter()
+    O.forward_pair(Wt.FULL, sd, imgs[:1], imgs[1:])
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 5), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"1 pair @224x224 (435.8 GFLOP, {dt:.1f} s); the 512x384 pair is 4.26x the FLOPs",
+            "gflops": round(435.81 / dt, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16"])
+    ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="image pairs per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from vista_slam_amd import weights as Wt
+    from vista_slam_amd.sta_frontend import STAFrontend
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+
+    model = STAFrontend(Wt.FULL, dev, precision=args.precision).load_procedural(seed=43)
+    B = args.pairs
+    imgs = Wt.synth_images(2 * B, H, W_, seed=43, tag=rank)          # different pairs on every rank
+    img_a = torch.from_numpy(imgs[:B]).to(dev)
+    img_b = torch.from_numpy(imgs[B:]).to(dev)
+
+    gathered = None
+    if world > 1:
+        compact_elems = 2 * B * (16 + 1 + 2 * H * W_)
+        gathered = torch.empty(world * compact_elems, device=dev)
+
+    def step():
+        main_o, supp_o = model.forward_pair(img_a, img_b)
+        if world > 1:   # compact per-pair outputs -> every rank (slam.py consumes pose, conf, depth, conf map)
+            parts = []
+            for o in (main_o, supp_o):
+                parts += [o["relative_pose"].reshape(-1), o["relative_pose_conf"].reshape(-1),
+                          o["pts3d_pred"][..., 2].reshape(-1), o["conf"].reshape(-1)]
+            dist.all_gather_into_tensor(gathered, torch.cat(parts))
+        return main_o, supp_o
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    if not args.no_kernel_timing:
+        model.kernel_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert bool(torch.isfinite(out[0]["pts3d_pred"]).all()), "non-finite output"
+
+    roof = None
+    if not args.no_kernel_timing:
+        n, ms, fl = model.kernel_timing_read()
+        model.kernel_timing(False)
+        if n > 0 and ms > 0:
+            ach = fl / (ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm_kernel<SPLIT,A_DENSE,EPI_F32> (attn.proj / mlp.fc2 / embeds)",
+                    "achieved": round(ach, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
+                    "mfma_products_per_flop": 3 if args.precision == "f16x3" else 1,
+                    "issued_frac": round(ach * (3 if args.precision == "f16x3" else 1) / PEAK_F16_MFMA_TFLOPS, 4)}
+
+    if rank == 0:
+        pairs = B * world * args.steps
+        flops_pair = model.flops_per_pair(H, W_)
+        res = {"metric": "STA image-pairs/sec @512x384", "value": round(pairs / dt, 3), "unit": "pairs/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f16x3-split MFMA, fp32 accumulate" if args.precision == "f16x3" else "f16 MFMA, fp32 accumulate",
+               "data": "synthetic (uint8-uniform RGB pairs, procedural weights of the full 438M-parameter architecture)",
+               "config": {"workload": f"512x384 batch={B} pairs/GPU STA two-view forward (BASELINE configs[1])",
+                          "pairs_per_gpu": B, "H": H, "W": W_, "precision": args.precision,
+                          "parallelism": f"pair-sharded x{world}, RCCL all-gather of compact outputs" if world > 1 else "single GPU"},
+               "gflop_per_pair": round(flops_pair / 1e9, 2),
+               "whole_path_tflops": round(pairs * flops_pair / dt / 1e12, 1),
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline()
+            except Exception as e:   # noqa: BLE001  (the baseline is a report, never the product)
+                res["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -143,6 +143,13 @@ int64_t sta_weight_bytes(const sta_handle* h);
 int sta_enable_stage_timing(sta_handle* h, int on);
 int sta_get_stage_ms(sta_handle* h, float ms[4]);
 
+/* Per-launch hipEvent timing of the dominant kernel (gemm_kernel<.., dense, fp32 epilogue>: the
+ * proj / fc2 / embed GEMMs) on the stream it is launched on.  enable!=0 resets the counters and
+ * starts recording; sta_kernel_timing_read synchronises on the recorded events and returns the
+ * number of launches, the summed kernel time and the summed algorithmic FLOPs (2*M*N*K). */
+int sta_kernel_timing(sta_handle* h, int enable);
+int sta_kernel_timing_read(sta_handle* h, int* launches, double* total_ms, double* total_flops);
+
 /* Time `iters` back-to-back launches of the dominant GEMM kernel (M x N x K, this handle's
  * precision) with hipEvents on `stream`; returns average ms per launch in *ms_out. */
 int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, float* ms_out, void* stream);

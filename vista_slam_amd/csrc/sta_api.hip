@@ -67,6 +67,8 @@ struct sta_handle {
     float* rope_tab = nullptr; int rope_P = 0;
     // timing
     bool timing = false; hipEvent_t ev[5]; bool ev_ok = false;
+    // per-launch timing of the dominant kernel (gemm_kernel<*, A_DENSE, EPI_F32>) for the roofline report
+    bool ktime = false; std::vector<hipEvent_t> kev; int kn = 0; std::vector<double> kflops;
     bool dry = false;   // planning pass: run the orchestration without launching to size the workspace
 };
 
@@ -292,6 +294,7 @@ extern "C" int sta_destroy(sta_handle* h) {
     if (h->ws) hipFree(h->ws);
     if (h->rope_tab) hipFree(h->rope_tab);
     if (h->ev_ok) for (auto& e : h->ev) hipEventDestroy(e);
+    for (auto& e : h->kev) hipEventDestroy(e);
     delete h;
     return 0;
 }
@@ -363,6 +366,17 @@ static int launch_gemm(sta_handle* h, const GemmParams& p, hipStream_t st) {
     if (h->dry) return 0;
     int tm = (p.M + GEMM_BM - 1) / GEMM_BM, tn = (p.N + GEMM_BN - 1) / GEMM_BN;
     dim3 grid((unsigned)(tm * tn));
+    const bool timed = h->ktime && AMODE == A_DENSE && EPI == EPI_F32;
+    if (timed) {
+        if ((int)h->kev.size() < 2 * (h->kn + 1)) {
+            hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+            h->kev.push_back(a); h->kev.push_back(b);
+        }
+        if ((int)h->kflops.size() <= h->kn) h->kflops.resize(h->kn + 1);
+        h->kflops[h->kn] = 2.0 * p.M * p.N * p.K;
+        HIPCHK(hipEventRecord(h->kev[2 * h->kn], st));
+        h->kn++;
+    }
     if (h->prec == STA_PREC_F16X3) {
         static bool attr_done = false;
         if (!attr_done) {
@@ -374,6 +388,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p, hipStream_t st) {
         hipLaunchKernelGGL((gemm_kernel<false, AMODE, EPI>), grid, dim3(256), gemm_smem_bytes<false>(), st, p);
     }
     HIPCHK(hipGetLastError());
+    if (timed) HIPCHK(hipEventRecord(h->kev[2 * (h->kn - 1) + 1], st));
     return 0;
 }
 
@@ -828,6 +843,24 @@ extern "C" int sta_forward_pair(sta_handle* h, const float* img_a, const float* 
         if (rec) HIPCHK(hipEventRecord(h->ev[4], st));
         return 0;
     });
+}
+
+extern "C" int sta_kernel_timing(sta_handle* h, int enable) {
+    REQUIRE(h, "null handle");
+    h->ktime = enable != 0; h->kn = 0;
+    return 0;
+}
+extern "C" int sta_kernel_timing_read(sta_handle* h, int* launches, double* total_ms, double* total_flops) {
+    REQUIRE(h && launches && total_ms && total_flops, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    double ms = 0, fl = 0;
+    for (int i = 0; i < h->kn; ++i) {
+        HIPCHK(hipEventSynchronize(h->kev[2 * i + 1]));
+        float t = 0; HIPCHK(hipEventElapsedTime(&t, h->kev[2 * i], h->kev[2 * i + 1]));
+        ms += t; fl += h->kflops[i];
+    }
+    *launches = h->kn; *total_ms = ms; *total_flops = fl;
+    return 0;
 }
 
 extern "C" int sta_enable_stage_timing(sta_handle* h, int on) { REQUIRE(h, "null handle"); h->timing = on != 0; return 0; }

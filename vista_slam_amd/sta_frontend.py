@@ -278,6 +278,14 @@ class STAFrontend:
         _lib.check(self.lib.sta_get_stage_ms(self._h, ms))
         return dict(zip(("encode", "decode", "pose", "dpt"), [float(x) for x in ms]))
 
+    def kernel_timing(self, on: bool = True):
+        _lib.check(self.lib.sta_kernel_timing(self._h, int(on)))
+
+    def kernel_timing_read(self):
+        n, ms, fl = C.c_int(), C.c_double(), C.c_double()
+        _lib.check(self.lib.sta_kernel_timing_read(self._h, C.byref(n), C.byref(ms), C.byref(fl)))
+        return int(n.value), float(ms.value), float(fl.value)
+
     def bench_gemm(self, M: int, N: int, K: int, iters: int = 20) -> float:
         ms = C.c_float()
         _lib.check(self.lib.sta_bench_gemm(self._h, M, N, K, iters, C.byref(ms), _stream_ptr()))
