@@ -151,8 +151,10 @@ int sta_kernel_timing(sta_handle* h, int enable);
 int sta_kernel_timing_read(sta_handle* h, int* launches, double* total_ms, double* total_flops);
 
 /* Time `iters` back-to-back launches of the dominant GEMM kernel (M x N x K, this handle's
- * precision) with hipEvents on `stream`; returns average ms per launch in *ms_out. */
-int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, float* ms_out, void* stream);
+ * precision, random operands) with hipEvents on `stream`; average ms per launch in *ms_out.
+ * tile: 0 = product selection, 1 = 128x128, 2 = 256x256, 3 = 256x128.  ablation (tile 2/3 only,
+ * bench-only kernel variants): 0 none, 1 no DMA in the K loop, 2 DMA+barriers only, 3 MFMA only. */
+int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, int tile, int ablation, float* ms_out, void* stream);
 
 const char* sta_last_error(void);
 const char* sta_version(void);

@@ -13,6 +13,11 @@
 extern "C" {
 #endif
 
+/* Force the GEMM tile family: 0 = automatic (product behaviour), 1 = 128x128 register-staged kernel,
+ * 2 = 256-row direct-to-LDS kernel (whenever N % 128 == 0).  Lets the tests cover both families on
+ * small shapes. */
+int sta_set_gemm_variant(sta_handle* h, int variant);
+
 /* nn.Linear (+GELU/ReLU, +residual): out[M,N] = act(A[M,K] W[N,K]^T + bias) (+resid).
  * act: 0 none, 1 erf-GELU, 2 ReLU.  via_f16 != 0 uses the fp16-plane epilogue (sta_blocks.py:73-79). */
 int sta_debug_gemm(sta_handle* h, const float* A, const float* W, const float* bias, int M, int N, int K,

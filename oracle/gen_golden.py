@@ -172,6 +172,7 @@ def gen_ops():
 
 
 CASES = {
+    "sharpfull": [dict(name="full_224_b1_sharp", cfg=W.FULL, H=224, W_=224, B=1, sub=8, qk_gain=3.0)],
     "tiny": [
         dict(name="tiny_32x32_b1", cfg=W.TINY, H=32, W_=32, B=1, taps=True),
         dict(name="tiny_48x64_b2", cfg=W.TINY, H=48, W_=64, B=2),
@@ -180,7 +181,11 @@ CASES = {
     ],
     "full224": [
         dict(name="full_224_b1", cfg=W.FULL, H=224, W_=224, B=1, sub=8),
-        dict(name="full_224_b1_sharp", cfg=W.FULL, H=224, W_=224, B=1, sub=8, qk_gain=6.0),
+        # qk_gain 3: peaky attention yet still well conditioned at full depth (reference fp32 vs fp64 on the
+        # encoder: 4e-6).  At gain 6 the 36-layer model is chaotic - the reference's own fp32-vs-fp64
+        # difference is 3e-2 and a 1e-6 input perturbation moves the output by 3.5e-2 - so it cannot
+        # serve as a parity target (measured with /root/reference, see DESIGN.md "Precision").
+        dict(name="full_224_b1_sharp", cfg=W.FULL, H=224, W_=224, B=1, sub=8, qk_gain=3.0),
     ],
     "full512": [
         dict(name="full_384x512_b1", cfg=W.FULL, H=384, W_=512, B=1, sub=16),

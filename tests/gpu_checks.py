@@ -42,14 +42,19 @@ def drop_models():
     torch.cuda.empty_cache()
 
 
-def kernel_handle(precision):
+def kernel_handle(precision, variant=0):
     m = model("tiny", 1.0, precision)
+    _lib.check(m.lib.sta_set_gemm_variant(m._h, variant))
     return m, m.lib, m._h
 
 
+def set_variant(m, variant):
+    _lib.check(m.lib.sta_set_gemm_variant(m._h, variant))
+
+
 # ------------------------------------------------------------------------------------------ kernels
-def check_gemm(precision, M=300, N=200, K=96, act=0, via_f16=0, resid=False, seed=0):
-    m, lib, h = kernel_handle(precision)
+def check_gemm(precision, M=300, N=200, K=96, act=0, via_f16=0, resid=False, seed=0, variant=0):
+    m, lib, h = kernel_handle(precision, variant)
     g = torch.Generator().manual_seed(seed)
     A = torch.randn(M, K, generator=g) * 1.3
     Wt = torch.randn(N, K, generator=g) * 0.1
@@ -71,8 +76,8 @@ def check_gemm(precision, M=300, N=200, K=96, act=0, via_f16=0, resid=False, see
     return {"rel_l2": rel_l2(out.cpu().numpy(), ref.numpy()), "max_rel": max_rel(out.cpu().numpy(), ref.numpy())}
 
 
-def check_qkv_rope(precision, S=2, hp=3, wp=4, pose_tok=1, K=128, Cdim=128, seed=1):
-    m, lib, h = kernel_handle(precision)
+def check_qkv_rope(precision, S=2, hp=3, wp=4, pose_tok=1, K=128, Cdim=128, seed=1, variant=0):
+    m, lib, h = kernel_handle(precision, variant)
     g = torch.Generator().manual_seed(seed)
     ntok = hp * wp + pose_tok
     x = torch.randn(S * ntok, K, generator=g)
@@ -114,8 +119,8 @@ def check_attention(precision, S=2, heads=2, nq=197, nk=197, kv_shift=0, sharp=1
     return {"rel_l2": rel_l2(o, ref.numpy()), "max_rel": max_rel(o, ref.numpy()), "nan": float(np.isnan(o).sum())}
 
 
-def check_conv3(precision, n=2, H=7, W_=5, Cin=32, Co=48, stride=1, relu_in=0, act=0, resid=False, seed=3):
-    m, lib, h = kernel_handle(precision)
+def check_conv3(precision, n=2, H=7, W_=5, Cin=32, Co=48, stride=1, relu_in=0, act=0, resid=False, seed=3, variant=0):
+    m, lib, h = kernel_handle(precision, variant)
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n, Cin, H, W_, generator=g)
     w = torch.randn(Co, Cin, 3, 3, generator=g) * 0.1
@@ -139,8 +144,8 @@ def check_conv3(precision, n=2, H=7, W_=5, Cin=32, Co=48, stride=1, relu_in=0, a
     return {"rel_l2": rel_l2(o, ref.numpy()), "max_rel": max_rel(o, ref.numpy())}
 
 
-def check_convt(precision, n=2, H=3, W_=5, Cdim=96, k=4, seed=4):
-    m, lib, h = kernel_handle(precision)
+def check_convt(precision, n=2, H=3, W_=5, Cdim=96, k=4, seed=4, variant=0):
+    m, lib, h = kernel_handle(precision, variant)
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n, Cdim, H, W_, generator=g)
     w = torch.randn(Cdim, Cdim, k, k, generator=g) * 0.1
@@ -235,11 +240,12 @@ def check_ops_golden(precision):
 
 
 # ------------------------------------------------------------------------------------------ end to end
-def run_golden_case(name, precision, taps=True):
+def run_golden_case(name, precision, taps=True, variant=0):
     """HIP forward on the procedural inputs of a golden case; returns {key: rel-L2 error}."""
     g, meta = load_golden(name)
     cfg_name = "tiny" if int(meta["cfg_enc_embed_dim"]) == W.TINY.enc_embed_dim else "full"
     m = model(cfg_name, float(meta["qk_gain"]), precision)
+    set_variant(m, variant)
     cfg = m.cfg
     H, W_, B, sub = int(meta["H"]), int(meta["W"]), int(meta["B"]), int(meta["sub"])
     gen = W.smooth_images if int(meta["smooth"]) else W.synth_images

@@ -1,0 +1,75 @@
+"""CPU, world_size=2, gloo: the multi-GPU layer of the STA path (pair sharding + all-gather of the
+compact per-pair outputs).  The compute itself has no CPU path, so each rank fabricates deterministic
+per-pair outputs; what is checked is that every rank reassembles ALL pairs in the global order."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from vista_slam_amd import parallel as P
+
+H, W_ = 4, 6
+
+
+def fake_outputs(pair_ids):
+    """Deterministic stand-in for forward_pair outputs of the given global pair ids."""
+    def one(side):
+        B = len(pair_ids)
+        ids = torch.tensor(pair_ids, dtype=torch.float32).view(B, 1, 1)
+        return {"relative_pose": ids.view(B, 1, 1) * 10 + side + torch.arange(16.).view(1, 4, 4),
+                "relative_pose_conf": ids.view(B) * 0.01 + side,
+                "pts3d_pred": (ids.view(B, 1, 1, 1) + torch.arange(H * W_ * 3.).view(1, H, W_, 3) * 0.001 + side),
+                "conf": ids.view(B, 1, 1) + 1 + torch.arange(H * W_ * 1.).view(1, H, W_) * 0.01 + side}
+    return one(0), one(1)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, num_pairs, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = P.shard_range(num_pairs, world, rank)
+        main, supp = fake_outputs(list(range(lo, hi)))
+        packed = P.pack_compact(main, supp)
+        allp = P.gather_compact(packed, num_pairs)
+        gm, gs = P.unpack_compact(allp, H, W_)
+        rm, rs = fake_outputs(list(range(num_pairs)))
+        ok = allp.shape == (num_pairs, P.compact_elems_per_pair(H, W_))
+        for got, ref in ((gm, rm), (gs, rs)):
+            ok &= torch.equal(got["relative_pose"], ref["relative_pose"])
+            ok &= torch.equal(got["relative_pose_conf"], ref["relative_pose_conf"])
+            ok &= torch.equal(got["depth"], ref["pts3d_pred"][..., 2])
+            ok &= torch.equal(got["conf"], ref["conf"])
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_pairs", [16, 5, 2])   # equal shards (bench), ragged shards, one pair per rank
+def test_two_rank_gather_reassembles_all_pairs(num_pairs):
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), num_pairs, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_shard_range_covers_everything_once():
+    for n in (0, 1, 5, 8, 16, 17):
+        for world in (1, 2, 3, 8):
+            spans = [P.shard_range(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_single_process_gather_is_identity():
+    main, supp = fake_outputs([0, 1, 2])
+    p = P.pack_compact(main, supp)
+    assert P.gather_compact(p, 3) is p

@@ -1,0 +1,34 @@
+"""Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls, total/avg/min/max duration.
+
+    python tools/rocpd_stats.py gpurun_out/prof1/*/*.db > profiles/r01_kernel_stats.txt
+"""
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r"\[clone .*\]", "", name)
+    name = name.replace("void ", "").replace("(GemmParams)", "").replace("(AttnParams)", "").replace("(LnParams)", "")
+    return name[:110]
+
+
+def main(paths):
+    rows = {}
+    for p in paths:
+        db = sqlite3.connect(p)
+        cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+        namecol = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+        for name, start, end in db.execute(f"select {namecol}, start, end from kernels"):
+            d = (end - start) / 1e3
+            r = rows.setdefault(short(name), [0, 0.0, 1e30, 0.0])
+            r[0] += 1; r[1] += d; r[2] = min(r[2], d); r[3] = max(r[3], d)
+    tot = sum(r[1] for r in rows.values())
+    print(f"{'kernel':110s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s}")
+    for k, r in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+        print(f"{k:110s} {r[0]:7d} {r[1] / 1e3:10.3f} {r[1] / r[0]:10.2f} {r[2]:9.2f} {r[3]:9.2f} {100 * r[1] / tot:6.2f}")
+    print(f"{'TOTAL':110s} {sum(r[0] for r in rows.values()):7d} {tot / 1e3:10.3f}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

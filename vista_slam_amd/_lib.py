@@ -48,10 +48,11 @@ SIGNATURES = {
     "sta_get_stage_ms": (_i, [_vp, C.POINTER(_f)]),
     "sta_kernel_timing": (_i, [_vp, _i]),
     "sta_kernel_timing_read": (_i, [_vp, C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
-    "sta_bench_gemm": (_i, [_vp, _i, _i, _i, _i, C.POINTER(_f), _vp]),
+    "sta_bench_gemm": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(_f), _vp]),
     "sta_last_error": (C.c_char_p, []),
     "sta_version": (C.c_char_p, []),
     # ---- debug / kernel-level test entry points
+    "sta_set_gemm_variant": (_i, [_vp, _i]),
     "sta_debug_gemm": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _vp]),
     "sta_debug_qkv_rope": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _vp]),
     "sta_debug_attention": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _vp]),

@@ -304,29 +304,34 @@ __device__ inline void nearest_rotation(const double M[3][3], double R[3][3]) {
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[i][j] = l0[i] * w0[j] + l1[i] * w1[j] + l2[i] * w2[j];
 }
 
-__global__ __launch_bounds__(256) void pose_head_kernel(const PoseParams p) {
-    __shared__ float bufA[1024];
-    __shared__ float bufB[1024];
+// one MLP layer: out[b, n] = relu(w[n,:] . in[b,:] + bias[n]); one wave per (sample, neuron) so the
+// 1.85 MFLOP head spreads over the chip instead of serialising on B blocks.
+__global__ __launch_bounds__(256) void pose_layer_kernel(const float* in, int64_t in_stride, const float* w, const float* bias,
+                                                         float* out, int K, int N, int relu) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    if (n >= N) return;
+    const float4* wr = reinterpret_cast<const float4*>(w + (size_t)n * K);
+    const float4* xr = reinterpret_cast<const float4*>(in + (size_t)b * in_stride);
+    float s = 0.f;
+    for (int k = lane; k < K / 4; k += 64) { float4 a = wr[k], x = xr[k]; s += (a.x * x.x + a.y * x.y) + (a.z * x.z + a.w * x.w); }
+    s = wave_sum(s);
+    if (lane == 0) { s += bias[n]; out[(size_t)b * N + n] = relu ? fmaxf(s, 0.f) : s; }
+}
+
+// heads fc_t(3) / fc_rot(9) / fc_conf(1) + rotation orthogonalisation + 4x4 packing; one block per sample
+__global__ __launch_bounds__(256) void pose_final_kernel(const PoseParams p, const float* feat) {
     __shared__ float outv[16];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < p.D; i += 256) bufA[i] = p.tok[(size_t)b * p.tok_stride + i];
+    const float* in = feat + (size_t)b * p.Hd;
+    for (int n = wave; n < 13; n += 4) {
+        const float* wr = n < 3 ? p.wt + (size_t)n * p.Hd : (n < 12 ? p.wr + (size_t)(n - 3) * p.Hd : p.wc);
+        float s = 0.f;
+        for (int k = lane; k < p.Hd; k += 64) s += wr[k] * in[k];
+        s = wave_sum(s);
+        if (lane == 0) outv[n] = s + (n < 3 ? p.bt[n] : (n < 12 ? p.br[n - 3] : p.bc[0]));
+    }
     __syncthreads();
-    auto layer = [&](const float* w, const float* bias, const float* in, float* out, int K, int N, bool relu) {
-        for (int n = wave; n < N; n += 4) {
-            const float* wr = w + (size_t)n * K;
-            float s = 0.f;
-            for (int k = lane; k < K; k += 64) s += wr[k] * in[k];
-            s = wave_sum(s);
-            if (lane == 0) { s += bias[n]; out[n] = relu ? fmaxf(s, 0.f) : s; }
-        }
-        __syncthreads();
-    };
-    layer(p.w0, p.b0, bufA, bufB, p.D, p.Hd, true);
-    layer(p.w1, p.b1, bufB, bufA, p.Hd, p.Hd, true);
-    layer(p.w2, p.b2, bufA, bufB, p.Hd, p.Hd, true);
-    layer(p.wt, p.bt, bufB, outv, p.Hd, 3, false);
-    layer(p.wr, p.br, bufB, outv + 3, p.Hd, 9, false);
-    layer(p.wc, p.bc, bufB, outv + 12, p.Hd, 1, false);
     if (tid == 0) {
         // m (3x3 row-major from fc_rot) -> normalise rows -> R = nearest rotation of normalised m
         double M[3][3], R[3][3];

@@ -44,6 +44,8 @@ struct GemmParams {
     const float* rope_tab;                               // [(pos+1)][16][2] cos,sin ; pos = -1 .. P-1
     // ---- EPI_CONVT
     int ct_k, ct_cout, ct_h, ct_w;
+    // ---- misc
+    const f16* zero_page;                                // >= 64 B of zeros (OOB taps of the direct-to-LDS conv loader)
 };
 
 #define GEMM_BM 128
@@ -69,6 +71,85 @@ __device__ __forceinline__ uint4 relu_pair_hi(uint4 hi, uint4& lo) {
     }
     lo = b.u;
     return a.u;
+}
+
+// Epilogue of one 32x32 MFMA accumulator tile.  C/D layout of v_mfma_f32_32x32x16: this lane holds
+// column `col` (= tile col + lane&31) and rows row0 + (r&3) + 8*(r>>2) + 4*(lane>>5), r = 0..15.
+// The tile column origin is a multiple of 32 and (for EPI_QKV) segment/head boundaries are multiples
+// of 64, so segment, head and the RoPE half (y for d<32, x for d>=32) are wave-uniform.
+template <bool SPLIT, int EPI>
+__device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx16& acc, int row0, int col, int lane) {
+    const int lhi = lane >> 5;
+    const bool col_ok = col < p.N;
+    const float bv = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
+    int seg = 0, head = 0, dcol = 0, xpart = 0;
+    if (EPI == EPI_QKV) {
+        int cbase = (col - (lane & 31)) & ~63;
+        int cc = cbase;
+        if (cbase >= p.nq + p.nk) { seg = 2; cc = cbase - p.nq - p.nk; }
+        else if (cbase >= p.nq) { seg = 1; cc = cbase - p.nq; }
+        head = cc >> 6;
+        dcol = col - cbase;
+        xpart = (dcol >> 5) & 1;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const bool ok = col_ok && row < p.M;
+        float v = acc[r] + bv;
+        if (EPI == EPI_F32) {
+            if (ok) {
+                int orow = row;
+                if (p.rows_in > 0) orow = (row / p.rows_in) * p.rows_out + p.row_off + row % p.rows_in;
+                if (p.resid) v += p.resid[(size_t)orow * p.ldr + col];
+                p.C32[(size_t)orow * p.ldc + col] = v;
+            }
+        } else if (EPI == EPI_F16) {
+            if (ok) {
+                if (p.act == ACT_GELU) v = gelu_erf(v);
+                else if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                size_t o = (size_t)row * p.ldc16 + col;
+                if (p.R1_hi) { v += (float)p.R1_hi[o]; if (SPLIT) v += (float)p.R1_lo[o]; }
+                if (p.R2_hi) { v += (float)p.R2_hi[o]; if (SPLIT) v += (float)p.R2_lo[o]; }
+                if (SPLIT) { f16 h, l; split_f16(v, h, l); p.C_hi[o] = h; p.C_lo[o] = l; }
+                else p.C_hi[o] = to_f16_sat(v);
+            }
+        } else if (EPI == EPI_QKV) {
+            const int rowc = row < p.M ? row : p.M - 1;
+            const int s = rowc / p.ntok, t = rowc - s * p.ntok;
+            if (seg < 2) {
+                int tt = p.has_pose_tok ? t - 1 : t;
+                int py = tt < 0 ? -1 : tt / p.wp;
+                int px = tt < 0 ? -1 : tt - (tt / p.wp) * p.wp;
+                int pos = (xpart ? px : py) + 1;
+                const float2 cs = *reinterpret_cast<const float2*>(p.rope_tab + ((size_t)pos * 16 + (lane & 15)) * 2);
+                float other = __shfl_xor(v, 16);
+                v = (lane & 16) ? (v * cs.x + other * cs.y) : (v * cs.x - other * cs.y);
+                if (ok) {
+                    size_t o = ((size_t)(s * p.heads + head) * p.npad + t) * 64 + dcol;
+                    f16* dh = seg == 0 ? p.Q_hi : p.K_hi;
+                    f16* dl = seg == 0 ? p.Q_lo : p.K_lo;
+                    if (SPLIT) { f16 h, l; split_f16(v, h, l); dh[o] = h; dl[o] = l; }
+                    else dh[o] = to_f16_sat(v);
+                }
+            } else if (ok) {
+                size_t o = ((size_t)(s * p.heads + head) * 64 + dcol) * p.npad + t;
+                if (SPLIT) { f16 h, l; split_f16(v, h, l); p.Vt_hi[o] = h; p.Vt_lo[o] = l; }
+                else p.Vt_hi[o] = to_f16_sat(v);
+            }
+        } else {  // EPI_CONVT
+            if (ok) {
+                int g = col / p.ct_cout, co = col - g * p.ct_cout;
+                int dy = g / p.ct_k, dx = g - dy * p.ct_k;
+                int hw = p.ct_h * p.ct_w;
+                int img = row / hw, rem = row - img * hw;
+                int y = rem / p.ct_w, x = rem - y * p.ct_w;
+                size_t o = (((size_t)img * (p.ct_h * p.ct_k) + (y * p.ct_k + dy)) * (p.ct_w * p.ct_k) + (x * p.ct_k + dx)) * p.ct_cout + co;
+                if (SPLIT) { f16 h, l; split_f16(v, h, l); p.C_hi[o] = h; p.C_lo[o] = l; }
+                else p.C_hi[o] = to_f16_sat(v);
+            }
+        }
+    }
 }
 
 template <bool SPLIT, int AMODE, int EPI>
@@ -215,81 +296,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 
     // ------------------------------------------------------------------ epilogue
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + l31;
-        const bool col_ok = col < p.N;
-        const float bv = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
-
-        // wave-uniform QKV segment decode (64-wide wave span never straddles a head / segment)
-        int seg = 0, head = 0, dcol = 0;
-        if (EPI == EPI_QKV) {
-            int cbase = n0 + wn * 64;
-            int cc = cbase;
-            if (cbase >= p.nq + p.nk) { seg = 2; cc = cbase - p.nq - p.nk; }
-            else if (cbase >= p.nq) { seg = 1; cc = cbase - p.nq; }
-            head = cc >> 6;
-            dcol = j * 32 + l31;
-        }
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                const bool ok = col_ok && row < p.M;
-                float v = acc[i][j][r] + bv;
-                if (EPI == EPI_F32) {
-                    if (ok) {
-                        int orow = row;
-                        if (p.rows_in > 0) orow = (row / p.rows_in) * p.rows_out + p.row_off + row % p.rows_in;
-                        if (p.resid) v += p.resid[(size_t)orow * p.ldr + col];
-                        p.C32[(size_t)orow * p.ldc + col] = v;
-                    }
-                } else if (EPI == EPI_F16) {
-                    if (ok) {
-                        if (p.act == ACT_GELU) v = gelu_erf(v);
-                        else if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-                        size_t o = (size_t)row * p.ldc16 + col;
-                        if (p.R1_hi) { v += (float)p.R1_hi[o]; if (SPLIT) v += (float)p.R1_lo[o]; }
-                        if (p.R2_hi) { v += (float)p.R2_hi[o]; if (SPLIT) v += (float)p.R2_lo[o]; }
-                        if (SPLIT) { f16 h, l; split_f16(v, h, l); p.C_hi[o] = h; p.C_lo[o] = l; }
-                        else p.C_hi[o] = to_f16_sat(v);
-                    }
-                } else if (EPI == EPI_QKV) {
-                    const int rowc = row < p.M ? row : p.M - 1;
-                    const int s = rowc / p.ntok, t = rowc - s * p.ntok;
-                    if (seg < 2) {
-                        int tt = p.has_pose_tok ? t - 1 : t;
-                        int py = tt < 0 ? -1 : tt / p.wp;
-                        int px = tt < 0 ? -1 : tt - (tt / p.wp) * p.wp;
-                        int pos = (j == 0 ? py : px) + 1;
-                        const float2 cs = *reinterpret_cast<const float2*>(p.rope_tab + ((size_t)pos * 16 + (lane & 15)) * 2);
-                        float other = __shfl_xor(v, 16);
-                        v = (lane & 16) ? (v * cs.x + other * cs.y) : (v * cs.x - other * cs.y);
-                        if (ok) {
-                            size_t o = ((size_t)(s * p.heads + head) * p.npad + t) * 64 + dcol;
-                            f16* dh = seg == 0 ? p.Q_hi : p.K_hi;
-                            f16* dl = seg == 0 ? p.Q_lo : p.K_lo;
-                            if (SPLIT) { f16 h, l; split_f16(v, h, l); dh[o] = h; dl[o] = l; }
-                            else dh[o] = to_f16_sat(v);
-                        }
-                    } else if (ok) {
-                        size_t o = ((size_t)(s * p.heads + head) * 64 + dcol) * p.npad + t;
-                        if (SPLIT) { f16 h, l; split_f16(v, h, l); p.Vt_hi[o] = h; p.Vt_lo[o] = l; }
-                        else p.Vt_hi[o] = to_f16_sat(v);
-                    }
-                } else {  // EPI_CONVT
-                    if (ok) {
-                        int g = col / p.ct_cout, co = col - g * p.ct_cout;
-                        int dy = g / p.ct_k, dx = g - dy * p.ct_k;
-                        int hw = p.ct_h * p.ct_w;
-                        int img = row / hw, rem = row - img * hw;
-                        int y = rem / p.ct_w, x = rem - y * p.ct_w;
-                        size_t o = (((size_t)img * (p.ct_h * p.ct_k) + (y * p.ct_k + dy)) * (p.ct_w * p.ct_k) + (x * p.ct_k + dx)) * p.ct_cout + co;
-                        if (SPLIT) { f16 h, l; split_f16(v, h, l); p.C_hi[o] = h; p.C_lo[o] = l; }
-                        else p.C_hi[o] = to_f16_sat(v);
-                    }
-                }
-            }
-        }
-    }
+        for (int i = 0; i < 2; ++i)
+            epilogue_tile<SPLIT, EPI>(p, acc[i][j], m0 + wm * 64 + i * 32, n0 + wn * 64 + j * 32 + l31, lane);
 }

@@ -3,6 +3,7 @@
 // attention.h and elementwise.h.  No torch, no BLAS, no CPU fallback.
 #include "../../include/sta_mi355.h"
 #include "gemm.h"
+#include "gemm2.h"
 #include "attention.h"
 #include "elementwise.h"
 
@@ -63,6 +64,8 @@ struct sta_handle {
     // staging + workspace
     float* stage = nullptr; int64_t stage_elems = 0;
     char* ws = nullptr; int64_t ws_cap = 0;
+    f16* zero_page = nullptr;
+    int gemm_variant = 0;   // 0 auto, 1 force 128x128 kernel, 2 force 256-row kernel (tests/bench only)
     // rope table
     float* rope_tab = nullptr; int rope_P = 0;
     // timing
@@ -279,8 +282,7 @@ extern "C" int sta_create(const sta_config* cfg, int device, sta_handle** out) {
     int64_t big = (int64_t)768 * 768 * 9;
     if (big > h->stage_elems) h->stage_elems = big;
     if (hipMalloc((void**)&h->stage, (size_t)h->stage_elems * 4) != hipSuccess) { sta_destroy(h); return set_err("staging alloc failed"); }
-    // dynamic LDS opt-in (64 KB for split tiles)
-    hipFuncSetAttribute((const void*)gemm_kernel<true, A_DENSE, EPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_smem_bytes<true>());
+    if (hipMalloc((void**)&h->zero_page, 256) != hipSuccess || hipMemset(h->zero_page, 0, 256) != hipSuccess) { sta_destroy(h); return set_err("zero page alloc failed"); }
     *out = h;
     return 0;
 }
@@ -293,6 +295,7 @@ extern "C" int sta_destroy(sta_handle* h) {
     if (h->stage) hipFree(h->stage);
     if (h->ws) hipFree(h->ws);
     if (h->rope_tab) hipFree(h->rope_tab);
+    if (h->zero_page) hipFree(h->zero_page);
     if (h->ev_ok) for (auto& e : h->ev) hipEventDestroy(e);
     for (auto& e : h->kev) hipEventDestroy(e);
     delete h;
@@ -303,6 +306,11 @@ extern "C" int sta_set_precision(sta_handle* h, int precision) {
     REQUIRE(h, "null handle");
     REQUIRE(precision == STA_PREC_F16 || precision == STA_PREC_F16X3, "unknown precision %d", precision);
     h->prec = precision;
+    return 0;
+}
+extern "C" int sta_set_gemm_variant(sta_handle* h, int variant) {
+    REQUIRE(h && variant >= 0 && variant <= 2, "bad gemm variant");
+    h->gemm_variant = variant;
     return 0;
 }
 extern "C" int sta_num_expected_tensors(const sta_handle* h) { return h ? (int)h->slots.size() : -1; }
@@ -358,14 +366,29 @@ extern "C" int sta_finalize_weights(sta_handle* h) {
 }
 
 // ------------------------------------------------------------------------------------------ launch helpers
+template <bool SPLIT, int AMODE, int EPI, int BM, int BN, int WMS, int WNS>
+static int launch_gemm2(const GemmParams& p, hipStream_t st) {
+    static bool attr_done = false;
+    constexpr int smem = gemm2_smem_bytes<SPLIT, BM, BN>();
+    if (!attr_done) {
+        HIPCHK(hipFuncSetAttribute((const void*)gemm2_kernel<SPLIT, AMODE, EPI, BM, BN, WMS, WNS>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_done = true;
+    }
+    int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm2_kernel<SPLIT, AMODE, EPI, BM, BN, WMS, WNS>), dim3((unsigned)(tm * tn)), dim3(WMS * WNS * 64), smem, st, p);
+    return 0;
+}
+
 template <int AMODE, int EPI>
-static int launch_gemm(sta_handle* h, const GemmParams& p, hipStream_t st) {
+static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
+    GemmParams p = p_in;
+    p.zero_page = h->zero_page;
     REQUIRE(p.K % GEMM_BK == 0, "GEMM K=%d must be a multiple of %d", p.K, GEMM_BK);
     REQUIRE(p.M > 0 && p.N > 0, "empty GEMM");
     if (AMODE == A_CONV3) REQUIRE(p.Cin % GEMM_BK == 0, "conv Cin=%d must be a multiple of %d", p.Cin, GEMM_BK);
     if (h->dry) return 0;
-    int tm = (p.M + GEMM_BM - 1) / GEMM_BM, tn = (p.N + GEMM_BN - 1) / GEMM_BN;
-    dim3 grid((unsigned)(tm * tn));
+    const bool split = h->prec == STA_PREC_F16X3;
     const bool timed = h->ktime && AMODE == A_DENSE && EPI == EPI_F32;
     if (timed) {
         if ((int)h->kev.size() < 2 * (h->kn + 1)) {
@@ -377,15 +400,35 @@ static int launch_gemm(sta_handle* h, const GemmParams& p, hipStream_t st) {
         HIPCHK(hipEventRecord(h->kev[2 * h->kn], st));
         h->kn++;
     }
-    if (h->prec == STA_PREC_F16X3) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            hipFuncSetAttribute((const void*)gemm_kernel<true, AMODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_smem_bytes<true>());
-            attr_done = true;
-        }
-        hipLaunchKernelGGL((gemm_kernel<true, AMODE, EPI>), grid, dim3(256), gemm_smem_bytes<true>(), st, p);
+    // Tile selection: the 256-row direct-to-LDS kernel when the grid still fills the chip, else the
+    // 128x128 kernel (small-M SLAM shapes, odd N).
+    const int64_t big_tiles = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
+    const int64_t mid_tiles = (int64_t)((p.M + 255) / 256) * ((p.N + 127) / 128);
+    int variant = 1;
+    if (p.N % 256 == 0 && big_tiles >= 128) variant = 2;
+    else if (p.N % 128 == 0 && mid_tiles >= 128) variant = 3;
+    if (h->gemm_variant == 2 && p.N % 128 == 0) variant = p.N % 256 == 0 ? 2 : 3;
+    if (EPI == EPI_QKV && variant == 2) variant = 3;   // the RoPE epilogue spills at 128 accumulators
+    if (h->gemm_variant == 1) variant = 1;
+    if (variant == 2) {
+        if (split) CHK((launch_gemm2<true, AMODE, EPI, 256, 256, 2, 4>(p, st)));
+        else CHK((launch_gemm2<false, AMODE, EPI, 256, 256, 2, 4>(p, st)));
+    } else if (variant == 3) {
+        if (split) CHK((launch_gemm2<true, AMODE, EPI, 256, 128, 4, 2>(p, st)));
+        else CHK((launch_gemm2<false, AMODE, EPI, 256, 128, 4, 2>(p, st)));
     } else {
-        hipLaunchKernelGGL((gemm_kernel<false, AMODE, EPI>), grid, dim3(256), gemm_smem_bytes<false>(), st, p);
+        int tm = (p.M + GEMM_BM - 1) / GEMM_BM, tn = (p.N + GEMM_BN - 1) / GEMM_BN;
+        dim3 grid((unsigned)(tm * tn));
+        if (split) {
+            static bool attr_done = false;
+            if (!attr_done) {
+                HIPCHK(hipFuncSetAttribute((const void*)gemm_kernel<true, AMODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_smem_bytes<true>()));
+                attr_done = true;
+            }
+            hipLaunchKernelGGL((gemm_kernel<true, AMODE, EPI>), grid, dim3(256), gemm_smem_bytes<true>(), st, p);
+        } else {
+            hipLaunchKernelGGL((gemm_kernel<false, AMODE, EPI>), grid, dim3(256), gemm_smem_bytes<false>(), st, p);
+        }
     }
     HIPCHK(hipGetLastError());
     if (timed) HIPCHK(hipEventRecord(h->kev[2 * (h->kn - 1) + 1], st));
@@ -624,14 +667,22 @@ static int decode_impl(sta_handle* h, Bump& ws, const float* feat1, const float*
 }
 
 // ------------------------------------------------------------------------------------------ pose head
-static int pose_impl(sta_handle* h, const float* tok, int B, int64_t stride, float* pose, float* conf, hipStream_t st) {
+static int pose_impl(sta_handle* h, Bump& ws, const float* tok, int B, int64_t stride, float* pose, float* conf, hipStream_t st) {
+    const int D = h->cfg.dec_embed_dim, Hd = 512;
+    float* f0 = (float*)ws.take((int64_t)B * Hd * 4);
+    float* f1 = (float*)ws.take((int64_t)B * Hd * 4);
     if (h->dry) return 0;
+    REQUIRE(!ws.overflow, "internal: pose workspace overflow");
     PoseParams p;
-    p.tok = tok; p.tok_stride = stride; p.D = h->cfg.dec_embed_dim; p.Hd = 512;
+    p.tok = tok; p.tok_stride = stride; p.D = D; p.Hd = Hd;
     p.w0 = h->pm0.w; p.b0 = h->pm0.b; p.w1 = h->pm1.w; p.b1 = h->pm1.b; p.w2 = h->pm2.w; p.b2 = h->pm2.b;
     p.wt = h->pt.w; p.bt = h->pt.b; p.wr = h->pr.w; p.br = h->pr.b; p.wc = h->pc.w; p.bc = h->pc.b;
     p.pose = pose; p.conf = conf;
-    hipLaunchKernelGGL(pose_head_kernel, dim3(B), dim3(256), 0, st, p);
+    dim3 grid(Hd / 4, B);
+    hipLaunchKernelGGL(pose_layer_kernel, grid, dim3(256), 0, st, tok, stride, p.w0, p.b0, f0, D, Hd, 1);
+    hipLaunchKernelGGL(pose_layer_kernel, grid, dim3(256), 0, st, f0, (int64_t)Hd, p.w1, p.b1, f1, Hd, Hd, 1);
+    hipLaunchKernelGGL(pose_layer_kernel, grid, dim3(256), 0, st, f1, (int64_t)Hd, p.w2, p.b2, f0, Hd, Hd, 1);
+    hipLaunchKernelGGL(pose_final_kernel, dim3(B), dim3(256), 0, st, p, f0);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -789,7 +840,9 @@ extern "C" int sta_head_pose(sta_handle* h, const float* tok, int B, int64_t tok
     REQUIRE(h && h->finalized, "handle not ready");
     REQUIRE(tok && pose && conf && B > 0, "bad argument");
     HIPCHK(hipSetDevice(h->device));
-    return pose_impl(h, tok, B, tok_stride, pose, conf, (hipStream_t)stream);
+    REQUIRE(tok_stride % 4 == 0, "tok_stride must be a multiple of 4 floats");
+    hipStream_t st = (hipStream_t)stream;
+    return plan_and_run(h, [&](Bump& ws) { return pose_impl(h, ws, tok, B, tok_stride, pose, conf, st); });
 }
 
 extern "C" int sta_head_pts(sta_handle* h, const float* enc_feat, int64_t enc_bstride,
@@ -834,8 +887,9 @@ extern "C" int sta_forward_pair(sta_handle* h, const float* img_a, const float* 
         CHK(decode_impl(h, ws, feat, feat + (size_t)B * N * E, B, hp, wp, x, w1.data(), w2.data(), st));
         if (rec) HIPCHK(hipEventRecord(h->ev[2], st));
         // pose heads read token 0 of the dec_norm'ed last layer (sta_model.py:273,277)
-        CHK(pose_impl(h, hk[2], B, (int64_t)Np * D, pose[0], pose_conf[0], st));
-        CHK(pose_impl(h, hk[2] + (size_t)B * Np * D, B, (int64_t)Np * D, pose[1], pose_conf[1], st));
+        ws.rewind(mark);
+        CHK(pose_impl(h, ws, hk[2], B, (int64_t)Np * D, pose[0], pose_conf[0], st));
+        CHK(pose_impl(h, ws, hk[2] + (size_t)B * Np * D, B, (int64_t)Np * D, pose[1], pose_conf[1], st));
         if (rec) HIPCHK(hipEventRecord(h->ev[3], st));
         ws.rewind(mark);
         CHK(dpt_impl(h, ws, feat, (int64_t)N * E, hk[0] + D, (int64_t)Np * D, hk[1] + D, (int64_t)Np * D, hk[2] + D, (int64_t)Np * D,
@@ -919,7 +973,22 @@ __global__ void fill_rand_f16_kernel(f16* p, int64_t n, uint32_t seed, float sca
     }
 }
 
-extern "C" int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, float* ms_out, void* stream) {
+template <int BM, int BN, int WMS, int WNS, int ABL>
+static int bench_launch2(bool split, const GemmParams& p, hipStream_t st) {
+    if (split) {
+        constexpr int smem = gemm2_smem_bytes<true, BM, BN>();
+        HIPCHK(hipFuncSetAttribute((const void*)gemm2_kernel<true, A_DENSE, EPI_F32, BM, BN, WMS, WNS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        hipLaunchKernelGGL((gemm2_kernel<true, A_DENSE, EPI_F32, BM, BN, WMS, WNS, ABL>), dim3((unsigned)(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN))), dim3(WMS * WNS * 64), smem, st, p);
+    } else {
+        constexpr int smem = gemm2_smem_bytes<false, BM, BN>();
+        HIPCHK(hipFuncSetAttribute((const void*)gemm2_kernel<false, A_DENSE, EPI_F32, BM, BN, WMS, WNS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        hipLaunchKernelGGL((gemm2_kernel<false, A_DENSE, EPI_F32, BM, BN, WMS, WNS, ABL>), dim3((unsigned)(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN))), dim3(WMS * WNS * 64), smem, st, p);
+    }
+    return 0;
+}
+
+// tile: 0 = automatic product selection, 1 = 128x128, 2 = 256x256, 3 = 256x128; abl: gemm2 ablation (tile 2/3 only)
+extern "C" int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, int tile, int abl, float* ms_out, void* stream) {
     REQUIRE(h && ms_out && iters > 0, "bad argument");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
@@ -939,13 +1008,29 @@ extern "C" int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, flo
     hipLaunchKernelGGL(fill_rand_f16_kernel, dim3(2048), dim3(256), 0, st, Wt.w.lo, (int64_t)N * K, 4u, 1.5e-5f);
     HIPCHK(hipMemsetAsync(Wt.bias, 0, (size_t)N * 4, st));
     if (!split) { A.lo = nullptr; }
+    GemmParams p = gp_dense(A, K, Wt, M);
+    p.C32 = C; p.ldc = N; p.ldr = N; p.zero_page = h->zero_page;
+    const int keep = h->gemm_variant;
+    auto once = [&]() -> int {
+        if (tile >= 2 && abl > 0) {
+            if (tile == 2) { if (abl == 1) return bench_launch2<256, 256, 2, 4, 1>(split, p, st); if (abl == 2) return bench_launch2<256, 256, 2, 4, 2>(split, p, st); return bench_launch2<256, 256, 2, 4, 3>(split, p, st); }
+            if (abl == 1) return bench_launch2<256, 128, 4, 2, 1>(split, p, st); if (abl == 2) return bench_launch2<256, 128, 4, 2, 2>(split, p, st); return bench_launch2<256, 128, 4, 2, 3>(split, p, st);
+        }
+        if (tile == 2) return bench_launch2<256, 256, 2, 4, 0>(split, p, st);
+        if (tile == 3) return bench_launch2<256, 128, 4, 2, 0>(split, p, st);
+        h->gemm_variant = tile == 1 ? 1 : 0;
+        int r = launch_gemm<A_DENSE, EPI_F32>(h, p, st);
+        h->gemm_variant = keep;
+        return r;
+    };
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    for (int i = 0; i < 2; ++i) CHK(gemm_f32(h, A, Wt, M, C, N, nullptr, st));
+    for (int i = 0; i < 2; ++i) CHK(once());
     HIPCHK(hipEventRecord(e0, st));
-    for (int i = 0; i < iters; ++i) CHK(gemm_f32(h, A, Wt, M, C, N, nullptr, st));
+    for (int i = 0; i < iters; ++i) CHK(once());
     HIPCHK(hipEventRecord(e1, st));
     HIPCHK(hipEventSynchronize(e1));
+    HIPCHK(hipGetLastError());
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     *ms_out = ms / iters;
     hipEventDestroy(e0); hipEventDestroy(e1);

@@ -286,9 +286,9 @@ class STAFrontend:
         _lib.check(self.lib.sta_kernel_timing_read(self._h, C.byref(n), C.byref(ms), C.byref(fl)))
         return int(n.value), float(ms.value), float(fl.value)
 
-    def bench_gemm(self, M: int, N: int, K: int, iters: int = 20) -> float:
+    def bench_gemm(self, M: int, N: int, K: int, iters: int = 20, tile: int = 0, ablation: int = 0) -> float:
         ms = C.c_float()
-        _lib.check(self.lib.sta_bench_gemm(self._h, M, N, K, iters, C.byref(ms), _stream_ptr()))
+        _lib.check(self.lib.sta_bench_gemm(self._h, M, N, K, iters, tile, ablation, C.byref(ms), _stream_ptr()))
         return float(ms.value)
 
     def workspace_bytes(self) -> int:
