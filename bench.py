@@ -28,6 +28,22 @@ H, W_, PAIRS_PER_GPU = 384, 512, 8
 PEAK_F16_MFMA_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json <- tools/pmc_summary.py; FETCH_SIZE doubled per the gfx950
+    correction).  bench.py cannot collect PMCs itself; null when no summary is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        for k, v in d.items():
+            if k.startswith("gemm2_kernel<true, 0, 0, 256, 256"):
+                return int(v["avg_hbm_bytes_per_launch"])
+    except Exception:   # noqa: BLE001
+        pass
+    return None
+
+
 def cpu_baseline():
     """Oracle (port of the reference algorithm, fp32, OpenMP) on the host cores: one 224x224 pair
     (BASELINE config 1 shape) - a bounded sample (~10-30 s) of the same per-pair workload."""
@@ -78,19 +94,15 @@ def main():
     img_a = torch.from_numpy(imgs[:B]).to(dev)
     img_b = torch.from_numpy(imgs[B:]).to(dev)
 
+    from vista_slam_amd import parallel as P
     gathered = None
     if world > 1:
-        compact_elems = 2 * B * (16 + 1 + 2 * H * W_)
-        gathered = torch.empty(world * compact_elems, device=dev)
+        gathered = torch.empty(world * B, P.compact_elems_per_pair(H, W_), device=dev)
 
     def step():
         main_o, supp_o = model.forward_pair(img_a, img_b)
         if world > 1:   # compact per-pair outputs -> every rank (slam.py consumes pose, conf, depth, conf map)
-            parts = []
-            for o in (main_o, supp_o):
-                parts += [o["relative_pose"].reshape(-1), o["relative_pose_conf"].reshape(-1),
-                          o["pts3d_pred"][..., 2].reshape(-1), o["conf"].reshape(-1)]
-            dist.all_gather_into_tensor(gathered, torch.cat(parts))
+            P.gather_compact(P.pack_compact(main_o, supp_o), world * B, out=gathered)
         return main_o, supp_o
 
     for _ in range(args.warmup):
@@ -116,13 +128,14 @@ def main():
 
     roof = None
     if not args.no_kernel_timing:
-        n, ms, fl = model.kernel_timing_read()
+        n, ms, fl, by = model.kernel_timing_read()
         model.kernel_timing(False)
         if n > 0 and ms > 0:
             ach = fl / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "gemm_kernel<SPLIT,A_DENSE,EPI_F32> (attn.proj / mlp.fc2 / embeds)",
                     "achieved": round(ach, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
+                    "algorithmic_bytes_per_launch": int(by / n), "gflop_per_launch": round(fl / n / 1e9, 2),
                     "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
                     "mfma_products_per_flop": 3 if args.precision == "f16x3" else 1,
                     "issued_frac": round(ach * (3 if args.precision == "f16x3" else 1) / PEAK_F16_MFMA_TFLOPS, 4)}

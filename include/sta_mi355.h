@@ -148,7 +148,8 @@ int sta_get_stage_ms(sta_handle* h, float ms[4]);
  * starts recording; sta_kernel_timing_read synchronises on the recorded events and returns the
  * number of launches, the summed kernel time and the summed algorithmic FLOPs (2*M*N*K). */
 int sta_kernel_timing(sta_handle* h, int enable);
-int sta_kernel_timing_read(sta_handle* h, int* launches, double* total_ms, double* total_flops);
+int sta_kernel_timing_read(sta_handle* h, int* launches, double* total_ms, double* total_flops,
+                           double* total_algorithmic_bytes);
 
 /* Time `iters` back-to-back launches of the dominant GEMM kernel (M x N x K, this handle's
  * precision, random operands) with hipEvents on `stream`; average ms per launch in *ms_out.

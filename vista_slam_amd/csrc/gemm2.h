@@ -77,8 +77,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
         const int gm = m0 + row;
         if (AMODE == A_DENSE) {
             const int gmc = gm < p.M ? gm : p.M - 1;
-            a_src_hi[s] = p.A_hi + (size_t)gmc * p.lda + src_chunk * 8;
-            a_src_lo[s] = SPLIT ? p.A_lo + (size_t)gmc * p.lda + src_chunk * 8 : nullptr;
+            const size_t rs = (ABL & 4) ? 32 : p.lda;   // bench-only: K-tile-blocked source layout [K/32][M][32]
+            a_src_hi[s] = p.A_hi + (size_t)gmc * rs + src_chunk * 8;
+            a_src_lo[s] = SPLIT ? p.A_lo + (size_t)gmc * rs + src_chunk * 8 : nullptr;
         } else {
             cv_ok[s] = gm < p.M;
             const int gmc = cv_ok[s] ? gm : 0;
@@ -95,12 +96,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
         const int row = 16 * (wave + NW * s) + row_in;
         const int gn = n0 + row;
         const int gnc = gn < p.N ? gn : p.N - 1;
-        b_src_hi[s] = p.B_hi + (size_t)gnc * p.K + src_chunk * 8;
-        b_src_lo[s] = SPLIT ? p.B_lo + (size_t)gnc * p.K + src_chunk * 8 : nullptr;
+        const size_t rsb = (ABL & 4) ? 32 : p.K;
+        b_src_hi[s] = p.B_hi + (size_t)gnc * rsb + src_chunk * 8;
+        b_src_lo[s] = SPLIT ? p.B_lo + (size_t)gnc * rsb + src_chunk * 8 : nullptr;
     }
 
     auto issue_tile = [&](int kt, int stage) {
         const int k0 = kt * GEMM_BK;
+        const size_t ka = (ABL & 4) ? (size_t)kt * p.M * 32 : (size_t)k0, kb = (ABL & 4) ? (size_t)kt * p.N * 32 : (size_t)k0;
         char* sA = smem + stage * STAGE;
         char* sB = sA + NPL * A_PLANE;
         int tap = 0, c0 = 0, ky = 0, kx = 0;
@@ -109,8 +112,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
         for (int s = 0; s < SA; ++s) {
             char* dst = sA + (wave + NW * s) * 1024;
             if (AMODE == A_DENSE) {
-                glds16(a_src_hi[s] + k0, dst);
-                if (SPLIT) glds16(a_src_lo[s] + k0, dst + A_PLANE);
+                glds16(a_src_hi[s] + ka, dst);
+                if (SPLIT) glds16(a_src_lo[s] + ka, dst + A_PLANE);
             } else {
                 const int yi = cv_y[s] + ky, xi = cv_x[s] + kx;
                 const bool ok = cv_ok[s] && yi >= 0 && yi < p.Hi && xi >= 0 && xi < p.Wi;
@@ -122,8 +125,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
 #pragma unroll
         for (int s = 0; s < SB; ++s) {
             char* dst = sB + (wave + NW * s) * 1024;
-            glds16(b_src_hi[s] + k0, dst);
-            if (SPLIT) glds16(b_src_lo[s] + k0, dst + B_PLANE);
+            glds16(b_src_hi[s] + kb, dst);
+            if (SPLIT) glds16(b_src_lo[s] + kb, dst + B_PLANE);
         }
     };
 
@@ -142,21 +145,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
 
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nkt && ABL != 1) issue_tile(kt + 1, cur ^ 1);
+        if (kt + 1 < nkt && (ABL & 3) != 1) issue_tile(kt + 1, cur ^ 1);
         const char* sA = smem + cur * STAGE;
         const char* sB = sA + NPL * A_PLANE;
         half8 a_hi[MT], a_lo[MT], b_hi[NT], b_lo[NT];
-        if (ABL == 3) {
+        if ((ABL & 3) == 3) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) { a_hi[i] = (half8)(f16)(0.001f * (lane + i)); a_lo[i] = a_hi[i]; asm volatile("" : "+v"(a_hi[i]), "+v"(a_lo[i])); }
 #pragma unroll
             for (int j = 0; j < NT; ++j) { b_hi[j] = (half8)(f16)(0.002f * (lane + j)); b_lo[j] = b_hi[j]; asm volatile("" : "+v"(b_hi[j]), "+v"(b_lo[j])); }
         }
 #pragma unroll
-        for (int ks = 0; ks < 2 && ABL != 2; ++ks) {
+        for (int ks = 0; ks < 2 && (ABL & 3) != 2; ++ks) {
             const int chunk = ks * 2 + lhi;
 #pragma unroll
-            for (int i = 0; i < MT && ABL != 3; ++i) {
+            for (int i = 0; i < MT && (ABL & 3) != 3; ++i) {
                 const int ra = wm * WM + i * 32 + l31;
                 a_hi[i] = *reinterpret_cast<const half8*>(sA + lds_off(ra, chunk));
                 if (SPLIT) a_lo[i] = *reinterpret_cast<const half8*>(sA + A_PLANE + lds_off(ra, chunk));
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
                 }
             }
 #pragma unroll
-            for (int j = 0; j < NT && ABL != 3; ++j) {
+            for (int j = 0; j < NT && (ABL & 3) != 3; ++j) {
                 const int rb = wn * WN + j * 32 + l31;
                 b_hi[j] = *reinterpret_cast<const half8*>(sB + lds_off(rb, chunk));
                 if (SPLIT) b_lo[j] = *reinterpret_cast<const half8*>(sB + B_PLANE + lds_off(rb, chunk));

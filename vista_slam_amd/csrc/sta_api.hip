@@ -71,7 +71,7 @@ struct sta_handle {
     // timing
     bool timing = false; hipEvent_t ev[5]; bool ev_ok = false;
     // per-launch timing of the dominant kernel (gemm_kernel<*, A_DENSE, EPI_F32>) for the roofline report
-    bool ktime = false; std::vector<hipEvent_t> kev; int kn = 0; std::vector<double> kflops;
+    bool ktime = false; std::vector<hipEvent_t> kev; int kn = 0; std::vector<double> kflops, kbytes;
     bool dry = false;   // planning pass: run the orchestration without launching to size the workspace
 };
 
@@ -397,6 +397,9 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
         }
         if ((int)h->kflops.size() <= h->kn) h->kflops.resize(h->kn + 1);
         h->kflops[h->kn] = 2.0 * p.M * p.N * p.K;
+        if ((int)h->kbytes.size() <= h->kn) h->kbytes.resize(h->kn + 1);
+        // algorithmic bytes: A and W planes (2 B x planes) read once, C written once (+ residual read)
+        h->kbytes[h->kn] = (split ? 4.0 : 2.0) * ((double)p.M * p.K + (double)p.N * p.K) + 4.0 * p.M * p.N * (p.resid ? 2.0 : 1.0);
         HIPCHK(hipEventRecord(h->kev[2 * h->kn], st));
         h->kn++;
     }
@@ -904,16 +907,16 @@ extern "C" int sta_kernel_timing(sta_handle* h, int enable) {
     h->ktime = enable != 0; h->kn = 0;
     return 0;
 }
-extern "C" int sta_kernel_timing_read(sta_handle* h, int* launches, double* total_ms, double* total_flops) {
-    REQUIRE(h && launches && total_ms && total_flops, "null argument");
+extern "C" int sta_kernel_timing_read(sta_handle* h, int* launches, double* total_ms, double* total_flops, double* total_bytes) {
+    REQUIRE(h && launches && total_ms && total_flops && total_bytes, "null argument");
     HIPCHK(hipSetDevice(h->device));
-    double ms = 0, fl = 0;
+    double ms = 0, fl = 0, by = 0;
     for (int i = 0; i < h->kn; ++i) {
         HIPCHK(hipEventSynchronize(h->kev[2 * i + 1]));
         float t = 0; HIPCHK(hipEventElapsedTime(&t, h->kev[2 * i], h->kev[2 * i + 1]));
-        ms += t; fl += h->kflops[i];
+        ms += t; fl += h->kflops[i]; by += h->kbytes[i];
     }
-    *launches = h->kn; *total_ms = ms; *total_flops = fl;
+    *launches = h->kn; *total_ms = ms; *total_flops = fl; *total_bytes = by;
     return 0;
 }
 
@@ -1013,7 +1016,17 @@ extern "C" int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, int
     const int keep = h->gemm_variant;
     auto once = [&]() -> int {
         if (tile >= 2 && abl > 0) {
-            if (tile == 2) { if (abl == 1) return bench_launch2<256, 256, 2, 4, 1>(split, p, st); if (abl == 2) return bench_launch2<256, 256, 2, 4, 2>(split, p, st); return bench_launch2<256, 256, 2, 4, 3>(split, p, st); }
+            if (tile == 2) {
+                switch (abl) {
+                    case 1: return bench_launch2<256, 256, 2, 4, 1>(split, p, st);
+                    case 2: return bench_launch2<256, 256, 2, 4, 2>(split, p, st);
+                    case 3: return bench_launch2<256, 256, 2, 4, 3>(split, p, st);
+                    case 4: return bench_launch2<256, 256, 2, 4, 4>(split, p, st);
+                    case 5: return bench_launch2<256, 256, 2, 4, 5>(split, p, st);
+                    case 6: return bench_launch2<256, 256, 2, 4, 6>(split, p, st);
+                    default: return bench_launch2<256, 256, 2, 4, 7>(split, p, st);
+                }
+            }
             if (abl == 1) return bench_launch2<256, 128, 4, 2, 1>(split, p, st); if (abl == 2) return bench_launch2<256, 128, 4, 2, 2>(split, p, st); return bench_launch2<256, 128, 4, 2, 3>(split, p, st);
         }
         if (tile == 2) return bench_launch2<256, 256, 2, 4, 0>(split, p, st);

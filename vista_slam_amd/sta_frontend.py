@@ -282,9 +282,9 @@ class STAFrontend:
         _lib.check(self.lib.sta_kernel_timing(self._h, int(on)))
 
     def kernel_timing_read(self):
-        n, ms, fl = C.c_int(), C.c_double(), C.c_double()
-        _lib.check(self.lib.sta_kernel_timing_read(self._h, C.byref(n), C.byref(ms), C.byref(fl)))
-        return int(n.value), float(ms.value), float(fl.value)
+        n, ms, fl, by = C.c_int(), C.c_double(), C.c_double(), C.c_double()
+        _lib.check(self.lib.sta_kernel_timing_read(self._h, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)))
+        return int(n.value), float(ms.value), float(fl.value), float(by.value)
 
     def bench_gemm(self, M: int, N: int, K: int, iters: int = 20, tile: int = 0, ablation: int = 0) -> float:
         ms = C.c_float()
