@@ -153,6 +153,7 @@ def main():
                           "parallelism": f"pair-sharded x{world}, RCCL all-gather of compact outputs" if world > 1 else "single GPU"},
                "gflop_per_pair": round(flops_pair / 1e9, 2),
                "whole_path_tflops": round(pairs * flops_pair / dt / 1e12, 1),
+               "workspace_gb": round(model.workspace_bytes() / 1e9, 2),
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             try:
