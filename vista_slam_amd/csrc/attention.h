@@ -40,9 +40,19 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int s = blockIdx.z, h = blockIdx.y;
+    // 1-D grid, XCD-aware: block b runs on XCD b%8 (observed dispatch); give each XCD a contiguous range
+    // of logical ids so the query blocks of one (sequence, head) share that XCD's L2 copy of K/V.
+    const int nqb = (p.nq + 127) / 128;
+    const int nwg = nqb * p.heads * p.S;
+    int logical;
+    {
+        const int bid = blockIdx.x, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    const int qb = logical % nqb;
+    const int h = (logical / nqb) % p.heads, s = logical / (nqb * p.heads);
     const int skv = (s + p.kv_shift) % p.S;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = qb * 128 + wave * 32;
 
     const size_t qoff = (size_t)(s * p.heads + h) * p.npad * 64;
     const size_t koff = (size_t)(skv * p.heads + h) * p.npad * 64;

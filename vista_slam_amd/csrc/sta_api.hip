@@ -4,6 +4,7 @@
 #include "../../include/sta_mi355.h"
 #include "gemm.h"
 #include "gemm2.h"
+#include "gemm3.h"
 #include "attention.h"
 #include "elementwise.h"
 
@@ -381,6 +382,22 @@ static int launch_gemm2(const GemmParams& p, hipStream_t st) {
 }
 
 template <int AMODE, int EPI>
+static int launch_gemm3(bool split, const GemmParams& p, hipStream_t st) {
+    static bool attr_done[2] = {false, false};
+    const int tm = (p.M + 255) / 256, tn = (p.N + 255) / 256;
+    if (split) {
+        constexpr int smem = gemm2_smem_bytes<true, 256, 256>();
+        if (!attr_done[1]) { HIPCHK(hipFuncSetAttribute((const void*)gemm3_kernel<true, AMODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr_done[1] = true; }
+        hipLaunchKernelGGL((gemm3_kernel<true, AMODE, EPI>), dim3((unsigned)(tm * tn)), dim3(256), smem, st, p);
+    } else {
+        constexpr int smem = gemm2_smem_bytes<false, 256, 256>();
+        if (!attr_done[0]) { HIPCHK(hipFuncSetAttribute((const void*)gemm3_kernel<false, AMODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr_done[0] = true; }
+        hipLaunchKernelGGL((gemm3_kernel<false, AMODE, EPI>), dim3((unsigned)(tm * tn)), dim3(256), smem, st, p);
+    }
+    return 0;
+}
+
+template <int AMODE, int EPI>
 static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
     GemmParams p = p_in;
     p.zero_page = h->zero_page;
@@ -514,7 +531,7 @@ static int run_attn(sta_handle* h, const QKVOut& qkv, const Planes& out, int ldo
     p.O_hi = out.hi; p.O_lo = out.lo; p.ldo = ldo;
     p.S = S; p.heads = heads; p.nq = nq; p.nk = nk; p.npad = qkv.npad; p.kv_shift = kv_shift;
     p.scale_log2e = 0.125f * 1.44269504088896340736f;
-    dim3 grid((nq + 127) / 128, heads, S);
+    dim3 grid((unsigned)(((nq + 127) / 128) * heads * S));
     if (h->prec == STA_PREC_F16X3) {
         static bool attr_done = false;
         if (!attr_done) { hipFuncSetAttribute((const void*)attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_smem_bytes<true>()); attr_done = true; }
@@ -1031,6 +1048,7 @@ extern "C" int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, int
         }
         if (tile == 2) return bench_launch2<256, 256, 2, 4, 0>(split, p, st);
         if (tile == 3) return bench_launch2<256, 128, 4, 2, 0>(split, p, st);
+        if (tile == 4) return launch_gemm3<A_DENSE, EPI_F32>(split, p, st);
         h->gemm_variant = tile == 1 ? 1 : 0;
         int r = launch_gemm<A_DENSE, EPI_F32>(h, p, st);
         h->gemm_variant = keep;
