@@ -14,7 +14,7 @@ extern "C" {
 #endif
 
 /* Force the GEMM tile family: 0 = automatic (product behaviour), 1 = 128x128 register-staged kernel,
- * 2 = 256-row direct-to-LDS kernel (whenever N % 128 == 0).  Lets the tests cover both families on
+ * 2 = 256-row direct-to-LDS kernels, 3 = 192-row ones (whenever N % 128 == 0).  Lets the tests cover the families on
  * small shapes. */
 int sta_set_gemm_variant(sta_handle* h, int variant);
 

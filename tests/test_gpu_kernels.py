@@ -20,7 +20,10 @@ def G():
                                 dict(act=2, via_f16=1), dict(M=1, N=96, K=32), dict(M=129, N=129, K=64),
                                 # 256-row direct-to-LDS family (forced on small shapes): 256x256 and 256x128 tiles, M tails
                                 dict(M=700, N=512, K=256, variant=2), dict(M=300, N=384, K=96, variant=2, resid=True),
-                                dict(M=513, N=256, K=1024, variant=2, act=1, via_f16=1), dict(M=5, N=128, K=32, variant=2, act=2, via_f16=1)])
+                                dict(M=513, N=256, K=1024, variant=2, act=1, via_f16=1), dict(M=5, N=128, K=32, variant=2, act=2, via_f16=1),
+                                # 192-row tiles (fractional DMA slot assignment)
+                                dict(M=700, N=512, K=256, variant=3), dict(M=385, N=384, K=96, variant=3, resid=True),
+                                dict(M=193, N=128, K=64, variant=3, act=1, via_f16=1)])
 def test_gemm(G, prec, kw):
     r = G.check_gemm(prec, **kw)
     assert r["rel_l2"] < TOL[prec], r
@@ -28,7 +31,8 @@ def test_gemm(G, prec, kw):
 
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("kw", [dict(), dict(hp=14, wp=14, pose_tok=0, S=1), dict(hp=3, wp=5, pose_tok=1, S=3),
-                                dict(hp=14, wp=14, pose_tok=1, S=2, variant=2), dict(hp=5, wp=7, pose_tok=0, S=3, Cdim=256, K=256, variant=2)])
+                                dict(hp=14, wp=14, pose_tok=1, S=2, variant=2), dict(hp=5, wp=7, pose_tok=0, S=3, Cdim=256, K=256, variant=2),
+                                dict(hp=14, wp=14, pose_tok=1, S=2, variant=3)])
 def test_qkv_rope(G, prec, kw):
     r = G.check_qkv_rope(prec, **kw)
     assert r["q"] < TOL[prec] and r["k"] < TOL[prec] and r["v"] < TOL[prec], r
@@ -49,7 +53,8 @@ def test_attention(G, prec, kw):
 @pytest.mark.parametrize("kw", [dict(), dict(stride=2), dict(stride=2, H=6, W_=8),
                                 dict(relu_in=1, act=2, resid=True, Cin=96, Co=256, H=9, W_=12), dict(H=1, W_=1),
                                 dict(relu_in=1, act=2, resid=True, Cin=96, Co=256, H=19, W_=23, variant=2),
-                                dict(Cin=64, Co=128, H=17, W_=9, variant=2), dict(stride=2, Cin=32, Co=256, H=15, W_=14, variant=2)])
+                                dict(Cin=64, Co=128, H=17, W_=9, variant=2), dict(stride=2, Cin=32, Co=256, H=15, W_=14, variant=2),
+                                dict(relu_in=1, act=2, resid=True, Cin=96, Co=256, H=19, W_=23, variant=3), dict(Cin=64, Co=128, H=17, W_=9, variant=3)])
 def test_conv3x3(G, prec, kw):
     r = G.check_conv3(prec, **kw)
     assert r["rel_l2"] < TOL[prec], r

@@ -29,9 +29,10 @@ def test_tiny_goldens_default_precision(G, case):
 @pytest.mark.parametrize("case", ["tiny_48x64_b2", "tiny_48x80_smooth_sharp"])
 def test_tiny_goldens_large_tile_kernel(G, case):
     """Same goldens with the 256-row direct-to-LDS GEMM family forced (the bench-scale kernels)."""
-    r = G.run_golden_case(case, "f16x3", variant=2)
-    bad = {k: v for k, v in r.items() if v > TOL}
-    assert not bad, bad
+    for variant in (2, 3):
+        r = G.run_golden_case(case, "f16x3", variant=variant)
+        bad = {k: v for k, v in r.items() if v > TOL}
+        assert not bad, (variant, bad)
 
 
 @pytest.mark.parametrize("case", ["tiny_32x32_b1", "tiny_48x64_b2_sharp"])

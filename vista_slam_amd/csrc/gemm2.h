@@ -39,8 +39,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
     constexpr int NPL = SPLIT ? 2 : 1;
     constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;
     constexpr int STAGE = NPL * (A_PLANE + B_PLANE);
-    constexpr int SA = BM / 16 / NW, SB = BN / 16 / NW;     // 1-KiB DMA slots per wave per plane
-    static_assert(SA >= 1 && SB >= 1 && BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "tile/wave mismatch");
+    // 1-KiB DMA slots (16 rows) per plane: slot g = wave + NW*s, valid while g < rows/16 (BM = 192 gives
+    // waves 0-3 two A slots and waves 4-7 one; the guard is wave-uniform)
+    constexpr int NSA = BM / 16, NSB = BN / 16;
+    constexpr int SA = (NSA + NW - 1) / NW, SB = (NSB + NW - 1) / NW;
+    static_assert(BM % 32 == 0 && BN % 32 == 0 && WM % 32 == 0 && WN % 32 == 0, "tile/wave mismatch");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -110,6 +113,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
         if (AMODE == A_CONV3) { tap = k0 / p.Cin; c0 = k0 - tap * p.Cin; ky = tap / 3; kx = tap - ky * 3; }
 #pragma unroll
         for (int s = 0; s < SA; ++s) {
+            if (NSA % NW != 0 && wave + NW * s >= NSA) continue;
             char* dst = sA + (wave + NW * s) * 1024;
             if (AMODE == A_DENSE) {
                 glds16(a_src_hi[s] + ka, dst);
@@ -124,6 +128,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
         }
 #pragma unroll
         for (int s = 0; s < SB; ++s) {
+            if (NSB % NW != 0 && wave + NW * s >= NSB) continue;
             char* dst = sB + (wave + NW * s) * 1024;
             glds16(b_src_hi[s] + kb, dst);
             if (SPLIT) glds16(b_src_lo[s] + kb, dst + B_PLANE);

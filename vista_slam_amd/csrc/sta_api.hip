@@ -310,7 +310,7 @@ extern "C" int sta_set_precision(sta_handle* h, int precision) {
     return 0;
 }
 extern "C" int sta_set_gemm_variant(sta_handle* h, int variant) {
-    REQUIRE(h && variant >= 0 && variant <= 2, "bad gemm variant");
+    REQUIRE(h && variant >= 0 && variant <= 3, "bad gemm variant");
     h->gemm_variant = variant;
     return 0;
 }
@@ -420,15 +420,33 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
         HIPCHK(hipEventRecord(h->kev[2 * h->kn], st));
         h->kn++;
     }
-    // Tile selection: the 256-row direct-to-LDS kernel when the grid still fills the chip, else the
-    // 128x128 kernel (small-M SLAM shapes, odd N).
-    const int64_t big_tiles = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
-    const int64_t mid_tiles = (int64_t)((p.M + 255) / 256) * ((p.N + 127) / 128);
+    // Tile selection by a measured cost model (tools/gemm_bench6/7.py on MI355X, f16x3):
+    //   time ~ rounds x (a*K + b) us, a = main-loop slope, b = fixed per-round cost (prologue + the
+    //   HBM-bound epilogue), rounds = tiles / resident slots.  Families whose LDS footprint admits two
+    //   workgroups per CU (192x128: 80 KiB, 128x128: 64 KiB) have 512 slots and overlap one block's
+    //   epilogue with the other's main loop, so their rounds are counted fractionally.
+    // It picks 192x256 for the encoder's N=1024 GEMMs (64x4 = 256 tiles = exactly one round instead of
+    // 192 tiles on 256 CUs), 256x256 for N=4096, 192x128 for the QKV epilogue and the decoder's odd
+    // grids, and the register-staged 128x128 kernel for small SLAM-scale problems.
+    struct Cand { int variant, bm, bn, slots; double a, b; };
+    static const Cand cands[] = {{2, 256, 256, 256, 0.0664, 26.0}, {4, 192, 256, 256, 0.0616, 17.7},
+                                 {3, 256, 128, 256, 0.0376, 16.0}, {5, 192, 128, 512, 0.0684, 11.4},
+                                 {1, 128, 128, 512, 0.0434, 12.4}};
     int variant = 1;
-    if (p.N % 256 == 0 && big_tiles >= 128) variant = 2;
-    else if (p.N % 128 == 0 && mid_tiles >= 128) variant = 3;
-    if (h->gemm_variant == 2 && p.N % 128 == 0) variant = p.N % 256 == 0 ? 2 : 3;
-    if (EPI == EPI_QKV && variant == 2) variant = 3;   // the RoPE epilogue spills at 128 accumulators
+    {
+        double best = 1e300;
+        for (const Cand& c : cands) {
+            if (c.variant != 1 && p.N % c.bn != 0) continue;
+            if (EPI == EPI_QKV && (c.variant == 2 || c.variant == 4)) continue;   // the RoPE epilogue spills beyond 96 accumulators/wave
+            const double tiles = (double)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn);
+            double rounds = tiles / c.slots;
+            rounds = c.slots == 256 ? ceil(rounds) : (rounds < 1.0 ? 1.0 : rounds + 0.1);
+            const double cost = rounds * (c.a * p.K + c.b);
+            if (cost < best) { best = cost; variant = c.variant; }
+        }
+    }
+    if (h->gemm_variant == 2 && p.N % 128 == 0) variant = (p.N % 256 == 0 && EPI != EPI_QKV) ? 2 : 3;
+    if (h->gemm_variant == 3 && p.N % 128 == 0) variant = (p.N % 256 == 0 && EPI != EPI_QKV) ? 4 : 5;
     if (h->gemm_variant == 1) variant = 1;
     if (variant == 2) {
         if (split) CHK((launch_gemm2<true, AMODE, EPI, 256, 256, 2, 4>(p, st)));
@@ -436,6 +454,12 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
     } else if (variant == 3) {
         if (split) CHK((launch_gemm2<true, AMODE, EPI, 256, 128, 4, 2>(p, st)));
         else CHK((launch_gemm2<false, AMODE, EPI, 256, 128, 4, 2>(p, st)));
+    } else if (variant == 4) {
+        if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 256, 2, 4>(p, st)));
+        else CHK((launch_gemm2<false, AMODE, EPI, 192, 256, 2, 4>(p, st)));
+    } else if (variant == 5) {
+        if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4>(p, st)));
+        else CHK((launch_gemm2<false, AMODE, EPI, 192, 128, 2, 4>(p, st)));
     } else {
         int tm = (p.M + GEMM_BM - 1) / GEMM_BM, tn = (p.N + GEMM_BN - 1) / GEMM_BN;
         dim3 grid((unsigned)(tm * tn));
@@ -1049,6 +1073,11 @@ extern "C" int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, int
         if (tile == 2) return bench_launch2<256, 256, 2, 4, 0>(split, p, st);
         if (tile == 3) return bench_launch2<256, 128, 4, 2, 0>(split, p, st);
         if (tile == 4) return launch_gemm3<A_DENSE, EPI_F32>(split, p, st);
+        if (tile == 5) return bench_launch2<192, 256, 2, 4, 0>(split, p, st);
+        if (tile == 6) return bench_launch2<192, 128, 2, 4, 0>(split, p, st);
+        if (tile == 7) return bench_launch2<192, 128, 2, 2, 0>(split, p, st);
+        if (tile == 8) return bench_launch2<128, 192, 2, 2, 0>(split, p, st);
+        if (tile == 9) return bench_launch2<128, 128, 2, 2, 0>(split, p, st);
         h->gemm_variant = tile == 1 ? 1 : 0;
         int r = launch_gemm<A_DENSE, EPI_F32>(h, p, st);
         h->gemm_variant = keep;
