@@ -146,9 +146,11 @@ int sta_get_stage_ms(sta_handle* h, float ms[4]);
 /* Per-launch hipEvent timing of the dominant kernel (gemm_kernel<.., dense, fp32 epilogue>: the
  * proj / fc2 / embed GEMMs) on the stream it is launched on.  enable!=0 resets the counters and
  * starts recording; sta_kernel_timing_read synchronises on the recorded events and returns the
- * number of launches, the summed kernel time and the summed algorithmic FLOPs (2*M*N*K). */
+ * number of launches, the summed kernel time, the summed algorithmic FLOPs (2*M*N*K) and bytes.
+ * tile_family selects ONE kernel symbol: 1 = gemm_kernel (128x128), 2..5 = gemm2_kernel 256x256,
+ * 256x128, 192x256, 192x128; 0 = all of them. */
 int sta_kernel_timing(sta_handle* h, int enable);
-int sta_kernel_timing_read(sta_handle* h, int* launches, double* total_ms, double* total_flops,
+int sta_kernel_timing_read(sta_handle* h, int tile_family, int* launches, double* total_ms, double* total_flops,
                            double* total_algorithmic_bytes);
 
 /* Time `iters` back-to-back launches of the dominant GEMM kernel (M x N x K, this handle's

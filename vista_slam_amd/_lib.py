@@ -47,7 +47,7 @@ SIGNATURES = {
     "sta_enable_stage_timing": (_i, [_vp, _i]),
     "sta_get_stage_ms": (_i, [_vp, C.POINTER(_f)]),
     "sta_kernel_timing": (_i, [_vp, _i]),
-    "sta_kernel_timing_read": (_i, [_vp, C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "sta_kernel_timing_read": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sta_bench_gemm": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(_f), _vp]),
     "sta_last_error": (C.c_char_p, []),
     "sta_version": (C.c_char_p, []),

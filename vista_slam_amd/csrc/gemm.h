@@ -41,6 +41,7 @@ struct GemmParams {
     // ---- EPI_QKV
     f16* Q_hi; f16* Q_lo; f16* K_hi; f16* K_lo; f16* Vt_hi; f16* Vt_lo;
     int nq, nk, nv, ntok, npad, heads, wp, has_pose_tok;
+    unsigned ntok_magic, wp_magic;                       // floor(2^32/d)+1 (0 when d == 1): exact n/d for n*d < 2^32
     const float* rope_tab;                               // [(pos+1)][16][2] cos,sin ; pos = -1 .. P-1
     // ---- EPI_CONVT
     int ct_k, ct_cout, ct_h, ct_w;
@@ -73,25 +74,90 @@ __device__ __forceinline__ uint4 relu_pair_hi(uint4 hi, uint4& lo) {
     return a.u;
 }
 
+__device__ __forceinline__ int fast_div(int n, int d, unsigned magic) {
+    return magic ? (int)__umulhi((unsigned)n, magic) : n;   // magic == 0 encodes d == 1
+}
+typedef uint2 __attribute__((aligned(2))) uint2_a2;   // 8-byte store of 4 halves at 2-byte alignment
+
+// QKV epilogue of one 32x32 accumulator tile: +bias, 2-D RoPE on q/k (pair partner = lane^16, cos/sin
+// from the table), head-major Q/K stores, and V written TRANSPOSED ([d][token]) - a lane owns one d
+// column and 4 consecutive tokens per register group, i.e. one 8-byte run of V^T per group.
+template <bool SPLIT>
+__device__ __forceinline__ void epilogue_qkv_tile(const GemmParams& p, const floatx16& acc, int row0, int col, int lane) {
+    const int lhi = lane >> 5;
+    const bool col_ok = col < p.N;
+    const float bv = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
+    const int cbase = (col - (lane & 31)) & ~63;
+    int seg = 0, cc = cbase;
+    if (cbase >= p.nq + p.nk) { seg = 2; cc = cbase - p.nq - p.nk; }
+    else if (cbase >= p.nq) { seg = 1; cc = cbase - p.nq; }
+    const int head = cc >> 6, dcol = col - cbase, xpart = (dcol >> 5) & 1;
+    if (seg == 2) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int rowg = row0 + 8 * g + 4 * lhi;
+            const int rc = rowg < p.M ? rowg : p.M - 1;
+            const int s = fast_div(rc, p.ntok, p.ntok_magic), t = rc - s * p.ntok;
+            f16 hh[4], ll[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = acc[g * 4 + e] + bv;
+                if (SPLIT) split_f16(v, hh[e], ll[e]); else { hh[e] = to_f16_sat(v); ll[e] = (f16)0; }
+            }
+            const size_t o = ((size_t)(s * p.heads + head) * 64 + dcol) * p.npad + t;
+            if (col_ok && rowg + 3 < p.M && t + 3 < p.ntok) {      // 4 tokens of one sequence: one run
+                H4 ph, pl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ph.e[e] = hh[e]; pl.e[e] = ll[e]; }
+                *reinterpret_cast<uint2_a2*>(p.Vt_hi + o) = ph.u;
+                if (SPLIT) *reinterpret_cast<uint2_a2*>(p.Vt_lo + o) = pl.u;
+            } else if (col_ok) {                                      // sequence boundary / M tail
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = rowg + e;
+                    if (row < p.M) {
+                        const int s2 = fast_div(row, p.ntok, p.ntok_magic), t2 = row - s2 * p.ntok;
+                        const size_t o2 = ((size_t)(s2 * p.heads + head) * 64 + dcol) * p.npad + t2;
+                        p.Vt_hi[o2] = hh[e];
+                        if (SPLIT) p.Vt_lo[o2] = ll[e];
+                    }
+                }
+            }
+        }
+        return;
+    }
+    f16* const dh = seg == 0 ? p.Q_hi : p.K_hi;
+    f16* const dl = seg == 0 ? p.Q_lo : p.K_lo;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const int rowc = row < p.M ? row : p.M - 1;
+        const int s = fast_div(rowc, p.ntok, p.ntok_magic), t = rowc - s * p.ntok;
+        const int tt = p.has_pose_tok ? t - 1 : t;
+        const int ty = tt < 0 ? 0 : fast_div(tt, p.wp, p.wp_magic);
+        const int pos = tt < 0 ? 0 : (xpart ? tt - ty * p.wp : ty) + 1;   // table row 0 == position -1 (pose token)
+        const float2 cs = *reinterpret_cast<const float2*>(p.rope_tab + ((size_t)pos * 16 + (lane & 15)) * 2);
+        float v = acc[r] + bv;
+        const float other = __shfl_xor(v, 16);
+        v = (lane & 16) ? (v * cs.x + other * cs.y) : (v * cs.x - other * cs.y);
+        if (col_ok && row < p.M) {
+            const size_t o = ((size_t)(s * p.heads + head) * p.npad + t) * 64 + dcol;
+            if (SPLIT) { f16 h, l; split_f16(v, h, l); dh[o] = h; dl[o] = l; }
+            else dh[o] = to_f16_sat(v);
+        }
+    }
+}
+
 // Epilogue of one 32x32 MFMA accumulator tile.  C/D layout of v_mfma_f32_32x32x16: this lane holds
 // column `col` (= tile col + lane&31) and rows row0 + (r&3) + 8*(r>>2) + 4*(lane>>5), r = 0..15.
 // The tile column origin is a multiple of 32 and (for EPI_QKV) segment/head boundaries are multiples
 // of 64, so segment, head and the RoPE half (y for d<32, x for d>=32) are wave-uniform.
 template <bool SPLIT, int EPI>
 __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx16& acc, int row0, int col, int lane) {
+    if (EPI == EPI_QKV) { epilogue_qkv_tile<SPLIT>(p, acc, row0, col, lane); return; }
     const int lhi = lane >> 5;
     const bool col_ok = col < p.N;
     const float bv = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
-    int seg = 0, head = 0, dcol = 0, xpart = 0;
-    if (EPI == EPI_QKV) {
-        int cbase = (col - (lane & 31)) & ~63;
-        int cc = cbase;
-        if (cbase >= p.nq + p.nk) { seg = 2; cc = cbase - p.nq - p.nk; }
-        else if (cbase >= p.nq) { seg = 1; cc = cbase - p.nq; }
-        head = cc >> 6;
-        dcol = col - cbase;
-        xpart = (dcol >> 5) & 1;
-    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
@@ -113,29 +179,6 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
                 if (p.R2_hi) { v += (float)p.R2_hi[o]; if (SPLIT) v += (float)p.R2_lo[o]; }
                 if (SPLIT) { f16 h, l; split_f16(v, h, l); p.C_hi[o] = h; p.C_lo[o] = l; }
                 else p.C_hi[o] = to_f16_sat(v);
-            }
-        } else if (EPI == EPI_QKV) {
-            const int rowc = row < p.M ? row : p.M - 1;
-            const int s = rowc / p.ntok, t = rowc - s * p.ntok;
-            if (seg < 2) {
-                int tt = p.has_pose_tok ? t - 1 : t;
-                int py = tt < 0 ? -1 : tt / p.wp;
-                int px = tt < 0 ? -1 : tt - (tt / p.wp) * p.wp;
-                int pos = (xpart ? px : py) + 1;
-                const float2 cs = *reinterpret_cast<const float2*>(p.rope_tab + ((size_t)pos * 16 + (lane & 15)) * 2);
-                float other = __shfl_xor(v, 16);
-                v = (lane & 16) ? (v * cs.x + other * cs.y) : (v * cs.x - other * cs.y);
-                if (ok) {
-                    size_t o = ((size_t)(s * p.heads + head) * p.npad + t) * 64 + dcol;
-                    f16* dh = seg == 0 ? p.Q_hi : p.K_hi;
-                    f16* dl = seg == 0 ? p.Q_lo : p.K_lo;
-                    if (SPLIT) { f16 h, l; split_f16(v, h, l); dh[o] = h; dl[o] = l; }
-                    else dh[o] = to_f16_sat(v);
-                }
-            } else if (ok) {
-                size_t o = ((size_t)(s * p.heads + head) * 64 + dcol) * p.npad + t;
-                if (SPLIT) { f16 h, l; split_f16(v, h, l); p.Vt_hi[o] = h; p.Vt_lo[o] = l; }
-                else p.Vt_hi[o] = to_f16_sat(v);
             }
         } else {  // EPI_CONVT
             if (ok) {

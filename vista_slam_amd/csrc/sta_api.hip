@@ -72,7 +72,7 @@ struct sta_handle {
     // timing
     bool timing = false; hipEvent_t ev[5]; bool ev_ok = false;
     // per-launch timing of the dominant kernel (gemm_kernel<*, A_DENSE, EPI_F32>) for the roofline report
-    bool ktime = false; std::vector<hipEvent_t> kev; int kn = 0; std::vector<double> kflops, kbytes;
+    bool ktime = false; std::vector<hipEvent_t> kev; int kn = 0; std::vector<double> kflops, kbytes; std::vector<int> kvar;
     bool dry = false;   // planning pass: run the orchestration without launching to size the workspace
 };
 
@@ -431,7 +431,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
     struct Cand { int variant, bm, bn, slots; double a, b; };
     static const Cand cands[] = {{2, 256, 256, 256, 0.0664, 26.0}, {4, 192, 256, 256, 0.0616, 17.7},
                                  {3, 256, 128, 256, 0.0376, 16.0}, {5, 192, 128, 512, 0.0684, 11.4},
-                                 {1, 128, 128, 512, 0.0434, 12.4}};
+                                 {1, 128, 128, 512, 0.056, 18.0}};
     int variant = 1;
     {
         double best = 1e300;
@@ -475,7 +475,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
         }
     }
     HIPCHK(hipGetLastError());
-    if (timed) HIPCHK(hipEventRecord(h->kev[2 * (h->kn - 1) + 1], st));
+    if (timed) { HIPCHK(hipEventRecord(h->kev[2 * (h->kn - 1) + 1], st)); if ((int)h->kvar.size() < h->kn) h->kvar.resize(h->kn); h->kvar[h->kn - 1] = variant; }
     return 0;
 }
 
@@ -507,6 +507,8 @@ static int gemm_qkv(sta_handle* h, const Planes& A, const Lin& W, int M, int nq,
     p.Q_hi = o.q.hi; p.Q_lo = o.q.lo; p.K_hi = o.k.hi; p.K_lo = o.k.lo; p.Vt_hi = o.vt.hi; p.Vt_lo = o.vt.lo;
     p.nq = nq; p.nk = nk; p.nv = nv; p.ntok = ntok; p.npad = o.npad; p.heads = heads; p.wp = wp; p.has_pose_tok = has_pose;
     p.rope_tab = h->rope_tab;
+    p.ntok_magic = ntok > 1 ? (unsigned)((1ull << 32) / (unsigned)ntok + 1) : 0u;
+    p.wp_magic = wp > 1 ? (unsigned)((1ull << 32) / (unsigned)wp + 1) : 0u;
     REQUIRE(nq + nk + nv == W.N, "qkv segment mismatch");
     return launch_gemm<A_DENSE, EPI_QKV>(h, p, st);
 }
@@ -948,16 +950,19 @@ extern "C" int sta_kernel_timing(sta_handle* h, int enable) {
     h->ktime = enable != 0; h->kn = 0;
     return 0;
 }
-extern "C" int sta_kernel_timing_read(sta_handle* h, int* launches, double* total_ms, double* total_flops, double* total_bytes) {
+extern "C" int sta_kernel_timing_read(sta_handle* h, int variant, int* launches, double* total_ms, double* total_flops, double* total_bytes) {
     REQUIRE(h && launches && total_ms && total_flops && total_bytes, "null argument");
     HIPCHK(hipSetDevice(h->device));
     double ms = 0, fl = 0, by = 0;
+    int cnt = 0;
     for (int i = 0; i < h->kn; ++i) {
+        if (variant > 0 && h->kvar[i] != variant) continue;
+        ++cnt;
         HIPCHK(hipEventSynchronize(h->kev[2 * i + 1]));
         float t = 0; HIPCHK(hipEventElapsedTime(&t, h->kev[2 * i], h->kev[2 * i + 1]));
         ms += t; fl += h->kflops[i]; by += h->kbytes[i];
     }
-    *launches = h->kn; *total_ms = ms; *total_flops = fl; *total_bytes = by;
+    *launches = cnt; *total_ms = ms; *total_flops = fl; *total_bytes = by;
     return 0;
 }
 

@@ -281,9 +281,9 @@ class STAFrontend:
     def kernel_timing(self, on: bool = True):
         _lib.check(self.lib.sta_kernel_timing(self._h, int(on)))
 
-    def kernel_timing_read(self):
+    def kernel_timing_read(self, tile_family: int = 0):
         n, ms, fl, by = C.c_int(), C.c_double(), C.c_double(), C.c_double()
-        _lib.check(self.lib.sta_kernel_timing_read(self._h, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)))
+        _lib.check(self.lib.sta_kernel_timing_read(self._h, tile_family, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)))
         return int(n.value), float(ms.value), float(fl.value), float(by.value)
 
     def bench_gemm(self, M: int, N: int, K: int, iters: int = 20, tile: int = 0, ablation: int = 0) -> float:
