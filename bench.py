@@ -44,6 +44,35 @@ def pmc_traffic():
     return None
 
 
+def slam_probe(model, dev, iters=20):
+    """Secondary figure: latency of the split entry points exactly as OnlineSLAM calls them
+    (slam.py:144,162,165,179-180) at the SLAM resolution 224x224, batch 1 (launch-bound regime)."""
+    import torch
+    from vista_slam_amd import weights as Wt
+    imgs = torch.from_numpy(Wt.synth_images(2, 224, 224, seed=43, tag=7)).to(dev)
+    ts = torch.tensor([[224, 224]])
+
+    def timed(fn):
+        for _ in range(3):
+            out = fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            out = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3, out
+    enc_ms, (fa, pa) = timed(lambda: model._encode_image(imgs[:1], ts, normalize=False))
+    fb, pb = model._encode_image(imgs[1:], ts, normalize=False)
+    dec_ms, (d1, d2) = timed(lambda: model._decode_stereo(fa, fb, pa, pb))
+    pose_ms, _ = timed(lambda: model.head_pose_s(d1[-1][:, 0, :]))
+    dpt_ms, _ = timed(lambda: model.head_pts([fa] + [t[:, 1:, :] for t in d1], ts))
+    pair_ms = dec_ms + pose_ms + 2 * dpt_ms
+    return {"encode_ms": round(enc_ms, 3), "decode_ms": round(dec_ms, 3), "pose_ms": round(pose_ms, 3),
+            "dpt_ms_per_view": round(dpt_ms, 3), "accepted_pair_ms": round(pair_ms, 3),
+            "keyframes_per_s_est_5pairs": round(1e3 / (enc_ms + 5 * pair_ms), 2),
+            "note": "frontend-only estimate for a TUM-style keyframe (1 encode + 5 accepted pairs); the reference's CPU stages (ORB/DBoW3, PGO) are not included"}
+
+
 def cpu_baseline():
     """Oracle (port of the reference algorithm, fp32, OpenMP) on the host cores: one 224x224 pair
     (BASELINE config 1 shape) - a bounded sample (~10-30 s) of the same per-pair workload."""
@@ -71,6 +100,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="image pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-slam-probe", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -162,6 +192,8 @@ def main():
                "whole_path_tflops": round(pairs * flops_pair / dt / 1e12, 1),
                "workspace_gb": round(model.workspace_bytes() / 1e9, 2),
                "roofline": roof}
+        if world == 1 and not args.no_slam_probe:
+            res["slam_224_b1"] = slam_probe(model, dev)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline()

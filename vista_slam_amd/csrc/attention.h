@@ -165,22 +165,25 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);
+        // raw v_exp_f32: arguments are <= 0 (or -inf), results in [0,1]; no denormal/overflow handling needed
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float pv = exp2f(sacc[t][r] - m_new);
+                float pv = __builtin_amdgcn_exp2f(sacc[t][r] - m_new);
                 sacc[t][r] = pv;
                 psum += pv;
             }
         l_run = l_run * alpha + psum;
         m_run = m_new;
+        if (!__all(alpha == 1.0f)) {     // running max unchanged for every query of the wave: nothing to rescale
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+            for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+                for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+        }
 
         // ---- O^T += V^T P^T   (k index of the MFMA = 8*lhi + j  <->  key t*32 + 16w + 8(j>>2) + 4lhi + (j&3))
 #pragma unroll
