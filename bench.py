@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-slam-probe", action="store_true")
+    ap.add_argument("--gemm-variant", type=int, default=0, help="experiments only: force a GEMM tile family (0 = product selection)")
     args = ap.parse_args()
 
     import torch
@@ -119,6 +120,9 @@ def main():
     dev = f"cuda:{local}"
 
     model = STAFrontend(Wt.FULL, dev, precision=args.precision).load_procedural(seed=43)
+    if args.gemm_variant:
+        from vista_slam_amd import _lib
+        _lib.check(model.lib.sta_set_gemm_variant(model._h, args.gemm_variant))
     B = args.pairs
     imgs = Wt.synth_images(2 * B, H, W_, seed=43, tag=rank)          # different pairs on every rank
     img_a = torch.from_numpy(imgs[:B]).to(dev)
