@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     const float inv = 1.0f / l_tot;
     const int q = q0 + l31;
     if (q < p.nq) {
-        const size_t ob = (size_t)(s * p.nq + q) * p.ldo + h * 64;
+        const int64_t orow = (int64_t)s * p.nq + q, orows = (int64_t)p.S * p.nq;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -242,8 +242,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
                     if (SPLIT) split_f16(v, oh.e[e], ol.e[e]); else oh.e[e] = to_f16_sat(v);
                 }
                 const int dcol = d * 32 + 8 * g + 4 * lhi;
-                *reinterpret_cast<uint2*>(p.O_hi + ob + dcol) = oh.u;
-                if (SPLIT) *reinterpret_cast<uint2*>(p.O_lo + ob + dcol) = ol.u;
+                const size_t o = blk_off<SPLIT>(orow, h * 64 + dcol, orows);    // blocked planes [ldo/32][S*nq][hi32|lo32]
+                *reinterpret_cast<uint2*>(p.O_hi + o) = oh.u;
+                if (SPLIT) *reinterpret_cast<uint2*>(p.O_hi + o + 32) = ol.u;
             }
     }
 }

@@ -57,8 +57,9 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
                     H4 h, l;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e]); else h.e[e] = to_f16_sat(y[e]); }
-                    *reinterpret_cast<uint2*>(p.o1_hi + (size_t)row * p.C + idx) = h.u;
-                    if (SPLIT) *reinterpret_cast<uint2*>(p.o1_lo + (size_t)row * p.C + idx) = l.u;
+                    const size_t o = blk_off<SPLIT>(row, idx, p.M);
+                    *reinterpret_cast<uint2*>(p.o1_hi + o) = h.u;
+                    if (SPLIT) *reinterpret_cast<uint2*>(p.o1_hi + o + 32) = l.u;
                 }
             }
             if (p.g2) {
@@ -68,8 +69,9 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
                 H4 h, l;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e]); else h.e[e] = to_f16_sat(y[e]); }
-                *reinterpret_cast<uint2*>(p.o2_hi + (size_t)row * p.C + idx) = h.u;
-                if (SPLIT) *reinterpret_cast<uint2*>(p.o2_lo + (size_t)row * p.C + idx) = l.u;
+                const size_t o = blk_off<SPLIT>(row, idx, p.M);
+                *reinterpret_cast<uint2*>(p.o2_hi + o) = h.u;
+                if (SPLIT) *reinterpret_cast<uint2*>(p.o2_hi + o + 32) = l.u;
             }
         }
     }
@@ -79,7 +81,8 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
 // fp32 rows [nb, rows, C] (batch stride bstride floats) -> contiguous fp16 planes [nb*rows, C].
 template <bool SPLIT>
 __global__ void rows_to_planes_kernel(const float* x, int64_t bstride, int rows, int C, int64_t total4,
-                                      f16* o_hi, f16* o_lo, int64_t obstride /* output batch stride in rows; 0 = rows */) {
+                                      f16* o_hi, f16* o_lo, int64_t obstride /* output batch stride in rows; 0 = rows */,
+                                      int64_t orows /* rows of the blocked output planes; 0 = row-major [.,C] (Q/K buffers) */) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
     const int c4 = C / 4;
@@ -92,20 +95,27 @@ __global__ void rows_to_planes_kernel(const float* x, int64_t bstride, int rows,
 #pragma unroll
         for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e]); else h.e[e] = to_f16_sat(y[e]); }
         const int64_t orow = obstride ? b * obstride + rr : r;
-        *reinterpret_cast<uint2*>(o_hi + orow * C + c) = h.u;
-        if (SPLIT) *reinterpret_cast<uint2*>(o_lo + orow * C + c) = l.u;
+        if (orows) {
+            const size_t o = blk_off<SPLIT>(orow, c, orows);
+            *reinterpret_cast<uint2*>(o_hi + o) = h.u;
+            if (SPLIT) *reinterpret_cast<uint2*>(o_hi + o + 32) = l.u;
+        } else {
+            *reinterpret_cast<uint2*>(o_hi + orow * C + c) = h.u;
+            if (SPLIT) *reinterpret_cast<uint2*>(o_lo + orow * C + c) = l.u;
+        }
     }
 }
 
 // planes [nb, rows(+pad), C] -> fp32 [nb, rows, C]  (test/debug taps only)
 __global__ void planes_to_f32_kernel(const f16* hi, const f16* lo, int64_t ibstride_rows, int rows, int C,
-                                     int64_t total, float* out) {
+                                     int64_t total, float* out, int64_t irows /* blocked planes with irows rows; 0 = row-major */) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
     for (; i < total; i += step) {
         int64_t r = i / C; int c = (int)(i - r * C);
         int64_t b = r / rows; int rr = (int)(r - b * rows);
-        int64_t src = ((ibstride_rows ? b * ibstride_rows + rr : r)) * C + c;
+        const int64_t srow = ibstride_rows ? b * ibstride_rows + rr : r;
+        const size_t src = irows ? (lo ? blk_off<true>(srow, c, irows) : blk_off<false>(srow, c, irows)) : (size_t)(srow * C + c);
         float v = (float)hi[src]; if (lo) v += (float)lo[src];
         out[i] = v;
     }
@@ -127,7 +137,7 @@ __global__ void pack_vt_kernel(const float* v, int nb, int rows, int npad, f16* 
 // img NCHW fp32 [n,3,H,W] -> planes [n*hp*wp, 768], K order (c, ky, kx) == conv weight flatten.
 // One thread = one (token, c, ky) row of 16 pixels (64 B in, 32 B out per plane).
 template <bool SPLIT>
-__global__ void patch_gather_kernel(const float* img, int n, int H, int W, f16* o_hi, f16* o_lo) {
+__global__ void patch_gather_kernel(const float* img, int n, int H, int W, f16* o_hi, f16* o_lo, int64_t row0, int64_t orows) {
     const int hp = H / 16, wp = W / 16;
     const int64_t total = (int64_t)n * hp * wp * 48;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -150,9 +160,9 @@ __global__ void patch_gather_kernel(const float* img, int n, int H, int W, f16* 
                 if (k < 8) { h0.e[k] = hh; l0.e[k] = ll; } else { h1.e[k - 8] = hh; l1.e[k - 8] = ll; }
             }
         }
-        size_t o = (size_t)tok * 768 + ck * 16;
+        const size_t o = blk_off<SPLIT>(row0 + tok, ck * 16, orows);
         *reinterpret_cast<uint4*>(o_hi + o) = h0.u; *reinterpret_cast<uint4*>(o_hi + o + 8) = h1.u;
-        if (SPLIT) { *reinterpret_cast<uint4*>(o_lo + o) = l0.u; *reinterpret_cast<uint4*>(o_lo + o + 8) = l1.u; }
+        if (SPLIT) { *reinterpret_cast<uint4*>(o_hi + o + 32) = l0.u; *reinterpret_cast<uint4*>(o_hi + o + 40) = l1.u; }
     }
 }
 
@@ -183,11 +193,12 @@ __global__ void bilinear_up2_kernel(const f16* i_hi, const f16* i_lo, int n, int
         int y1 = y0 + (y0 < Hi - 1), x1 = x0 + (x0 < Wi - 1);
         float fy = sy - y0, fx = sx - x0;
         const size_t base = (size_t)b * Hi * Wi;
-        const size_t o00 = ((base + (size_t)y0 * Wi + x0) * C) + c, o01 = ((base + (size_t)y0 * Wi + x1) * C) + c;
-        const size_t o10 = ((base + (size_t)y1 * Wi + x0) * C) + c, o11 = ((base + (size_t)y1 * Wi + x1) * C) + c;
+        const int64_t irows = (int64_t)n * Hi * Wi;
+        const size_t o00 = blk_off<SPLIT>(base + (size_t)y0 * Wi + x0, c, irows), o01 = blk_off<SPLIT>(base + (size_t)y0 * Wi + x1, c, irows);
+        const size_t o10 = blk_off<SPLIT>(base + (size_t)y1 * Wi + x0, c, irows), o11 = blk_off<SPLIT>(base + (size_t)y1 * Wi + x1, c, irows);
         H8 a, b_, c_, d; a.u = ldg16(i_hi + o00); b_.u = ldg16(i_hi + o01); c_.u = ldg16(i_hi + o10); d.u = ldg16(i_hi + o11);
         H8 al, bl, cl, dl;
-        if (SPLIT) { al.u = ldg16(i_lo + o00); bl.u = ldg16(i_lo + o01); cl.u = ldg16(i_lo + o10); dl.u = ldg16(i_lo + o11); }
+        if (SPLIT) { al.u = ldg16(i_hi + o00 + 32); bl.u = ldg16(i_hi + o01 + 32); cl.u = ldg16(i_hi + o10 + 32); dl.u = ldg16(i_hi + o11 + 32); }
         H8 oh, ol;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -199,9 +210,9 @@ __global__ void bilinear_up2_kernel(const f16* i_hi, const f16* i_lo, int n, int
             float v = (1.f - fy) * top + fy * bot;
             if (SPLIT) split_f16(v, oh.e[e], ol.e[e]); else oh.e[e] = to_f16_sat(v);
         }
-        size_t o = (((size_t)b * Hc + y) * Wc + x) * C + c;
+        const size_t o = blk_off<SPLIT>(((size_t)b * Hc + y) * Wc + x, c, (int64_t)n * Hc * Wc);
         *reinterpret_cast<uint4*>(o_hi + o) = oh.u;
-        if (SPLIT) *reinterpret_cast<uint4*>(o_lo + o) = ol.u;
+        if (SPLIT) *reinterpret_cast<uint4*>(o_hi + o + 32) = ol.u;
     }
 }
 
@@ -211,7 +222,7 @@ __global__ void bilinear_up2_kernel(const f16* i_hi, const f16* i_lo, int n, int
 //   pts = xyz / max(|xyz|,1e-8) * expm1(|xyz|),  conf = 1 + exp(c)
 // Input planes [npix, 128] (ReLU already applied by the producing conv).  16 lanes per pixel.
 template <bool SPLIT>
-__global__ __launch_bounds__(256) void head_final_kernel(const f16* i_hi, const f16* i_lo, int64_t npix,
+__global__ __launch_bounds__(256) void head_final_kernel(const f16* i_hi, const f16* i_lo, int64_t pix0, int64_t irows, int64_t npix,
                                                          const float* w /*[4][128]*/, const float* bias /*[4]*/,
                                                          float* pts, float* conf) {
     const int sub = threadIdx.x & 15;
@@ -228,8 +239,9 @@ __global__ __launch_bounds__(256) void head_final_kernel(const f16* i_hi, const 
         const bool ok = pix < npix;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         if (ok) {
-            H8 a; a.u = ldg16(i_hi + pix * 128 + sub * 8);
-            H8 al; if (SPLIT) al.u = ldg16(i_lo + pix * 128 + sub * 8);
+            const size_t o = blk_off<SPLIT>(pix0 + pix, sub * 8, irows);
+            H8 a; a.u = ldg16(i_hi + o);
+            H8 al; if (SPLIT) al.u = ldg16(i_hi + o + 32);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float v = (float)a.e[e]; if (SPLIT) v += (float)al.e[e];
@@ -376,7 +388,7 @@ __global__ void rope2d_inplace_kernel(float* tok, int64_t sb, int64_t sn, const 
 //   mode 1: conv [Co,Ci,kh,kw] -> [Co][kh][kw][Ci]
 //   mode 2: transposed conv [Ci,Co,k,k] -> [(dy*k+dx)*Co+co][Ci]
 __global__ void repack_weight_kernel(const float* src, f16* hi, f16* lo, int64_t total, int mode,
-                                     int d0, int d1, int d2, int d3) {
+                                     int d0, int d1, int d2, int d3, int64_t N, int64_t K, int64_t n_off) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
     for (; i < total; i += step) {
@@ -389,7 +401,10 @@ __global__ void repack_weight_kernel(const float* src, f16* hi, f16* lo, int64_t
             si = (((int64_t)ci * d1 + co) * d2 + dy) * d3 + dx;
         }
         f16 h, l; split_f16(src[si], h, l);
-        hi[i] = h; lo[i] = l;
+        // logical packed index i = n*K + k  ->  blocked [K/32][N][hi32|lo32]
+        const int64_t nl = i / K, k = i - nl * K, n = nl + n_off;
+        const size_t o = ((size_t)(k >> 5) * N + n) * 64 + (k & 31);
+        hi[o] = h; hi[o + 32] = l;
     }
 }
 

@@ -27,7 +27,8 @@ enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
 
 struct GemmParams {
     // ---- A operand
-    const f16* A_hi; const f16* A_lo; int lda;          // dense [M, lda]
+    const f16* A_hi; const f16* A_lo; int lda;          // blocked planes (A_lo == A_hi + 32 in f16x3); lda unused
+    int64_t a_rp;                                        // rows of the A planes (pixels of the conv input)
     int Hi, Wi, Cin, Ho, Wo, cstride, relu_in;           // conv3x3: NHWC [nimg,Hi,Wi,Cin] -> [nimg,Ho,Wo,*]
     // ---- B operand (weights, [N,K] planes) and bias
     const f16* B_hi; const f16* B_lo; const float* bias;
@@ -36,7 +37,8 @@ struct GemmParams {
     float* C32; int ldc; const float* resid; int ldr;
     int rows_in, rows_out, row_off;                      // out_row = (m/rows_in)*rows_out + row_off + m%rows_in
     // ---- EPI_F16
-    f16* C_hi; f16* C_lo; int ldc16; int act;
+    f16* C_hi; f16* C_lo; int ldc16; int act;            // blocked output planes with c_rp rows (ldc16 unused)
+    int64_t c_rp;
     const f16* R1_hi; const f16* R1_lo; const f16* R2_hi; const f16* R2_lo;
     // ---- EPI_QKV
     f16* Q_hi; f16* Q_lo; f16* K_hi; f16* K_lo; f16* Vt_hi; f16* Vt_lo;
@@ -174,10 +176,10 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
             if (ok) {
                 if (p.act == ACT_GELU) v = gelu_erf(v);
                 else if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-                size_t o = (size_t)row * p.ldc16 + col;
-                if (p.R1_hi) { v += (float)p.R1_hi[o]; if (SPLIT) v += (float)p.R1_lo[o]; }
-                if (p.R2_hi) { v += (float)p.R2_hi[o]; if (SPLIT) v += (float)p.R2_lo[o]; }
-                if (SPLIT) { f16 h, l; split_f16(v, h, l); p.C_hi[o] = h; p.C_lo[o] = l; }
+                const size_t o = blk_off<SPLIT>(row, col, p.c_rp);
+                if (p.R1_hi) { v += (float)p.R1_hi[o]; if (SPLIT) v += (float)p.R1_hi[o + 32]; }
+                if (p.R2_hi) { v += (float)p.R2_hi[o]; if (SPLIT) v += (float)p.R2_hi[o + 32]; }
+                if (SPLIT) { f16 h, l; split_f16(v, h, l); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
                 else p.C_hi[o] = to_f16_sat(v);
             }
         } else {  // EPI_CONVT
@@ -187,8 +189,9 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
                 int hw = p.ct_h * p.ct_w;
                 int img = row / hw, rem = row - img * hw;
                 int y = rem / p.ct_w, x = rem - y * p.ct_w;
-                size_t o = (((size_t)img * (p.ct_h * p.ct_k) + (y * p.ct_k + dy)) * (p.ct_w * p.ct_k) + (x * p.ct_k + dx)) * p.ct_cout + co;
-                if (SPLIT) { f16 h, l; split_f16(v, h, l); p.C_hi[o] = h; p.C_lo[o] = l; }
+                const size_t opix = ((size_t)img * (p.ct_h * p.ct_k) + (y * p.ct_k + dy)) * (p.ct_w * p.ct_k) + (x * p.ct_k + dx);
+                const size_t o = blk_off<SPLIT>(opix, co, p.c_rp);
+                if (SPLIT) { f16 h, l; split_f16(v, h, l); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
                 else p.C_hi[o] = to_f16_sat(v);
             }
         }
@@ -226,8 +229,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         int gm = m0 + row;
         if (AMODE == A_DENSE) {
             int gmc = gm < p.M ? gm : p.M - 1;
-            a_ptr_hi[i] = p.A_hi + (size_t)gmc * p.lda + kc * 8;
-            a_ptr_lo[i] = SPLIT ? p.A_lo + (size_t)gmc * p.lda + kc * 8 : nullptr;
+            a_ptr_hi[i] = p.A_hi + (size_t)gmc * (SPLIT ? 64 : 32) + kc * 8;
+            a_ptr_lo[i] = SPLIT ? a_ptr_hi[i] + 32 : nullptr;
         } else {
             cv_ok[i] = gm < p.M;
             int gmc = cv_ok[i] ? gm : 0;
@@ -240,20 +243,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         }
         int gn = n0 + row;
         int gnc = gn < p.N ? gn : p.N - 1;
-        b_ptr_hi[i] = p.B_hi + (size_t)gnc * p.K + kc * 8;
-        b_ptr_lo[i] = SPLIT ? p.B_lo + (size_t)gnc * p.K + kc * 8 : nullptr;
+        b_ptr_hi[i] = p.B_hi + (size_t)gnc * 64 + kc * 8;          // weights: [K/32][N][hi32|lo32]
+        b_ptr_lo[i] = SPLIT ? b_ptr_hi[i] + 32 : nullptr;
     }
 
     uint4 ra_hi[2], ra_lo[2], rb_hi[2], rb_lo[2];
     const int nkt = p.K / GEMM_BK;
 
+    const size_t a_kstride = (size_t)p.a_rp * (SPLIT ? 64 : 32), b_kstride = (size_t)p.N * 64;
     auto load_tile = [&](int kt) {
         const int k0 = kt * GEMM_BK;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (AMODE == A_DENSE) {
-                ra_hi[i] = ldg16(a_ptr_hi[i] + k0);
-                if (SPLIT) ra_lo[i] = ldg16(a_ptr_lo[i] + k0);
+                ra_hi[i] = ldg16(a_ptr_hi[i] + kt * a_kstride);
+                if (SPLIT) ra_lo[i] = ldg16(a_ptr_lo[i] + kt * a_kstride);
             } else {
                 int tap = k0 / p.Cin;
                 int c0 = k0 - tap * p.Cin;
@@ -263,9 +267,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
                 uint4 z = make_uint4(0, 0, 0, 0);
                 ra_hi[i] = z; if (SPLIT) ra_lo[i] = z;
                 if (ok) {
-                    size_t off = ((size_t)(cv_img[i] * p.Hi + yi) * p.Wi + xi) * p.Cin + c0 + a_kc[i] * 8;
+                    size_t off = ((size_t)(c0 >> 5) * p.a_rp + (size_t)(cv_img[i] * p.Hi + yi) * p.Wi + xi) * (SPLIT ? 64 : 32) + a_kc[i] * 8;
                     ra_hi[i] = ldg16(p.A_hi + off);
-                    if (SPLIT) ra_lo[i] = ldg16(p.A_lo + off);
+                    if (SPLIT) ra_lo[i] = ldg16(p.A_hi + off + 32);
                     if (p.relu_in) {
                         uint4 lo = SPLIT ? ra_lo[i] : z;
                         ra_hi[i] = relu_pair_hi(ra_hi[i], lo);
@@ -273,8 +277,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
                     }
                 }
             }
-            rb_hi[i] = ldg16(b_ptr_hi[i] + k0);
-            if (SPLIT) rb_lo[i] = ldg16(b_ptr_lo[i] + k0);
+            rb_hi[i] = ldg16(b_ptr_hi[i] + kt * b_kstride);
+            if (SPLIT) rb_lo[i] = ldg16(b_ptr_lo[i] + kt * b_kstride);
         }
     };
     auto store_tile = [&](int stage) {

@@ -1,21 +1,23 @@
-// Large-tile MFMA GEMM / implicit-GEMM conv for gfx950 (the throughput kernel).
+// Large-tile MFMA GEMM / implicit-GEMM conv for gfx950 (the throughput kernel family).
 //
-// Same math, operands, epilogues and GemmParams as gemm.h; different machine mapping:
-//  * BM x BN x 32 block tile with BM = 256, BN in {256, 128}, 8 waves (512 threads, 2 waves per SIMD,
-//    one workgroup per CU).  256x256: waves 2(M) x 4(N), each 128x64 = 4x2 MFMA 32x32 tiles
-//    (128 accumulator registers).  Per K step a wave issues 12 ds_read_b128 for 24 (split: 3 products)
-//    v_mfma_f32_32x32x16_f16, i.e. 48 MFMAs (1536 matrix-pipe cycles) per barrier - 4x the work per
-//    barrier and half the L2->LDS bytes per FLOP of the 128x128 kernel.
-//  * Operands go global -> LDS directly (global_load_lds_dwordx4, no VGPR round trip, no ds_write):
-//    each wave instruction fills 1 KiB = 16 rows x 64 B.  LDS stays lane-linear as the DMA requires;
-//    the bank-conflict swizzle (16-B chunk ^= (row>>2)&3) is applied to the per-lane SOURCE address
-//    and again on the fragment read (same involution on both sides).
-//  * Two LDS stages (2 x 64 KiB for the split 256x256 tile): DMA of tile k+1 overlaps the MFMAs of
-//    tile k; one vmcnt(0) + barrier per K step.
-//  * 3x3 conv taps that fall outside the image read a zero page (the DMA cannot synthesise zeros);
-//    the RCU's input ReLU is applied on the fragment registers.
-//  * Block id -> tile: bijective XCD remap (consecutive logical tiles share an XCD's L2) and
-//    band-major order (4 M-tiles x all N-tiles) so co-resident blocks reuse A row panels / W panels.
+// Same math, epilogues and GemmParams as gemm.h; different machine mapping:
+//  * BM x BN x 32 block tile (256x256, 256x128, 192x256, 192x128), 8 waves (512 threads).  The 192x128
+//    tile needs 80 KiB of LDS and ~110 VGPRs, so TWO workgroups share a CU: one block's HBM-bound
+//    epilogue and barrier bubbles are covered by the other's main loop (measured: the best family
+//    in-model, sta_api.hip cost model).
+//  * Operands go global -> LDS directly (global_load_lds_dwordx4: no VGPR round trip, no ds_write).
+//    Activations and weights live in the K-tile-blocked layout  [K/32][rows][hi32|lo32]  (blk_off in
+//    sta_common.h): one K tile of 8 consecutive rows is 1 KiB of CONTIGUOUS memory, i.e. every DMA
+//    wave-instruction reads 8 full 128-B lines (row-major operands gave half-line 64-B pieces and
+//    25 % less DMA throughput, tools/gemm_bench2.py).
+//  * LDS image (f16x3): rows of 128 B = [hi 32 halves | lo 32 halves]; the 16-B chunk index is XORed
+//    with (row>>1)&7 so the fragment ds_read_b128 is bank-conflict free.  The DMA writes lane-linear,
+//    so the XOR is applied to the per-lane SOURCE chunk (same involution on both sides).
+//    (f16: rows of 64 B, chunk ^ (row>>2)&3, weights still read from the interleaved layout.)
+//  * Two LDS stages: the DMA of tile k+1 overlaps the MFMAs of tile k; one vmcnt(0)+barrier per K tile.
+//  * 3x3 conv taps outside the image read a zero page; the RCU's input ReLU is applied on fragments.
+//  * Block id -> tile: bijective XCD remap + band-major order (4 M-tiles x all N-tiles) so the blocks
+//    resident on one XCD share A / W panels in that XCD's L2.
 #pragma once
 #include "gemm.h"
 
@@ -29,20 +31,26 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_base
 template <bool SPLIT, int BM, int BN>
 constexpr int gemm2_smem_bytes() { return 2 * (SPLIT ? 2 : 1) * (BM + BN) * 64; }
 
-// ABL (bench-only ablations, 0 in the product): 1 = no DMA inside the K loop, 2 = DMA + barriers only
-// (no LDS reads, no MFMA), 3 = MFMA on stale registers (no LDS reads).
+// LDS byte offset of 16-B chunk `chunk` of tile row `row` (SPLIT: 8 chunks/row = 4 hi + 4 lo)
+template <bool SPLIT>
+__device__ __forceinline__ int lds2_off(int row, int chunk) {
+    return SPLIT ? row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4) : row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
+}
+
+// ABL (bench-only ablations, 0 in the product): 1 = no DMA inside the K loop, 2 = DMA + barriers only,
+// 3 = MFMA on stale registers (no LDS reads).
 template <bool SPLIT, int AMODE, int EPI, int BM, int BN, int WAVES_M, int WAVES_N, int ABL = 0>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MT = WM / 32, NT = WN / 32;
-    constexpr int NPL = SPLIT ? 2 : 1;
-    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;
-    constexpr int STAGE = NPL * (A_PLANE + B_PLANE);
-    // 1-KiB DMA slots (16 rows) per plane: slot g = wave + NW*s, valid while g < rows/16 (BM = 192 gives
-    // waves 0-3 two A slots and waves 4-7 one; the guard is wave-uniform)
-    constexpr int NSA = BM / 16, NSB = BN / 16;
+    constexpr int RB = SPLIT ? 128 : 64;                     // LDS row bytes
+    constexpr int RPS = 1024 / RB;                           // rows per 1-KiB DMA slot (8 or 16)
+    constexpr int CPR = RB / 16;                             // 16-B chunks per row (8 or 4)
+    constexpr int A_TILE = BM * RB, B_TILE = BN * RB, STAGE = A_TILE + B_TILE;
+    constexpr int NSA = BM / RPS, NSB = BN / RPS;
     constexpr int SA = (NSA + NW - 1) / NW, SB = (NSB + NW - 1) / NW;
+    constexpr int A_ES = SPLIT ? 64 : 32;                    // global elements per activation row block
     static_assert(BM % 32 == 0 && BN % 32 == 0 && WM % 32 == 0 && WN % 32 == 0, "tile/wave mismatch");
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -68,21 +76,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
     }
     const int m0 = bm * BM, n0 = bn * BN;
 
-    // ---- per-lane DMA source bookkeeping
-    const int row_in = lane >> 2;
-    const int src_chunk = (lane & 3) ^ ((row_in >> 2) & 3);
-    const f16* a_src_hi[SA]; const f16* a_src_lo[SA];
-    const f16* b_src_hi[SB]; const f16* b_src_lo[SB];
-    int cv_img[SA], cv_y[SA], cv_x[SA]; bool cv_ok[SA];
+    // ---- per-lane DMA source bookkeeping.  Lane l of a slot fills LDS row (l / CPR), chunk (l % CPR);
+    // it must fetch source chunk (l % CPR) ^ swizzle(row).
+    const int row_in = lane / CPR, c_lds = lane % CPR;
+    size_t a_src[SA], b_src[SB];           // element offsets of this lane's 16 B within K tile 0
+    int cv_img[SA], cv_y[SA], cv_x[SA], cv_chunk[SA]; bool cv_ok[SA];
 #pragma unroll
     for (int s = 0; s < SA; ++s) {
-        const int row = 16 * (wave + NW * s) + row_in;
+        const int row = RPS * (wave + NW * s) + row_in;                      // tile row
+        const int sw = SPLIT ? (row >> 1) & 7 : (row >> 2) & 3;
+        const int chunk = c_lds ^ sw;                                         // source chunk of the row block
         const int gm = m0 + row;
         if (AMODE == A_DENSE) {
             const int gmc = gm < p.M ? gm : p.M - 1;
-            const size_t rs = (ABL & 4) ? 32 : p.lda;   // bench-only: K-tile-blocked source layout [K/32][M][32]
-            a_src_hi[s] = p.A_hi + (size_t)gmc * rs + src_chunk * 8;
-            a_src_lo[s] = SPLIT ? p.A_lo + (size_t)gmc * rs + src_chunk * 8 : nullptr;
+            a_src[s] = (size_t)gmc * A_ES + chunk * 8;
         } else {
             cv_ok[s] = gm < p.M;
             const int gmc = cv_ok[s] ? gm : 0;
@@ -91,47 +98,42 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
             const int rem = gmc - cv_img[s] * hw;
             cv_y[s] = (rem / p.Wo) * p.cstride - 1;
             cv_x[s] = (rem % p.Wo) * p.cstride - 1;
-            a_src_hi[s] = nullptr; a_src_lo[s] = nullptr;
+            cv_chunk[s] = chunk;
+            a_src[s] = 0;
         }
     }
 #pragma unroll
     for (int s = 0; s < SB; ++s) {
-        const int row = 16 * (wave + NW * s) + row_in;
+        const int row = RPS * (wave + NW * s) + row_in;
+        const int sw = SPLIT ? (row >> 1) & 7 : (row >> 2) & 3;
         const int gn = n0 + row;
         const int gnc = gn < p.N ? gn : p.N - 1;
-        const size_t rsb = (ABL & 4) ? 32 : p.K;
-        b_src_hi[s] = p.B_hi + (size_t)gnc * rsb + src_chunk * 8;
-        b_src_lo[s] = SPLIT ? p.B_lo + (size_t)gnc * rsb + src_chunk * 8 : nullptr;
+        b_src[s] = (size_t)gnc * 64 + (c_lds ^ sw) * 8;                      // weights are always [hi32|lo32]
     }
+    const size_t a_kstride = (size_t)p.a_rp * A_ES, b_kstride = (size_t)p.N * 64;
 
     auto issue_tile = [&](int kt, int stage) {
-        const int k0 = kt * GEMM_BK;
-        const size_t ka = (ABL & 4) ? (size_t)kt * p.M * 32 : (size_t)k0, kb = (ABL & 4) ? (size_t)kt * p.N * 32 : (size_t)k0;
         char* sA = smem + stage * STAGE;
-        char* sB = sA + NPL * A_PLANE;
-        int tap = 0, c0 = 0, ky = 0, kx = 0;
-        if (AMODE == A_CONV3) { tap = k0 / p.Cin; c0 = k0 - tap * p.Cin; ky = tap / 3; kx = tap - ky * 3; }
+        char* sB = sA + A_TILE;
+        int tap = 0, cb = 0, ky = 0, kx = 0;
+        if (AMODE == A_CONV3) { const int cblocks = p.Cin >> 5; tap = kt / cblocks; cb = kt - tap * cblocks; ky = tap / 3; kx = tap - ky * 3; }
 #pragma unroll
         for (int s = 0; s < SA; ++s) {
             if (NSA % NW != 0 && wave + NW * s >= NSA) continue;
             char* dst = sA + (wave + NW * s) * 1024;
             if (AMODE == A_DENSE) {
-                glds16(a_src_hi[s] + ka, dst);
-                if (SPLIT) glds16(a_src_lo[s] + ka, dst + A_PLANE);
+                glds16(p.A_hi + a_src[s] + kt * a_kstride, dst);
             } else {
                 const int yi = cv_y[s] + ky, xi = cv_x[s] + kx;
                 const bool ok = cv_ok[s] && yi >= 0 && yi < p.Hi && xi >= 0 && xi < p.Wi;
-                const size_t off = ((size_t)(cv_img[s] * p.Hi + yi) * p.Wi + xi) * p.Cin + c0 + src_chunk * 8;
-                glds16(ok ? p.A_hi + off : p.zero_page, dst);
-                if (SPLIT) glds16(ok ? p.A_lo + off : p.zero_page, dst + A_PLANE);
+                const size_t pix = (size_t)(cv_img[s] * p.Hi + yi) * p.Wi + xi;
+                glds16(ok ? p.A_hi + ((size_t)cb * p.a_rp + pix) * A_ES + cv_chunk[s] * 8 : p.zero_page, dst);
             }
         }
 #pragma unroll
         for (int s = 0; s < SB; ++s) {
             if (NSB % NW != 0 && wave + NW * s >= NSB) continue;
-            char* dst = sB + (wave + NW * s) * 1024;
-            glds16(b_src_hi[s] + kb, dst);
-            if (SPLIT) glds16(b_src_lo[s] + kb, dst + B_PLANE);
+            glds16(p.B_hi + b_src[s] + kt * b_kstride, sB + (wave + NW * s) * 1024);
         }
     };
 
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
         const int cur = kt & 1;
         if (kt + 1 < nkt && (ABL & 3) != 1) issue_tile(kt + 1, cur ^ 1);
         const char* sA = smem + cur * STAGE;
-        const char* sB = sA + NPL * A_PLANE;
+        const char* sB = sA + A_TILE;
         half8 a_hi[MT], a_lo[MT], b_hi[NT], b_lo[NT];
         if ((ABL & 3) == 3) {
 #pragma unroll
@@ -166,8 +168,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
 #pragma unroll
             for (int i = 0; i < MT && (ABL & 3) != 3; ++i) {
                 const int ra = wm * WM + i * 32 + l31;
-                a_hi[i] = *reinterpret_cast<const half8*>(sA + lds_off(ra, chunk));
-                if (SPLIT) a_lo[i] = *reinterpret_cast<const half8*>(sA + A_PLANE + lds_off(ra, chunk));
+                a_hi[i] = *reinterpret_cast<const half8*>(sA + lds2_off<SPLIT>(ra, chunk));
+                if (SPLIT) a_lo[i] = *reinterpret_cast<const half8*>(sA + lds2_off<SPLIT>(ra, 4 + chunk));
                 if (AMODE == A_CONV3) {
                     if (p.relu_in) {   // relu(hi + lo): the sign of hi decides
                         const short8 neg = a_hi[i] < (half8)(f16)0;
@@ -179,8 +181,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
 #pragma unroll
             for (int j = 0; j < NT && (ABL & 3) != 3; ++j) {
                 const int rb = wn * WN + j * 32 + l31;
-                b_hi[j] = *reinterpret_cast<const half8*>(sB + lds_off(rb, chunk));
-                if (SPLIT) b_lo[j] = *reinterpret_cast<const half8*>(sB + B_PLANE + lds_off(rb, chunk));
+                b_hi[j] = *reinterpret_cast<const half8*>(sB + lds2_off<SPLIT>(rb, chunk));
+                if (SPLIT) b_lo[j] = *reinterpret_cast<const half8*>(sB + lds2_off<SPLIT>(rb, 4 + chunk));
             }
             // product-major order: consecutive MFMAs hit different accumulators (MT*NT apart)
             if (SPLIT) {

@@ -4,7 +4,6 @@
 #include "../../include/sta_mi355.h"
 #include "gemm.h"
 #include "gemm2.h"
-#include "gemm3.h"
 #include "attention.h"
 #include "elementwise.h"
 
@@ -28,7 +27,14 @@ static int set_err(const char* fmt, ...) {
 #define REQUIRE(c, ...) do { if (!(c)) return set_err(__VA_ARGS__); } while (0)
 
 // ------------------------------------------------------------------------------------------ types
-struct Planes { f16* hi = nullptr; f16* lo = nullptr; };
+// fp16 planes.  Activations / weights use the K-tile-blocked layout [cols/32][rp rows][hi32|lo32]
+// (lo == hi + 32 in f16x3, lo == nullptr in f16); rp == 0 marks the row-major Q/K/V^T buffers.
+struct Planes { f16* hi = nullptr; f16* lo = nullptr; int64_t rp = 0; };
+static inline Planes slice_rows(const Planes& p, int64_t r0) {
+    Planes q = p; const int64_t es = p.lo ? 64 : 32;
+    q.hi = p.hi + r0 * es; if (p.lo) q.lo = q.hi + 32;
+    return q;
+}
 struct Lin { Planes w; float* bias = nullptr; int N = 0, K = 0; };
 struct LNp { float* g = nullptr; float* b = nullptr; };
 struct EncBlk { LNp n1, n2; Lin qkv, proj, fc1, fc2; };
@@ -44,6 +50,7 @@ struct Slot {
     float* dst32 = nullptr;          // SK_F32 / SK_B_CONVT destination (+offset applied)
     f16* dst_hi = nullptr; f16* dst_lo = nullptr;   // packed destination (+row offset applied)
     int reps = 1;                    // SK_B_CONVT: k*k
+    int64_t N = 0, K = 0, n_off = 0; // packed-weight geometry: rows of the whole Lin, contraction length, row offset
     bool loaded = false;
 };
 
@@ -94,8 +101,14 @@ struct Bump {
         return base + a;
     }
     void rewind(int64_t mark) { off = mark; }
-    Planes planes(int64_t elems, bool split) {
+    Planes planes(int64_t elems, bool split) {      // row-major pair of planes (Q / K / V^T buffers)
         Planes p; p.hi = (f16*)take(elems * 2); p.lo = split ? (f16*)take(elems * 2) : nullptr; return p;
+    }
+    Planes act(int64_t rows, int64_t cols, bool split) {   // blocked activation planes, cols % 32 == 0
+        Planes p; p.rp = rows;
+        p.hi = (f16*)take(rows * cols * (split ? 4 : 2) + 256);
+        p.lo = split ? p.hi + 32 : nullptr;
+        return p;
     }
 };
 
@@ -113,8 +126,8 @@ static int ensure_ws(sta_handle* h, int64_t bytes) {
 // ------------------------------------------------------------------------------------------ schema
 static int make_lin(sta_handle* h, Lin& L, int N, int K, bool bias = true) {
     L.N = N; L.K = K;
-    CHK(dalloc(h, (void**)&L.w.hi, (int64_t)N * K * 2));
-    CHK(dalloc(h, (void**)&L.w.lo, (int64_t)N * K * 2));
+    CHK(dalloc(h, (void**)&L.w.hi, (int64_t)N * K * 4 + 256));     // blocked [K/32][N][hi32|lo32]
+    L.w.lo = L.w.hi + 32; L.w.rp = N;
     if (bias) CHK(dalloc(h, (void**)&L.bias, (int64_t)N * 4));
     return 0;
 }
@@ -123,7 +136,7 @@ static int make_ln(sta_handle* h, LNp& n, int C) {
 }
 static void slot_w(sta_handle* h, const std::string& name, std::vector<int64_t> shape, SlotKind k, Lin& L, int row_off = 0) {
     Slot s; s.shape = std::move(shape); s.kind = k;
-    s.dst_hi = L.w.hi + (int64_t)row_off * L.K; s.dst_lo = L.w.lo + (int64_t)row_off * L.K;
+    s.dst_hi = L.w.hi; s.dst_lo = L.w.lo; s.N = L.N; s.K = L.K; s.n_off = row_off;
     h->slots[name] = s;
 }
 static void slot_f32(sta_handle* h, const std::string& name, std::vector<int64_t> shape, float* dst) {
@@ -347,7 +360,7 @@ extern "C" int sta_load_tensor(sta_handle* h, const char* name, const void* host
             } else {
                 int mode = s.kind == SK_W_ID ? 0 : (s.kind == SK_W_CONV ? 1 : 2);
                 int d0 = (int)s.shape[0], d1 = ndim > 1 ? (int)s.shape[1] : 1, d2 = ndim > 2 ? (int)s.shape[2] : 1, d3 = ndim > 3 ? (int)s.shape[3] : 1;
-                repack_weight_kernel<<<blocks, 256>>>(h->stage, s.dst_hi, s.dst_lo, n, mode, d0, d1, d2, d3);
+                repack_weight_kernel<<<blocks, 256>>>(h->stage, s.dst_hi, s.dst_lo, n, mode, d0, d1, d2, d3, s.N, s.K, s.n_off);
             }
             HIPCHK(hipGetLastError());
             HIPCHK(hipDeviceSynchronize());
@@ -379,22 +392,6 @@ static int launch_gemm2(const GemmParams& p, hipStream_t st) {
     }
     int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
     hipLaunchKernelGGL((gemm2_kernel<SPLIT, AMODE, EPI, BM, BN, WMS, WNS>), dim3((unsigned)(tm * tn)), dim3(WMS * WNS * 64), smem, st, p);
-    return 0;
-}
-
-template <int AMODE, int EPI>
-static int launch_gemm3(bool split, const GemmParams& p, hipStream_t st) {
-    static bool attr_done[2] = {false, false};
-    const int tm = (p.M + 255) / 256, tn = (p.N + 255) / 256;
-    if (split) {
-        constexpr int smem = gemm2_smem_bytes<true, 256, 256>();
-        if (!attr_done[1]) { HIPCHK(hipFuncSetAttribute((const void*)gemm3_kernel<true, AMODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr_done[1] = true; }
-        hipLaunchKernelGGL((gemm3_kernel<true, AMODE, EPI>), dim3((unsigned)(tm * tn)), dim3(256), smem, st, p);
-    } else {
-        constexpr int smem = gemm2_smem_bytes<false, 256, 256>();
-        if (!attr_done[0]) { HIPCHK(hipFuncSetAttribute((const void*)gemm3_kernel<false, AMODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr_done[0] = true; }
-        hipLaunchKernelGGL((gemm3_kernel<false, AMODE, EPI>), dim3((unsigned)(tm * tn)), dim3(256), smem, st, p);
-    }
     return 0;
 }
 
@@ -488,7 +485,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
 
 static GemmParams gp_dense(const Planes& A, int lda, const Lin& W, int M) {
     GemmParams p; memset(&p, 0, sizeof p);
-    p.A_hi = A.hi; p.A_lo = A.lo; p.lda = lda;
+    p.A_hi = A.hi; p.A_lo = A.lo; p.lda = lda; p.a_rp = A.rp;
     p.B_hi = W.w.hi; p.B_lo = W.w.lo; p.bias = W.bias;
     p.M = M; p.N = W.N; p.K = W.K;
     return p;
@@ -504,7 +501,8 @@ static int gemm_f32(sta_handle* h, const Planes& A, const Lin& W, int M, float* 
 }
 static int gemm_f16(sta_handle* h, const Planes& A, const Lin& W, int M, const Planes& out, int act, hipStream_t st) {
     GemmParams p = gp_dense(A, W.K, W, M);
-    p.C_hi = out.hi; p.C_lo = out.lo; p.ldc16 = W.N; p.act = act;
+    p.C_hi = out.hi; p.C_lo = out.lo; p.ldc16 = W.N; p.act = act; p.c_rp = out.rp;
+    REQUIRE(h->dry || (A.rp >= M && out.rp >= M), "internal: plane rows mismatch in gemm_f16");
     return launch_gemm<A_DENSE, EPI_F16>(h, p, st);
 }
 struct QKVOut { Planes q, k, vt; int npad; };
@@ -522,22 +520,23 @@ static int gemm_qkv(sta_handle* h, const Planes& A, const Lin& W, int M, int nq,
 static int gemm_convt(sta_handle* h, const Planes& A, const Lin& W, int nimg, int hh, int ww, int k, int cout,
                       const Planes& out, hipStream_t st) {
     GemmParams p = gp_dense(A, W.K, W, nimg * hh * ww);
-    p.C_hi = out.hi; p.C_lo = out.lo; p.ct_k = k; p.ct_cout = cout; p.ct_h = hh; p.ct_w = ww;
+    p.C_hi = out.hi; p.C_lo = out.lo; p.ct_k = k; p.ct_cout = cout; p.ct_h = hh; p.ct_w = ww; p.c_rp = out.rp;
     return launch_gemm<A_DENSE, EPI_CONVT>(h, p, st);
 }
 // 3x3 conv, pad 1, NHWC planes
 static int conv3(sta_handle* h, const Planes& in, int nimg, int Hi, int Wi, int Cin, const Lin& W, int stride,
                  bool relu_in, int act, const Planes& out, const Planes* r1, const Planes* r2, hipStream_t st) {
     GemmParams p; memset(&p, 0, sizeof p);
-    p.A_hi = in.hi; p.A_lo = in.lo;
+    p.A_hi = in.hi; p.A_lo = in.lo; p.a_rp = in.rp;
     p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.cstride = stride; p.relu_in = relu_in ? 1 : 0;
     p.Ho = (Hi + 2 - 3) / stride + 1; p.Wo = (Wi + 2 - 3) / stride + 1;
     p.B_hi = W.w.hi; p.B_lo = W.w.lo; p.bias = W.bias;
     p.M = nimg * p.Ho * p.Wo; p.N = W.N; p.K = W.K;
     REQUIRE(W.K == 9 * Cin, "conv weight K mismatch");
-    p.C_hi = out.hi; p.C_lo = out.lo; p.ldc16 = W.N; p.act = act;
-    if (r1) { p.R1_hi = r1->hi; p.R1_lo = r1->lo; }
-    if (r2) { p.R2_hi = r2->hi; p.R2_lo = r2->lo; }
+    p.C_hi = out.hi; p.C_lo = out.lo; p.ldc16 = W.N; p.act = act; p.c_rp = out.rp;
+    REQUIRE(h->dry || ((int64_t)nimg * Hi * Wi == in.rp && out.rp == p.M), "internal: conv plane rows mismatch");
+    if (r1) { p.R1_hi = r1->hi; p.R1_lo = r1->lo; REQUIRE(h->dry || r1->rp == out.rp, "internal: residual rows mismatch"); }
+    if (r2) { p.R2_hi = r2->hi; p.R2_lo = r2->lo; REQUIRE(h->dry || r2->rp == out.rp, "internal: residual rows mismatch"); }
     return launch_gemm<A_CONV3, EPI_F16>(h, p, st);
 }
 
@@ -580,8 +579,8 @@ static int run_rows_to_planes(sta_handle* h, const float* x, int64_t bstride, in
     if (h->dry) return 0;
     int64_t total4 = (int64_t)nb * rows * C / 4;
     int blocks = (int)((total4 + 255) / 256); if (blocks > 8192) blocks = 8192;
-    if (h->prec == STA_PREC_F16X3) hipLaunchKernelGGL(rows_to_planes_kernel<true>, dim3(blocks), dim3(256), 0, st, x, bstride, rows, C, total4, o.hi, o.lo, obstride);
-    else hipLaunchKernelGGL(rows_to_planes_kernel<false>, dim3(blocks), dim3(256), 0, st, x, bstride, rows, C, total4, o.hi, o.lo, obstride);
+    if (h->prec == STA_PREC_F16X3) hipLaunchKernelGGL(rows_to_planes_kernel<true>, dim3(blocks), dim3(256), 0, st, x, bstride, rows, C, total4, o.hi, o.lo, obstride, o.rp);
+    else hipLaunchKernelGGL(rows_to_planes_kernel<false>, dim3(blocks), dim3(256), 0, st, x, bstride, rows, C, total4, o.hi, o.lo, obstride, o.rp);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -625,10 +624,10 @@ static int encode_impl(sta_handle* h, Bump& ws, const float* const* imgs, int ns
     const bool split = h->prec == STA_PREC_F16X3;
     const int E = c.enc_embed_dim, Hh = c.enc_num_heads, hp = H / 16, wp = W / 16, N = hp * wp;
     const int n = nsets * B, M = n * N, npad = rup(N, 64);
-    Planes patches = ws.planes((int64_t)M * 768, split);
-    Planes lnp = ws.planes((int64_t)M * E, split);
-    Planes ao = ws.planes((int64_t)M * E, split);
-    Planes f1 = ws.planes((int64_t)M * E * c.mlp_ratio, split);
+    Planes patches = ws.act(M, 768, split);
+    Planes lnp = ws.act(M, E, split);
+    Planes ao = ws.act(M, E, split);
+    Planes f1 = ws.act(M, (int64_t)E * c.mlp_ratio, split);
     QKVOut qkv; qkv.npad = npad;
     int64_t hsz = (int64_t)n * Hh * npad * 64;
     qkv.q = ws.planes(hsz, split); qkv.k = ws.planes(hsz, split); qkv.vt = ws.planes(hsz, split);
@@ -637,11 +636,11 @@ static int encode_impl(sta_handle* h, Bump& ws, const float* const* imgs, int ns
     HIPCHK(hipMemsetAsync(qkv.vt.hi, 0, hsz * 2, st));
     if (split) HIPCHK(hipMemsetAsync(qkv.vt.lo, 0, hsz * 2, st));
     for (int sidx = 0; sidx < nsets; ++sidx) {
-        Planes dst = patches; dst.hi += (int64_t)sidx * B * N * 768; if (split) dst.lo += (int64_t)sidx * B * N * 768;
         int64_t total = (int64_t)B * N * 48;
         int blocks = (int)((total + 255) / 256);
-        if (split) hipLaunchKernelGGL(patch_gather_kernel<true>, dim3(blocks), dim3(256), 0, st, imgs[sidx], B, H, W, dst.hi, dst.lo);
-        else hipLaunchKernelGGL(patch_gather_kernel<false>, dim3(blocks), dim3(256), 0, st, imgs[sidx], B, H, W, dst.hi, dst.lo);
+        const int64_t row0 = (int64_t)sidx * B * N;
+        if (split) hipLaunchKernelGGL(patch_gather_kernel<true>, dim3(blocks), dim3(256), 0, st, imgs[sidx], B, H, W, patches.hi, patches.lo, row0, (int64_t)M);
+        else hipLaunchKernelGGL(patch_gather_kernel<false>, dim3(blocks), dim3(256), 0, st, imgs[sidx], B, H, W, patches.hi, patches.lo, row0, (int64_t)M);
         HIPCHK(hipGetLastError());
     }
     CHK(gemm_f32(h, patches, h->patch, M, feat, E, nullptr, st));
@@ -667,11 +666,11 @@ static int decode_impl(sta_handle* h, Bump& ws, const float* feat1, const float*
     const bool split = h->prec == STA_PREC_F16X3;
     const int E = c.enc_embed_dim, D = c.dec_embed_dim, Hh = c.dec_num_heads;
     const int N = hp * wp, Np = N + 1, S = 2 * B, M = S * Np, npad = rup(Np, 64);
-    Planes fp = ws.planes((int64_t)S * N * E, split);
-    Planes a1 = ws.planes((int64_t)M * D, split);
-    Planes ay = ws.planes((int64_t)M * D, split);
-    Planes ao = ws.planes((int64_t)M * D, split);
-    Planes f1 = ws.planes((int64_t)M * D * c.mlp_ratio, split);
+    Planes fp = ws.act((int64_t)S * N, E, split);
+    Planes a1 = ws.act(M, D, split);
+    Planes ay = ws.act(M, D, split);
+    Planes ao = ws.act(M, D, split);
+    Planes f1 = ws.act(M, (int64_t)D * c.mlp_ratio, split);
     QKVOut qkv; qkv.npad = npad;
     int64_t hsz = (int64_t)S * Hh * npad * 64;
     qkv.q = ws.planes(hsz, split); qkv.k = ws.planes(hsz, split); qkv.vt = ws.planes(hsz, split);
@@ -680,7 +679,7 @@ static int decode_impl(sta_handle* h, Bump& ws, const float* feat1, const float*
     HIPCHK(hipMemsetAsync(qkv.vt.hi, 0, hsz * 2, st));
     if (split) HIPCHK(hipMemsetAsync(qkv.vt.lo, 0, hsz * 2, st));
 
-    Planes fp2 = fp; fp2.hi += (int64_t)B * N * E; if (split) fp2.lo += (int64_t)B * N * E;
+    Planes fp2 = slice_rows(fp, (int64_t)B * N);
     CHK(run_rows_to_planes(h, feat1, (int64_t)N * E, B, N, E, fp, st));
     CHK(run_rows_to_planes(h, feat2, (int64_t)N * E, B, N, E, fp2, st));
     CHK(gemm_f32(h, fp, h->dec_embed, S * N, x, D, nullptr, st, N, Np, 1));
@@ -758,19 +757,19 @@ static int dpt_impl(sta_handle* h, Bump& ws, const float* enc, int64_t enc_bs,
     const bool split = h->prec == STA_PREC_F16X3;
     const int E = c.enc_embed_dim, D = c.dec_embed_dim, hp = H / 16, wp = W / 16, N = hp * wp;
     const int M = n * N;
-    Planes t0 = ws.planes((int64_t)M * E, split), t1 = ws.planes((int64_t)M * D, split);
-    Planes t2 = ws.planes((int64_t)M * D, split), t3 = ws.planes((int64_t)M * D, split);
+    Planes t0 = ws.act(M, E, split), t1 = ws.act(M, D, split);
+    Planes t2 = ws.act(M, D, split), t3 = ws.act(M, D, split);
     CHK(run_rows_to_planes(h, enc, enc_bs, n, N, E, t0, st));
     CHK(run_rows_to_planes(h, h1, h1_bs, n, N, D, t1, st));
     CHK(run_rows_to_planes(h, h2, h2_bs, n, N, D, t2, st));
     CHK(run_rows_to_planes(h, h3, h3_bs, n, N, D, t3, st));
     // act_postprocess (dpt_block.py:356-410)
-    Planes a0 = ws.planes((int64_t)M * 96, split), l0 = ws.planes((int64_t)M * 16 * 96, split);
-    Planes a1 = ws.planes((int64_t)M * 192, split), l1 = ws.planes((int64_t)M * 4 * 192, split);
-    Planes l2 = ws.planes((int64_t)M * 384, split);
-    Planes a3 = ws.planes((int64_t)M * 768, split);
+    Planes a0 = ws.act(M, 96, split), l0 = ws.act((int64_t)M * 16, 96, split);
+    Planes a1 = ws.act(M, 192, split), l1 = ws.act((int64_t)M * 4, 192, split);
+    Planes l2 = ws.act(M, 384, split);
+    Planes a3 = ws.act(M, 768, split);
     const int h3s = (hp - 1) / 2 + 1, w3s = (wp - 1) / 2 + 1;
-    Planes l3 = ws.planes((int64_t)n * h3s * w3s * 768, split);
+    Planes l3 = ws.act((int64_t)n * h3s * w3s, 768, split);
     REQUIRE(!ws.overflow, "internal: dpt workspace overflow (stage 1)");
     CHK(gemm_f16(h, t0, h->act0_0, M, a0, ACT_NONE, st));
     CHK(gemm_convt(h, a0, h->act0_1, n, hp, wp, 4, 96, l0, st));
@@ -784,7 +783,7 @@ static int dpt_impl(sta_handle* h, Bump& ws, const float* enc, int64_t enc_bs,
     const int Cs[4] = {96, 192, 384, 768};
     Planes lin[4] = {l0, l1, l2, l3}, r[4];
     for (int k = 0; k < 4; ++k) {
-        r[k] = ws.planes((int64_t)n * Hs[k] * Ws[k] * 256, split);
+        r[k] = ws.act((int64_t)n * Hs[k] * Ws[k], 256, split);
         REQUIRE(!ws.overflow, "internal: dpt workspace overflow (rn)");
         CHK(conv3(h, lin[k], n, Hs[k], Ws[k], Cs[k], h->rn[k], 1, false, ACT_NONE, r[k], nullptr, nullptr, st));
     }
@@ -795,31 +794,31 @@ static int dpt_impl(sta_handle* h, Bump& ws, const float* enc, int64_t enc_bs,
     for (int k = 3; k >= 0; --k) {
         const Refine& rf = h->ref[k];
         const int hh = Hs[k], ww = Ws[k];
-        const int64_t el = (int64_t)n * hh * ww * 256;
-        Planes tmp = ws.planes(el, split), cur = r[k];
+        const int64_t el = (int64_t)n * hh * ww;
+        Planes tmp = ws.act(el, 256, split), cur = r[k];
         if (k < 3) {
             REQUIRE(ph == hh && pw == ww, "internal: refinenet size mismatch %dx%d vs %dx%d", ph, pw, hh, ww);
-            Planes sum = ws.planes(el, split);
+            Planes sum = ws.act(el, 256, split);
             REQUIRE(!ws.overflow, "internal: dpt workspace overflow (fusion)");
             CHK(run_rcu(h, r[k], n, hh, ww, rf.u1, tmp, sum, &path, st));   // path + RCU1(layer)
             cur = sum;
         }
-        Planes y = ws.planes(el, split), z = ws.planes(el, split);
+        Planes y = ws.act(el, 256, split), z = ws.act(el, 256, split);
         REQUIRE(!ws.overflow, "internal: dpt workspace overflow (rcu2)");
         CHK(run_rcu(h, cur, n, hh, ww, rf.u2, tmp, y, nullptr, st));
         CHK(gemm_f16(h, y, rf.out, n * hh * ww, z, ACT_NONE, st));
         // upsample x2 (align_corners) ; refinenet4 output is cropped to the layers[2] size (dpt_head.py:58)
         int oh = 2 * hh, ow = 2 * ww;
         if (k == 3) { if (oh > Hs[2]) oh = Hs[2]; if (ow > Ws[2]) ow = Ws[2]; }
-        Planes up = ws.planes((int64_t)n * oh * ow * 256, split);
+        Planes up = ws.act((int64_t)n * oh * ow, 256, split);
         REQUIRE(!ws.overflow, "internal: dpt workspace overflow (up)");
         CHK(run_up2(h, z, n, hh, ww, 256, oh, ow, up, st));
         path = up; ph = oh; pw = ow;
     }
     // head: 3x3 256->128, up x2, 3x3 128->128 + ReLU, 1x1 128->4 + postprocess (dpt_block.py:316-324)
-    Planes h0 = ws.planes((int64_t)n * ph * pw * 128, split);
-    Planes h0u = ws.planes((int64_t)n * H * W * 128, split);
-    Planes h2o = ws.planes((int64_t)n * H * W * 128, split);
+    Planes h0 = ws.act((int64_t)n * ph * pw, 128, split);
+    Planes h0u = ws.act((int64_t)n * H * W, 128, split);
+    Planes h2o = ws.act((int64_t)n * H * W, 128, split);
     REQUIRE(!ws.overflow, "internal: dpt workspace overflow (head)");
     REQUIRE(2 * ph == H && 2 * pw == W, "internal: head size mismatch");
     CHK(conv3(h, path, n, ph, pw, 256, h->head0, 1, false, ACT_NONE, h0, nullptr, nullptr, st));
@@ -830,11 +829,10 @@ static int dpt_impl(sta_handle* h, Bump& ws, const float* enc, int64_t enc_bs,
         if (cnt <= 0) continue;
         float* pp = part == 0 ? ptsA : ptsB; float* cp = part == 0 ? confA : confB;
         int64_t npix = (int64_t)cnt * H * W;
-        const f16* ih = h2o.hi + (int64_t)i0 * H * W * 128;
-        const f16* il = split ? h2o.lo + (int64_t)i0 * H * W * 128 : nullptr;
+        const int64_t pix0 = (int64_t)i0 * H * W;
         int blocks = (int)((npix * 16 + 255) / 256); if (blocks > 16384) blocks = 16384;
-        if (split) hipLaunchKernelGGL(head_final_kernel<true>, dim3(blocks), dim3(256), 0, st, ih, il, npix, h->head4.w, h->head4.b, pp, cp);
-        else hipLaunchKernelGGL(head_final_kernel<false>, dim3(blocks), dim3(256), 0, st, ih, il, npix, h->head4.w, h->head4.b, pp, cp);
+        if (split) hipLaunchKernelGGL(head_final_kernel<true>, dim3(blocks), dim3(256), 0, st, h2o.hi, h2o.lo, pix0, h2o.rp, npix, h->head4.w, h->head4.b, pp, cp);
+        else hipLaunchKernelGGL(head_final_kernel<false>, dim3(blocks), dim3(256), 0, st, h2o.hi, h2o.lo, pix0, h2o.rp, npix, h->head4.w, h->head4.b, pp, cp);
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -1053,17 +1051,17 @@ extern "C" int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, int
     CHK(ensure_ws(h, bytes));
     h->dry = false;
     Bump ws{h->ws, h->ws_cap};
-    Planes A = ws.planes((int64_t)M * K, true);
-    Lin Wt; Wt.N = N; Wt.K = K; Wt.w = ws.planes((int64_t)N * K, true);
+    Planes A = ws.act(M, K, true);
+    Lin Wt; Wt.N = N; Wt.K = K; Wt.w = ws.act(N, K, true);
     Wt.bias = (float*)ws.take((int64_t)N * 4);
     float* C = (float*)ws.take((int64_t)M * N * 4);
     REQUIRE(!ws.overflow, "internal: bench workspace overflow");
-    hipLaunchKernelGGL(fill_rand_f16_kernel, dim3(2048), dim3(256), 0, st, A.hi, (int64_t)M * K, 1u, 1.0f);
-    hipLaunchKernelGGL(fill_rand_f16_kernel, dim3(2048), dim3(256), 0, st, A.lo, (int64_t)M * K, 2u, 4.8e-4f);
-    hipLaunchKernelGGL(fill_rand_f16_kernel, dim3(2048), dim3(256), 0, st, Wt.w.hi, (int64_t)N * K, 3u, 0.03f);
-    hipLaunchKernelGGL(fill_rand_f16_kernel, dim3(2048), dim3(256), 0, st, Wt.w.lo, (int64_t)N * K, 4u, 1.5e-5f);
+    // random operands (both hi and lo halves of every row block get full-range random bits: the data
+    // dependence of MFMA power is what matters for a throughput number)
+    hipLaunchKernelGGL(fill_rand_f16_kernel, dim3(2048), dim3(256), 0, st, A.hi, (int64_t)M * K * 2, 1u, 1.0f);
+    hipLaunchKernelGGL(fill_rand_f16_kernel, dim3(2048), dim3(256), 0, st, Wt.w.hi, (int64_t)N * K * 2, 3u, 0.03f);
     HIPCHK(hipMemsetAsync(Wt.bias, 0, (size_t)N * 4, st));
-    if (!split) { A.lo = nullptr; }
+    if (!split) { A.lo = nullptr; }   // f16 mode reads the same buffer as [K/32][M][32]
     GemmParams p = gp_dense(A, K, Wt, M);
     p.C32 = C; p.ldc = N; p.ldr = N; p.zero_page = h->zero_page;
     const int keep = h->gemm_variant;
@@ -1084,7 +1082,6 @@ extern "C" int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, int
         }
         if (tile == 2) return bench_launch2<256, 256, 2, 4, 0>(split, p, st);
         if (tile == 3) return bench_launch2<256, 128, 4, 2, 0>(split, p, st);
-        if (tile == 4) return launch_gemm3<A_DENSE, EPI_F32>(split, p, st);
         if (tile == 5) return bench_launch2<192, 256, 2, 4, 0>(split, p, st);
         if (tile == 6) return bench_launch2<192, 128, 2, 4, 0>(split, p, st);
         if (tile == 7) return bench_launch2<192, 128, 2, 2, 0>(split, p, st);

@@ -45,5 +45,13 @@ __device__ __forceinline__ float gelu_erf(float x) {
 __device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
 __device__ __forceinline__ uint2 ldg8(const void* p) { return *reinterpret_cast<const uint2*>(p); }
 
+// K-tile-blocked plane layout of every fp16 activation / weight tensor:  [cols/32][rows][hi32 | lo32]
+// (f16 mode: [cols/32][rows][32]).  Element (row, col): hi at blk_off, lo 32 elements further.
+// One K tile (32 columns) of consecutive rows is contiguous memory - the unit the GEMM DMA moves.
+template <bool SPLIT>
+__device__ __forceinline__ size_t blk_off(int64_t row, int col, int64_t rows) {
+    return ((size_t)(col >> 5) * rows + row) * (SPLIT ? 64 : 32) + (col & 31);
+}
+
 union H8 { uint4 u; half8 h; f16 e[8]; };
 union H4 { uint2 u; half4 h; f16 e[4]; };
