@@ -146,13 +146,25 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nkt = p.K / GEMM_BK;
+    // RING3 (bench experiment, ABL bit 3): three LDS stages, the DMA runs two K tiles ahead and stays in
+    // flight across the barrier (counted vmcnt, raw s_barrier) instead of draining every K tile.
+    constexpr bool RING3 = (ABL & 8) != 0;
+    constexpr int GPW = SA + SB;                   // DMA instructions per wave per K tile (exact when slots divide evenly)
     issue_tile(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (RING3) {
+        if (nkt > 1) issue_tile(1, 1);
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
 
     for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt && (ABL & 3) != 1) issue_tile(kt + 1, cur ^ 1);
+        const int cur = RING3 ? kt % 3 : (kt & 1);
+        if (RING3) {
+            if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kt + 2 < nkt) issue_tile(kt + 2, (kt + 2) % 3);
+        } else if (kt + 1 < nkt && (ABL & 3) != 1) issue_tile(kt + 1, cur ^ 1);
         const char* sA = smem + cur * STAGE;
         const char* sB = sA + A_TILE;
         half8 a_hi[MT], a_lo[MT], b_hi[NT], b_lo[NT];
@@ -203,8 +215,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (!RING3) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     }
 
 #pragma unroll

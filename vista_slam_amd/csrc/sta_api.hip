@@ -1030,7 +1030,7 @@ __global__ void fill_rand_f16_kernel(f16* p, int64_t n, uint32_t seed, float sca
 template <int BM, int BN, int WMS, int WNS, int ABL>
 static int bench_launch2(bool split, const GemmParams& p, hipStream_t st) {
     if (split) {
-        constexpr int smem = gemm2_smem_bytes<true, BM, BN>();
+        constexpr int smem = gemm2_smem_bytes<true, BM, BN>() * ((ABL & 8) ? 3 : 2) / 2;
         HIPCHK(hipFuncSetAttribute((const void*)gemm2_kernel<true, A_DENSE, EPI_F32, BM, BN, WMS, WNS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         hipLaunchKernelGGL((gemm2_kernel<true, A_DENSE, EPI_F32, BM, BN, WMS, WNS, ABL>), dim3((unsigned)(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN))), dim3(WMS * WNS * 64), smem, st, p);
     } else {
@@ -1082,6 +1082,7 @@ extern "C" int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, int
         }
         if (tile == 2) return bench_launch2<256, 256, 2, 4, 0>(split, p, st);
         if (tile == 3) return bench_launch2<256, 128, 4, 2, 0>(split, p, st);
+        if (tile == 10) return bench_launch2<256, 128, 4, 2, 8>(split, p, st);   // 3-stage ring experiment
         if (tile == 5) return bench_launch2<192, 256, 2, 4, 0>(split, p, st);
         if (tile == 6) return bench_launch2<192, 128, 2, 4, 0>(split, p, st);
         if (tile == 7) return bench_launch2<192, 128, 2, 2, 0>(split, p, st);
