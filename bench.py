@@ -28,7 +28,7 @@ H, W_, PAIRS_PER_GPU = 384, 512, 8
 PEAK_F16_MFMA_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 
 
-def pmc_traffic():
+def pmc_traffic(kernel_prefix):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r01_pmc_traffic.json <- tools/pmc_summary.py; FETCH_SIZE doubled per the gfx950
     correction).  bench.py cannot collect PMCs itself; null when no summary is committed."""
@@ -37,7 +37,7 @@ def pmc_traffic():
         with open(path) as f:
             d = json.load(f)
         for k, v in d.items():
-            if k.startswith("gemm2_kernel<true, 0, 0, 192, 256") or k.startswith("gemm2_kernel<true, 0, 0, 256, 256"):
+            if k.startswith(kernel_prefix):
                 return int(v["avg_hbm_bytes_per_launch"])
     except Exception:   # noqa: BLE001
         pass
@@ -175,7 +175,7 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": names[fam] + " (attn.proj / mlp.fc2 fp32-epilogue GEMMs)",
                     "achieved": round(ach, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
+                    "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": pmc_traffic(names[fam][:-3]),
                     "algorithmic_bytes_per_launch": int(by / n), "gflop_per_launch": round(fl / n / 1e9, 2),
                     "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
                     "mfma_products_per_flop": 3 if args.precision == "f16x3" else 1,
