@@ -13,7 +13,11 @@ LIB = os.path.join(HERE, "libsta_oracle.so")
 
 
 def build(force=False, verbose=True):
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= os.path.getmtime(SRC):
+    import hashlib
+    with open(SRC, "rb") as f:
+        digest = hashlib.sha256(f.read()).hexdigest()
+    hfile = LIB + ".srchash"
+    if not force and os.path.exists(LIB) and os.path.exists(hfile) and open(hfile).read().strip() == digest:
         return LIB
     gcc = shutil.which("gcc")
     if gcc is None:
@@ -25,6 +29,8 @@ def build(force=False, verbose=True):
         if verbose:
             print("[oracle build]", " ".join(cmd), flush=True)
         if subprocess.run(cmd).returncode == 0:
+            with open(hfile, "w") as f:
+                f.write(digest)
             return LIB
     raise RuntimeError("oracle build failed")
 

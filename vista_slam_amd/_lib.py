@@ -80,6 +80,10 @@ def load():
         raise StaError(
             f"{LIB_PATH} not found: the MI355X STA frontend has no CPU fallback. "
             "Build it with `python -m vista_slam_amd.build` (needs hipcc) or `__graft_entry__.build()`.")
+    # torch must be imported BEFORE the library: the ROCm wheel bundles its own libamdhip64 and the
+    # process must end up with exactly one HIP runtime (loading /opt/rocm's first makes the second
+    # initialisation fail with "no ROCm-capable device is detected").
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export it

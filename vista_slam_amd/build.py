@@ -11,7 +11,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libsta_mi355.so")
 SOURCES = ["sta_api.hip"]
-DEPS = ["sta_api.hip", "sta_debug.inc", "gemm.h", "attention.h", "elementwise.h", "sta_common.h",
+DEPS = ["sta_api.hip", "sta_debug.inc", "gemm.h", "gemm2.h", "attention.h", "elementwise.h", "sta_common.h",
         os.path.join("..", "..", "include", "sta_mi355.h"), os.path.join("..", "..", "include", "sta_mi355_debug.h")]
 
 
@@ -22,11 +22,25 @@ def hipcc_path():
     return None
 
 
+HASH_FILE = LIB + ".srchash"
+
+
+def source_hash():
+    """Content hash of every source the library is built from (mtimes do not survive the gpurun
+    snapshot copy, so staleness is decided by content)."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in DEPS:
+        with open(os.path.join(CSRC, d), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def is_stale():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(HASH_FILE):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    with open(HASH_FILE) as f:
+        return f.read().strip() != source_hash()
 
 
 def build_lib(force=False, verbose=True):
@@ -40,6 +54,8 @@ def build_lib(force=False, verbose=True):
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)
+    with open(HASH_FILE, "w") as f:
+        f.write(source_hash())
     return LIB
 
 
