@@ -124,6 +124,15 @@ int sta_forward_pair(sta_handle* h, const float* img_a, const float* img_b, int 
                      float* const pts[2], float* const conf[2],
                      float* const pose[2], float* const pose_conf[2], void* stream);
 
+/* Camera-format input (the step before the path): uint8 HWC images [B,H,W,3], 16-byte
+ * aligned.  The reference normalisation ImgNorm = ToTensor + Normalize(0.5,0.5)
+ * (vista_slam/utils/image.py:13; datasets/slam_images_only.py:19,30) is fused into the patch gather;
+ * results are bit-identical to sta_encode / sta_forward_pair on the normalised fp32 NCHW tensor. */
+int sta_encode_u8hwc(sta_handle* h, const uint8_t* img_dev, int B, int H, int W, float* feat_dev, void* stream);
+int sta_forward_pair_u8hwc(sta_handle* h, const uint8_t* img_a, const uint8_t* img_b, int B, int H, int W,
+                           float* const pts[2], float* const conf[2],
+                           float* const pose[2], float* const pose_conf[2], void* stream);
+
 /* In-place 2-D RoPE on fp32 tokens (B,N,Hh,D) with element strides (stride of D must be 1,
  * stride of Hh must be D; same contract as kernels.cu:91-94); pos int64 [B,N,2] contiguous. */
 int sta_rope2d_inplace(float* tokens_dev, int64_t stride_b, int64_t stride_n,

@@ -79,3 +79,110 @@ def test_error_paths(G):
         fresh.load_state_dict({"dec_norm.weight": np.zeros(128, np.float32)})
     with pytest.raises(_lib.StaError, match="not finalized"):
         fresh._encode_image(torch.zeros(1, 3, 32, 32, device="cuda:0"), None, normalize=False)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Full-size (BASELINE configs[1]: 512x384, batch 8) properties that need no oracle run: the oracle
+# would take minutes per pair at this size, so parity at scale is checked through size-independent
+# invariants of the algorithm plus the sub-sampled reference golden of pair 0.
+@pytest.fixture(scope="module")
+def full_b8(G):
+    import torch
+    from vista_slam_amd import weights as W
+    G.drop_models()
+    m = G.model("full", 1.0, "f16x3")
+    G.set_variant(m, 0)
+    imgs = W.synth_images(16, 384, 512, seed=43, tag=0)
+    a, b = torch.from_numpy(imgs[:8]).cuda(), torch.from_numpy(imgs[8:]).cuda()
+    main, supp = m.forward_pair(a, b)
+    torch.cuda.synchronize()
+    return m, a, b, main, supp
+
+
+def test_full_size_batch8_outputs_are_well_formed(full_b8):
+    import torch
+    m, a, b, main, supp = full_b8
+    for o in (main, supp):
+        assert o["pts3d_pred"].shape == (8, 384, 512, 3) and o["conf"].shape == (8, 384, 512)
+        assert bool(torch.isfinite(o["pts3d_pred"]).all()) and bool(torch.isfinite(o["conf"]).all())
+        assert float(o["conf"].min()) >= 1.0                                  # conf = 1 + exp(x)
+        R = o["relative_pose"][:, :3, :3].double()
+        eye = torch.eye(3, dtype=torch.float64, device=R.device)
+        assert float((R @ R.transpose(1, 2) - eye).abs().max()) < 1e-5        # pp.mat2SE3(atol=1e-3) needs this (slam.py:166)
+        assert float((torch.linalg.det(R) - 1).abs().max()) < 1e-5
+        assert bool((o["relative_pose"][:, 3] == torch.tensor([0., 0., 0., 1.], device=R.device)).all())
+        assert float(o["relative_pose_conf"].min()) > 0 and float(o["relative_pose_conf"].max()) < 1
+
+
+def test_full_size_batch_rows_are_independent(full_b8):
+    """Pairs are independent units: pair i of the batch-8 run == the same pair run alone (what the
+    multi-GPU sharding relies on).  Not bit-exact only because tile scheduling changes summation order."""
+    import torch
+    from helpers import rel_l2
+    m, a, b, main, supp = full_b8
+    for i in (0, 5):
+        m1, s1 = m.forward_pair(a[i:i + 1], b[i:i + 1])
+        torch.cuda.synchronize()
+        assert rel_l2(m1["pts3d_pred"].cpu().numpy(), main["pts3d_pred"][i:i + 1].cpu().numpy()) < 2e-5
+        assert rel_l2(s1["conf"].cpu().numpy(), supp["conf"][i:i + 1].cpu().numpy()) < 2e-5
+        assert rel_l2(m1["relative_pose"].cpu().numpy(), main["relative_pose"][i:i + 1].cpu().numpy()) < 2e-5
+
+
+def test_full_size_view_swap_symmetry(full_b8):
+    """The decoder weights are shared between the two sides (sta_model.py:231-235), so swapping the views
+    swaps the outputs: forward(b, a).main == forward(a, b).support."""
+    import torch
+    from helpers import rel_l2
+    m, a, b, main, supp = full_b8
+    main2, supp2 = m.forward_pair(b[:2], a[:2])
+    torch.cuda.synchronize()
+    assert rel_l2(main2["pts3d_pred"].cpu().numpy(), supp["pts3d_pred"][:2].cpu().numpy()) < 2e-5
+    assert rel_l2(supp2["relative_pose"].cpu().numpy(), main["relative_pose"][:2].cpu().numpy()) < 2e-5
+    assert rel_l2(supp2["conf"].cpu().numpy(), main["conf"][:2].cpu().numpy()) < 2e-5
+
+
+def test_full_size_pair0_matches_reference_golden(full_b8):
+    """Pair 0 of the batch-8 bench workload uses the same procedural images as the committed 384x512
+    golden (tag 0, images 0 and 8 differ from the B=1 golden's images 0 and 1) - so compare the B=1 golden
+    inputs explicitly through the same batched code path instead."""
+    import torch
+    from helpers import load_golden, rel_l2
+    from vista_slam_amd import weights as W
+    m = full_b8[0]
+    g, meta = load_golden("full_384x512_b1")
+    imgs = W.synth_images(2, 384, 512, seed=43, tag=0)
+    pad = W.synth_images(14, 384, 512, seed=43, tag=3)
+    a = torch.from_numpy(np_concat(imgs[:1], pad[:7])).cuda()
+    b = torch.from_numpy(np_concat(imgs[1:], pad[7:])).cuda()
+    main, supp = m.forward_pair(a, b)
+    torch.cuda.synchronize()
+    sub = int(meta["sub"])
+    assert rel_l2(main["pts3d_pred"][:1].cpu().numpy()[:, ::sub, ::sub], g["main_pts3d"]) < TOL
+    assert rel_l2(supp["conf"][:1].cpu().numpy()[:, ::sub, ::sub], g["supp_conf"]) < TOL
+    assert rel_l2(main["relative_pose"][:1].cpu().numpy(), g["main_pose"]) < TOL
+    assert rel_l2(supp["relative_pose"][:1].cpu().numpy(), g["supp_pose"]) < TOL
+
+
+def np_concat(x, y):
+    import numpy as np
+    return np.ascontiguousarray(np.concatenate([x, y], 0))
+
+
+def test_u8_hwc_input_is_bit_identical_to_normalised_fp32(G):
+    """f3 (input step): uint8 HWC frames with the reference ImgNorm fused into the patch gather give
+    exactly the encoder features / outputs of the fp32 NCHW path."""
+    import torch
+    from vista_slam_amd import weights as W
+    m = G.model("tiny", 1.0, "f16x3")
+    G.set_variant(m, 0)
+    f32 = torch.from_numpy(W.synth_images(4, 48, 64, seed=43, tag=5)).cuda()
+    u8 = torch.from_numpy(W.synth_images_u8(4, 48, 64, seed=43, tag=5)).cuda()
+    fa, _ = m._encode_image(f32, None, normalize=False)
+    fb, _ = m.encode_u8hwc(u8)
+    torch.cuda.synchronize()
+    assert torch.equal(fa, fb)
+    m1, s1 = m.forward_pair(f32[:2], f32[2:])
+    m2, s2 = m.forward_pair_u8hwc(u8[:2], u8[2:])
+    torch.cuda.synchronize()
+    for k in ("pts3d_pred", "conf", "relative_pose", "relative_pose_conf"):
+        assert torch.equal(m1[k], m2[k]) and torch.equal(s1[k], s2[k])

@@ -166,6 +166,42 @@ __global__ void patch_gather_kernel(const float* img, int n, int H, int W, f16* 
     }
 }
 
+// Same gather straight from camera-format input: uint8 HWC [n,H,W,3] (the step before the
+// path).  One thread = one (token, ky) row = 16 pixels x 3 interleaved channels = 48 CONTIGUOUS bytes
+// (3 x 16-B loads); the ImgNorm of the reference, ToTensor + Normalize(0.5, 0.5)
+// (vista_slam/utils/image.py:13, datasets/slam_images_only.py:19,30): (u/255 - 0.5)/0.5 in fp32 with the
+// same operation order, is fused here, so the result is bit-identical to feeding the normalised
+// fp32 NCHW image.
+template <bool SPLIT>
+__global__ void patch_gather_u8hwc_kernel(const uint8_t* img, int n, int H, int W, f16* o_hi, f16* o_lo, int64_t row0, int64_t orows) {
+    const int hp = H / 16, wp = W / 16;
+    const int64_t total = (int64_t)n * hp * wp * 16;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += step) {
+        const int ky = (int)(i % 16); const int64_t tok = i / 16;
+        const int px = (int)(tok % wp); const int64_t t2 = tok / wp; const int py = (int)(t2 % hp); const int b = (int)(t2 / hp);
+        const uint8_t* src = img + (((int64_t)b * H + py * 16 + ky) * W + px * 16) * 3;   // 48 B, 16-B aligned (W % 16 == 0)
+        union { uint4 v[3]; uint8_t e[48]; } raw;
+        raw.v[0] = ldg16(src); raw.v[1] = ldg16(src + 16); raw.v[2] = ldg16(src + 32);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            H8 h0, h1, l0, l1;
+#pragma unroll
+            for (int kx = 0; kx < 16; ++kx) {
+                const float a = (float)raw.e[kx * 3 + c] / 255.0f;
+                const float v = (a - 0.5f) / 0.5f;
+                f16 hh, ll;
+                if (SPLIT) split_f16(v, hh, ll); else { hh = to_f16_sat(v); ll = (f16)0; }
+                if (kx < 8) { h0.e[kx] = hh; l0.e[kx] = ll; } else { h1.e[kx - 8] = hh; l1.e[kx - 8] = ll; }
+            }
+            const size_t o = blk_off<SPLIT>(row0 + tok, (c * 16 + ky) * 16, orows);
+            *reinterpret_cast<uint4*>(o_hi + o) = h0.u; *reinterpret_cast<uint4*>(o_hi + o + 8) = h1.u;
+            if (SPLIT) { *reinterpret_cast<uint4*>(o_hi + o + 32) = l0.u; *reinterpret_cast<uint4*>(o_hi + o + 40) = l1.u; }
+        }
+    }
+}
+
 // x[s, 0, :] = token  (pose token prepend, sta_model.py:206-213)
 __global__ void fill_pose_token_kernel(float* x, int S, int ntok, int D, const float* tok) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

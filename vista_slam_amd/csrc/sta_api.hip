@@ -618,7 +618,7 @@ static inline int rup(int x, int m) { return (x + m - 1) / m * m; }
 
 // ------------------------------------------------------------------------------------------ encoder
 // imgs: nsets pointers of B images each -> feat [nsets*B, N, E] (fp32, caller memory = residual stream)
-static int encode_impl(sta_handle* h, Bump& ws, const float* const* imgs, int nsets, int B, int H, int W,
+static int encode_impl(sta_handle* h, Bump& ws, const void* const* imgs, bool u8hwc, int nsets, int B, int H, int W,
                        float* feat, hipStream_t st) {
     const sta_config& c = h->cfg;
     const bool split = h->prec == STA_PREC_F16X3;
@@ -639,8 +639,12 @@ static int encode_impl(sta_handle* h, Bump& ws, const float* const* imgs, int ns
         int64_t total = (int64_t)B * N * 48;
         int blocks = (int)((total + 255) / 256);
         const int64_t row0 = (int64_t)sidx * B * N;
-        if (split) hipLaunchKernelGGL(patch_gather_kernel<true>, dim3(blocks), dim3(256), 0, st, imgs[sidx], B, H, W, patches.hi, patches.lo, row0, (int64_t)M);
-        else hipLaunchKernelGGL(patch_gather_kernel<false>, dim3(blocks), dim3(256), 0, st, imgs[sidx], B, H, W, patches.hi, patches.lo, row0, (int64_t)M);
+        if (u8hwc) {
+            const int b16 = (int)(((int64_t)B * N * 16 + 255) / 256);
+            if (split) hipLaunchKernelGGL(patch_gather_u8hwc_kernel<true>, dim3(b16), dim3(256), 0, st, (const uint8_t*)imgs[sidx], B, H, W, patches.hi, patches.lo, row0, (int64_t)M);
+            else hipLaunchKernelGGL(patch_gather_u8hwc_kernel<false>, dim3(b16), dim3(256), 0, st, (const uint8_t*)imgs[sidx], B, H, W, patches.hi, patches.lo, row0, (int64_t)M);
+        } else if (split) hipLaunchKernelGGL(patch_gather_kernel<true>, dim3(blocks), dim3(256), 0, st, (const float*)imgs[sidx], B, H, W, patches.hi, patches.lo, row0, (int64_t)M);
+        else hipLaunchKernelGGL(patch_gather_kernel<false>, dim3(blocks), dim3(256), 0, st, (const float*)imgs[sidx], B, H, W, patches.hi, patches.lo, row0, (int64_t)M);
         HIPCHK(hipGetLastError());
     }
     CHK(gemm_f32(h, patches, h->patch, M, feat, E, nullptr, st));
@@ -869,8 +873,19 @@ extern "C" int sta_encode(sta_handle* h, const float* img_dev, int B, int H, int
     hipStream_t st = (hipStream_t)stream;
     const int hp = H / 16, wp = W / 16;
     CHK(ensure_rope(h, hp > wp ? hp : wp));
-    const float* imgs[1] = {img_dev};
-    return plan_and_run(h, [&](Bump& ws) { return encode_impl(h, ws, imgs, 1, B, H, W, feat_dev, st); });
+    const void* imgs[1] = {img_dev};
+    return plan_and_run(h, [&](Bump& ws) { return encode_impl(h, ws, imgs, false, 1, B, H, W, feat_dev, st); });
+}
+
+extern "C" int sta_encode_u8hwc(sta_handle* h, const uint8_t* img_dev, int B, int H, int W, float* feat_dev, void* stream) {
+    CHK(check_ready(h, B, H, W));
+    REQUIRE(img_dev && feat_dev, "null device pointer");
+    REQUIRE(((uintptr_t)img_dev & 15) == 0, "u8 HWC image must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int hp = H / 16, wp = W / 16;
+    CHK(ensure_rope(h, hp > wp ? hp : wp));
+    const void* imgs[1] = {img_dev};
+    return plan_and_run(h, [&](Bump& ws) { return encode_impl(h, ws, imgs, true, 1, B, H, W, feat_dev, st); });
 }
 
 extern "C" int sta_decode(sta_handle* h, const float* feat1, const float* feat2, int B, int hp, int wp,
@@ -909,9 +924,9 @@ extern "C" int sta_head_pts(sta_handle* h, const float* enc_feat, int64_t enc_bs
     });
 }
 
-extern "C" int sta_forward_pair(sta_handle* h, const float* img_a, const float* img_b, int B, int H, int W,
-                                float* const pts[2], float* const conf[2], float* const pose[2], float* const pose_conf[2],
-                                void* stream) {
+static int forward_pair_any(sta_handle* h, const void* img_a, const void* img_b, bool u8hwc, int B, int H, int W,
+                            float* const pts[2], float* const conf[2], float* const pose[2], float* const pose_conf[2],
+                            void* stream) {
     CHK(check_ready(h, B, H, W));
     REQUIRE(img_a && img_b && pts && conf && pose && pose_conf, "null argument");
     hipStream_t st = (hipStream_t)stream;
@@ -929,8 +944,8 @@ extern "C" int sta_forward_pair(sta_handle* h, const float* img_a, const float* 
         float* hk[3] = {(float*)ws.take(x_b), (float*)ws.take(x_b), (float*)ws.take(x_b)};
         const int64_t mark = ws.off;
         if (rec) HIPCHK(hipEventRecord(h->ev[0], st));
-        const float* imgs[2] = {img_a, img_b};
-        CHK(encode_impl(h, ws, imgs, 2, B, H, W, feat, st));
+        const void* imgs[2] = {img_a, img_b};
+        CHK(encode_impl(h, ws, imgs, u8hwc, 2, B, H, W, feat, st));
         if (rec) HIPCHK(hipEventRecord(h->ev[1], st));
         ws.rewind(mark);
         std::vector<float*> w1(dd + 1, nullptr), w2(dd + 1, nullptr);
@@ -948,6 +963,18 @@ extern "C" int sta_forward_pair(sta_handle* h, const float* img_a, const float* 
         if (rec) HIPCHK(hipEventRecord(h->ev[4], st));
         return 0;
     });
+}
+
+extern "C" int sta_forward_pair(sta_handle* h, const float* img_a, const float* img_b, int B, int H, int W,
+                                float* const pts[2], float* const conf[2], float* const pose[2], float* const pose_conf[2],
+                                void* stream) {
+    return forward_pair_any(h, img_a, img_b, false, B, H, W, pts, conf, pose, pose_conf, stream);
+}
+extern "C" int sta_forward_pair_u8hwc(sta_handle* h, const uint8_t* img_a, const uint8_t* img_b, int B, int H, int W,
+                                      float* const pts[2], float* const conf[2], float* const pose[2], float* const pose_conf[2],
+                                      void* stream) {
+    REQUIRE((((uintptr_t)img_a | (uintptr_t)img_b) & 15) == 0, "u8 HWC images must be 16-byte aligned");
+    return forward_pair_any(h, img_a, img_b, true, B, H, W, pts, conf, pose, pose_conf, stream);
 }
 
 extern "C" int sta_kernel_timing(sta_handle* h, int enable) {

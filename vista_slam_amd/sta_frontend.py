@@ -254,6 +254,40 @@ class STAFrontend:
                                              arrs[0], arrs[1], arrs[2], arrs[3], _stream_ptr()))
         return outs[0], outs[1]
 
+    def encode_u8hwc(self, image_u8: torch.Tensor):
+        """Extension: encode uint8 HWC camera frames [B,H,W,3] directly; the reference
+        ImgNorm (x/255-0.5)/0.5 is fused into the patch gather (bit-identical to `_encode_image` on the
+        normalised NCHW tensor)."""
+        assert image_u8.dtype == torch.uint8 and image_u8.dim() == 4 and image_u8.shape[-1] == 3
+        img = image_u8.to(self.device).contiguous()
+        B, H, W_, _ = img.shape
+        self._check_hw(H, W_, self.patch_size)
+        hp, wp = H // 16, W_ // 16
+        feat = torch.empty(B, hp * wp, self.cfg.enc_embed_dim, device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.sta_encode_u8hwc(self._h, img.data_ptr(), B, H, W_, feat.data_ptr(), _stream_ptr()))
+        return feat, self._positions(B, hp, wp)
+
+    def forward_pair_u8hwc(self, img_a: torch.Tensor, img_b: torch.Tensor):
+        """`forward_pair` on uint8 HWC frames [B,H,W,3]."""
+        assert img_a.dtype == torch.uint8 and img_b.dtype == torch.uint8 and img_a.shape == img_b.shape
+        a, b = img_a.to(self.device).contiguous(), img_b.to(self.device).contiguous()
+        B, H, W_, Cc = a.shape
+        assert Cc == 3
+        self._check_hw(H, W_)
+        outs = []
+        arrs = [(C.c_void_p * 2)() for _ in range(4)]
+        for k in range(2):
+            o = {"pts3d_pred": torch.empty(B, H, W_, 3, device=self.device, dtype=torch.float32),
+                 "conf": torch.empty(B, H, W_, device=self.device, dtype=torch.float32),
+                 "relative_pose": torch.empty(B, 4, 4, device=self.device, dtype=torch.float32),
+                 "relative_pose_conf": torch.empty(B, device=self.device, dtype=torch.float32)}
+            outs.append(o)
+            for arr, key in zip(arrs, ("pts3d_pred", "conf", "relative_pose", "relative_pose_conf")):
+                arr[k] = o[key].data_ptr()
+        _lib.check(self.lib.sta_forward_pair_u8hwc(self._h, a.data_ptr(), b.data_ptr(), B, H, W_,
+                                                   arrs[0], arrs[1], arrs[2], arrs[3], _stream_ptr()))
+        return outs[0], outs[1]
+
     def forward(self, views: dict, loop_num: int = 0):
         main_view = views["main_view"]
         support = list(views["neighbor_views"]) + list(views["loop_views"])   # eval: all loop views (sta_model.py:252-255)

@@ -237,6 +237,14 @@ def synth_images(n: int, H: int, W: int, seed: int = 43, tag: int = 0) -> np.nda
     return img.reshape(n, 3, H, W).astype(np.float32)
 
 
+def synth_images_u8(n: int, H: int, W: int, seed: int = 43, tag: int = 0) -> np.ndarray:
+    """The uint8 HWC frames [n,H,W,3] whose ImgNorm is exactly `synth_images(n, H, W, seed, tag)`."""
+    cnt = n * 3 * H * W
+    u = hash_uniform(_name_seed(seed, f"image/{tag}"), cnt)
+    u8 = np.floor((u + np.float32(1.0)) * np.float32(128.0)).clip(0, 255).astype(np.uint8)
+    return np.ascontiguousarray(u8.reshape(n, 3, H, W).transpose(0, 2, 3, 1))
+
+
 def smooth_images(n: int, H: int, W: int, seed: int = 43, tag: int = 0) -> np.ndarray:
     """Low-frequency synthetic images (sums of a few sinusoids) - a second, structured input
     distribution for parity tests (white noise excites every patch identically)."""
