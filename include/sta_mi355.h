@@ -133,6 +133,18 @@ int sta_forward_pair_u8hwc(sta_handle* h, const uint8_t* img_a, const uint8_t* i
                            float* const pts[2], float* const conf[2],
                            float* const pose[2], float* const pose_conf[2], void* stream);
 
+/* reductions that consume the path's output for every accepted pair, one fused pass.
+ * sta_estimate_intrinsics <- estimate_intrinsic_from_pts3d(pts3d, confidence, shared_intrinsic)
+ * (vista_slam/utils/slam_utils.py:8-79; slam.py:184) and, in the same read, depths = pts[...,2]
+ * (slam.py:185) and conf.mean() per image (pose_graph.py:37).  K_out is [3,3] (shared) or [B,3,3];
+ * depth_out [B,H,W] and conf_mean_out [B] may be NULL.
+ * sta_estimate_scale <- estimate_scale_with_depth_and_confidence(Di, Dj, ci, cj) (slam_utils.py:168-190),
+ * s_out is one device float. */
+int sta_estimate_intrinsics(sta_handle* h, const float* pts, const float* conf, int B, int H, int W, int shared,
+                            float* K_out, float* depth_out, float* conf_mean_out, void* stream);
+int sta_estimate_scale(sta_handle* h, const float* Di, const float* Dj, const float* ci, const float* cj, int64_t n,
+                       float* s_out, void* stream);
+
 /* In-place 2-D RoPE on fp32 tokens (B,N,Hh,D) with element strides (stride of D must be 1,
  * stride of Hh must be D; same contract as kernels.cu:91-94); pos int64 [B,N,2] contiguous. */
 int sta_rope2d_inplace(float* tokens_dev, int64_t stride_b, int64_t stride_n,

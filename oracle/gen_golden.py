@@ -171,6 +171,41 @@ def gen_ops():
     print("[golden] ops done", flush=True)
 
 
+def gen_post():
+    """Post-STA reductions from the reference's own functions.  slam_utils imports colorama
+    (terminal colours only, absent here) at module level, so a do-nothing stub is injected first - the
+    functions exercised (slam_utils.py:8-79,168-190) do not touch it."""
+    import types
+    if "colorama" not in sys.modules:
+        col = types.ModuleType("colorama")
+        class _Any:                      # any attribute (Fore.CYAN, Style.RESET_ALL, ...) -> ""
+            def __getattr__(self, _name):
+                return ""
+        col.Fore = _Any(); col.Style = _Any()
+        sys.modules["colorama"] = col
+    sys.path.insert(0, "/root/reference")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_slam_utils", "/root/reference/vista_slam/utils/slam_utils.py")
+    su = importlib.util.module_from_spec(spec); spec.loader.exec_module(su)
+    g = torch.Generator().manual_seed(77)
+    B, H, W_ = 2, 28, 36
+    yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W_).float(), indexing="ij")
+    z = 1.5 + 0.5 * torch.rand(B, H, W_, generator=g)
+    f = torch.tensor([31.0, 27.5]).view(B, 1, 1)
+    pts = torch.stack([(xx - W_ / 2) / f * z, (yy - H / 2) / f * z, z], -1) + 0.01 * torch.randn(B, H, W_, 3, generator=g)
+    pts[0, 3, 4] = 0.0                     # Z == 0 (and X == Y == 0): nan -> 0 path
+    pts[1, 5, 6, 2] = 0.0                  # Z == 0, X != 0: inf -> 0 path
+    conf = 1.0 + torch.rand(B, H, W_, generator=g) * 4
+    conf[0, 0, 0] = 0.0                    # clamp(min=1e-6)
+    res = {"pts": pts.numpy(), "conf": conf.numpy(),
+           "K_shared": su.estimate_intrinsic_from_pts3d(pts, conf, shared_intrinsic=True).numpy(),
+           "K_per": su.estimate_intrinsic_from_pts3d(pts, conf, shared_intrinsic=False).numpy(),
+           "scale": su.estimate_scale_with_depth_and_confidence(pts[0, ..., 2], pts[1, ..., 2], conf[0], conf[1]).numpy(),
+           "conf_mean": conf.mean(dim=(1, 2)).numpy()}
+    np.savez_compressed(os.path.join(OUT, "post.npz"), **res)
+    print("[golden] post done", res["K_shared"].tolist(), float(res["scale"]), flush=True)
+
+
 CASES = {
     "sharpfull": [dict(name="full_224_b1_sharp", cfg=W.FULL, H=224, W_=224, B=1, sub=8, qk_gain=3.0)],
     "tiny": [
@@ -193,11 +228,13 @@ CASES = {
 }
 
 if __name__ == "__main__":
-    sel = sys.argv[1:] or ["ops", "tiny", "full224", "full512"]
+    sel = sys.argv[1:] or ["ops", "post", "tiny", "full224", "full512"]
     torch.set_num_threads(os.cpu_count())
     for s in sel:
         if s == "ops":
             gen_ops()
+        elif s == "post":
+            gen_post()
         else:
             for c in CASES[s]:
                 run_case(**c)

@@ -275,3 +275,35 @@ def forward_pair(cfg, sd, img_a, img_b):
         pose, pconf = head_pose(cfg, sd, dec[-1][:, 0, :])
         res[key] = {"pts3d": pts, "conf": conf, "pose": pose, "pose_conf": pconf}
     return res
+
+
+# ------------------------------------------------------------------ post-STA reductions
+def estimate_intrinsic_from_pts3d(pts3d, confidence, shared_intrinsic=False):
+    """vista_slam/utils/slam_utils.py:8-79, restated in numpy float32 (same formula, same clamps)."""
+    pts3d = np.asarray(pts3d, np.float32); confidence = np.asarray(confidence, np.float32)
+    B, H, W_, _ = pts3d.shape
+    cx, cy = np.float32(W_ / 2.0), np.float32(H / 2.0)
+    v, u = np.meshgrid(np.arange(H), np.arange(W_), indexing="ij")
+    u = (u.astype(np.float32) - cx).reshape(1, -1)
+    v = (v.astype(np.float32) - cy).reshape(1, -1)
+    X, Y, Z = (pts3d[..., k].reshape(B, -1) for k in range(3))
+    w = np.maximum(confidence.reshape(B, -1), np.float32(1e-6))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        xz = np.nan_to_num(X / Z, nan=0.0, posinf=0.0, neginf=0.0).astype(np.float32)
+        yz = np.nan_to_num(Y / Z, nan=0.0, posinf=0.0, neginf=0.0).astype(np.float32)
+    if shared_intrinsic:
+        fx = (w * xz * u).sum(dtype=np.float64) / (w * xz ** 2).sum(dtype=np.float64)
+        fy = (w * yz * v).sum(dtype=np.float64) / (w * yz ** 2).sum(dtype=np.float64)
+        return np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float32)
+    fx = (w * xz * u).sum(axis=1, dtype=np.float64) / (w * xz ** 2).sum(axis=1, dtype=np.float64)
+    fy = (w * yz * v).sum(axis=1, dtype=np.float64) / (w * yz ** 2).sum(axis=1, dtype=np.float64)
+    K = np.zeros((B, 3, 3), np.float32)
+    K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2], K[:, 2, 2] = fx, fy, cx, cy, 1.0
+    return K
+
+
+def estimate_scale_with_depth_and_confidence(Di, Dj, ci, cj):
+    """vista_slam/utils/slam_utils.py:168-190."""
+    Di, Dj, ci, cj = (np.asarray(t, np.float32).reshape(-1) for t in (Di, Dj, ci, cj))
+    w = np.maximum(ci * cj, np.float32(1e-6))
+    return np.float32((w * Di * Dj).sum(dtype=np.float64) / (w * Di * Di).sum(dtype=np.float64))

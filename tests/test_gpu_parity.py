@@ -186,3 +186,22 @@ def test_u8_hwc_input_is_bit_identical_to_normalised_fp32(G):
     torch.cuda.synchronize()
     for k in ("pts3d_pred", "conf", "relative_pose", "relative_pose_conf"):
         assert torch.equal(m1[k], m2[k]) and torch.equal(s1[k], s2[k])
+
+
+def test_post_sta_reductions_f1(G):
+    """f1: fused intrinsics / depth / mean-confidence pass and the scale estimate vs reference goldens."""
+    import torch
+    from helpers import load_golden, max_rel
+    from vista_slam_amd import post
+    m = G.model("tiny", 1.0, "f16x3")
+    g = load_golden("post")[0]
+    pts, conf = torch.from_numpy(g["pts"]).cuda(), torch.from_numpy(g["conf"]).cuda()
+    K, depth, cmean = post.pair_reductions(m, pts, conf, shared_intrinsic=True)
+    Kp = post.estimate_intrinsic_from_pts3d(m, pts, conf, shared_intrinsic=False)
+    s = post.estimate_scale_with_depth_and_confidence(m, pts[0, ..., 2], pts[1, ..., 2], conf[0], conf[1])
+    torch.cuda.synchronize()
+    assert max_rel(K.cpu().numpy(), g["K_shared"]) < 1e-5
+    assert max_rel(Kp.cpu().numpy(), g["K_per"]) < 1e-5
+    assert torch.equal(depth, pts[..., 2])
+    assert max_rel(cmean.cpu().numpy(), g["conf_mean"]) < 1e-6
+    assert abs(float(s) - float(g["scale"])) < 1e-5 * abs(float(g["scale"]))

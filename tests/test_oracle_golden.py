@@ -78,3 +78,13 @@ def test_forward_vs_reference_golden(case):
     assert not bad, bad
     if "tap_dpt_path1_0" in g:        # intermediate taps (tiny_32x32_b1): decoder input
         assert rel_l2(r["dec1"][0], g["dec1_in"]) < TOL
+
+
+def test_post_sta_reductions_vs_reference_golden():
+    """oracle restatement of estimate_intrinsic_from_pts3d / estimate_scale... vs vectors
+    produced by the reference's own functions (incl. Z == 0 and conf == 0 pixels)."""
+    g = load_golden("post")[0]
+    assert max_rel(O.estimate_intrinsic_from_pts3d(g["pts"], g["conf"], True), g["K_shared"]) < 2e-6
+    assert max_rel(O.estimate_intrinsic_from_pts3d(g["pts"], g["conf"], False), g["K_per"]) < 2e-6
+    s = O.estimate_scale_with_depth_and_confidence(g["pts"][0, ..., 2], g["pts"][1, ..., 2], g["conf"][0], g["conf"][1])
+    assert abs(float(s) - float(g["scale"])) < 2e-6 * abs(float(g["scale"]))

@@ -43,6 +43,8 @@ SIGNATURES = {
     "sta_encode_u8hwc": (_i, [_vp, _fp, _i, _i, _i, _fp, _vp]),
     "sta_forward_pair_u8hwc": (_i, [_vp, _fp, _fp, _i, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
                                     C.POINTER(_vp), _vp]),
+    "sta_estimate_intrinsics": (_i, [_vp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _vp]),
+    "sta_estimate_scale": (_i, [_vp, _fp, _fp, _fp, _fp, _i64, _fp, _vp]),
     "sta_rope2d_inplace": (_i, [_fp, _i64, _i64, _vp, _i, _i, _i, _i, _f, _f, _vp]),
     "sta_flops_per_pair": (C.c_double, [_vp, _i, _i]),
     "sta_workspace_bytes": (_i64, [_vp]),

@@ -397,6 +397,93 @@ __global__ __launch_bounds__(256) void pose_final_kernel(const PoseParams p, con
 }
 
 // ---------------------------------------------------------------------------------------------
+// the reductions that consume the path's output every accepted pair, fused into one pass.
+//  * estimate_intrinsic_from_pts3d (vista_slam/utils/slam_utils.py:8-79): confidence-weighted least
+//    squares focal  fx = sum(w*xz*u)/sum(w*xz^2), fy likewise, u = col - W/2, v = row - H/2,
+//    w = clamp(conf, 1e-6), xz = nan_to_num(X/Z, 0), yz = nan_to_num(Y/Z, 0); shared or per-image K.
+//  * depths = pts[...,2] (slam.py:185) and conf.mean() per image (pose_graph.py:37).
+// HBM-bound (16 B/pixel in, 4 B out).  Partial sums are fp64 per block (deterministic two-stage
+// reduction: block partials -> finalise kernel), which is at least as accurate as torch's fp32 sums.
+__global__ __launch_bounds__(256) void intrinsics_partial_kernel(const float* pts, const float* conf, int B, int H, int W,
+                                                                 float* depth, double* partial /*[B][nblk][5]*/, int nblk) {
+    const int b = blockIdx.y;
+    const int64_t hw = (int64_t)H * W;
+    const float cx = W / 2.0f, cy = H / 2.0f;
+    double s[5] = {0, 0, 0, 0, 0};   // fx_num, fx_den, fy_num, fy_den, conf_sum
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (int64_t)gridDim.x * blockDim.x) {
+        const float* p3 = pts + ((int64_t)b * hw + i) * 3;
+        const float X = p3[0], Y = p3[1], Z = p3[2];
+        const float c = conf[(int64_t)b * hw + i];
+        if (depth) depth[(int64_t)b * hw + i] = Z;
+        const float w = fmaxf(c, 1e-6f);
+        float xz = X / Z, yz = Y / Z;
+        if (!isfinite(xz)) xz = 0.f;
+        if (!isfinite(yz)) yz = 0.f;
+        const float u = (float)(i % W) - cx, v = (float)(i / W) - cy;
+        s[0] += (double)(w * xz * u); s[1] += (double)(w * xz * xz);
+        s[2] += (double)(w * yz * v); s[3] += (double)(w * yz * yz);
+        s[4] += (double)c;
+    }
+    __shared__ double red[4][5];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        double v = s[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) partial[((int64_t)b * nblk + blockIdx.x) * 5 + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void intrinsics_final_kernel(const double* partial, int B, int nblk, int H, int W, int shared,
+                                        float* K /*[3,3] or [B,3,3]*/, float* conf_mean /*[B] or null*/) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double tot[5] = {0, 0, 0, 0, 0};
+    for (int b = 0; b < B; ++b) {
+        double s[5] = {0, 0, 0, 0, 0};
+        for (int j = 0; j < nblk; ++j) for (int k = 0; k < 5; ++k) s[k] += partial[((int64_t)b * nblk + j) * 5 + k];
+        if (conf_mean) conf_mean[b] = (float)(s[4] / ((double)H * W));
+        for (int k = 0; k < 5; ++k) tot[k] += s[k];
+        if (!shared) {
+            float* Kb = K + b * 9;
+            Kb[0] = (float)(s[0] / s[1]); Kb[1] = 0.f; Kb[2] = W / 2.0f;
+            Kb[3] = 0.f; Kb[4] = (float)(s[2] / s[3]); Kb[5] = H / 2.0f;
+            Kb[6] = 0.f; Kb[7] = 0.f; Kb[8] = 1.f;
+        }
+    }
+    if (shared) {
+        K[0] = (float)(tot[0] / tot[1]); K[1] = 0.f; K[2] = W / 2.0f;
+        K[3] = 0.f; K[4] = (float)(tot[2] / tot[3]); K[5] = H / 2.0f;
+        K[6] = 0.f; K[7] = 0.f; K[8] = 1.f;
+    }
+}
+
+// estimate_scale_with_depth_and_confidence (slam_utils.py:168-190): s = sum(w Di Dj) / sum(w Di Di),
+// w = clamp(ci*cj, 1e-6).  Single block (n ~ 5e4), fp64 partials.
+__global__ __launch_bounds__(1024) void scale_estimate_kernel(const float* Di, const float* Dj, const float* ci, const float* cj,
+                                                               int64_t n, float* s_out) {
+    double num = 0, den = 0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float w = fmaxf(ci[i] * cj[i], 1e-6f);
+        num += (double)(w * Di[i] * Dj[i]); den += (double)(w * Di[i] * Di[i]);
+    }
+    __shared__ double rn[16], rd[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { num += __shfl_xor(num, o); den += __shfl_xor(den, o); }
+    if (lane == 0) { rn[wave] = num; rd[wave] = den; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0, b = 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { a += rn[k]; b += rd[k]; }
+        *s_out = (float)(a / b);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // curope-compatible in-place 2-D RoPE on fp32 tokens (B,N,Hh,D) (kernels.cu:17-82): one thread per
 // (token, head, pair); accurate sinf/cosf/powf (the reference CUDA build uses fast-math variants).
 __global__ void rope2d_inplace_kernel(float* tok, int64_t sb, int64_t sn, const int64_t* pos,

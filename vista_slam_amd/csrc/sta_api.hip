@@ -977,6 +977,33 @@ extern "C" int sta_forward_pair_u8hwc(sta_handle* h, const uint8_t* img_a, const
     return forward_pair_any(h, img_a, img_b, true, B, H, W, pts, conf, pose, pose_conf, stream);
 }
 
+extern "C" int sta_estimate_intrinsics(sta_handle* h, const float* pts, const float* conf, int B, int H, int W, int shared,
+                                       float* K_out, float* depth_out, float* conf_mean_out, void* stream) {
+    REQUIRE(h && pts && conf && K_out && B > 0 && H > 0 && W > 0, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t hw = (int64_t)H * W;
+    int nblk = (int)((hw + 256 * 8 - 1) / (256 * 8)); if (nblk > 256) nblk = 256; if (nblk < 1) nblk = 1;
+    return plan_and_run(h, [&](Bump& ws) -> int {
+        double* partial = (double*)ws.take((int64_t)B * nblk * 5 * 8);
+        if (h->dry) return 0;
+        REQUIRE(!ws.overflow, "internal: workspace overflow");
+        hipLaunchKernelGGL(intrinsics_partial_kernel, dim3(nblk, B), dim3(256), 0, st, pts, conf, B, H, W, depth_out, partial, nblk);
+        hipLaunchKernelGGL(intrinsics_final_kernel, dim3(1), dim3(64), 0, st, partial, B, nblk, H, W, shared, K_out, conf_mean_out);
+        HIPCHK(hipGetLastError());
+        return 0;
+    });
+}
+
+extern "C" int sta_estimate_scale(sta_handle* h, const float* Di, const float* Dj, const float* ci, const float* cj, int64_t n,
+                                  float* s_out, void* stream) {
+    REQUIRE(h && Di && Dj && ci && cj && s_out && n > 0, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(scale_estimate_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, Di, Dj, ci, cj, n, s_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int sta_kernel_timing(sta_handle* h, int enable) {
     REQUIRE(h, "null handle");
     h->ktime = enable != 0; h->kn = 0;
