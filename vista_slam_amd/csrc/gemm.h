@@ -36,6 +36,8 @@ struct GemmParams {
     // ---- EPI_F32
     float* C32; int ldc; const float* resid; int ldr;
     int rows_in, rows_out, row_off;                      // out_row = (m/rows_in)*rows_out + row_off + m%rows_in
+    int ksplit;                                          // >1: split-K, every slice atomically adds into C32 (which already
+                                                         //     holds the residual); bias is added by slice 0 only
     // ---- EPI_F16
     f16* C_hi; f16* C_lo; int ldc16; int act;            // blocked output planes with c_rp rows (ldc16 unused)
     int64_t c_rp;
@@ -155,11 +157,12 @@ __device__ __forceinline__ void epilogue_qkv_tile(const GemmParams& p, const flo
 // The tile column origin is a multiple of 32 and (for EPI_QKV) segment/head boundaries are multiples
 // of 64, so segment, head and the RoPE half (y for d<32, x for d>=32) are wave-uniform.
 template <bool SPLIT, int EPI>
-__device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx16& acc, int row0, int col, int lane) {
+__device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx16& acc, int row0, int col, int lane,
+                                              bool first_slice = true) {
     if (EPI == EPI_QKV) { epilogue_qkv_tile<SPLIT>(p, acc, row0, col, lane); return; }
     const int lhi = lane >> 5;
     const bool col_ok = col < p.N;
-    const float bv = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
+    const float bv = (p.bias != nullptr && col_ok && first_slice) ? p.bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
@@ -169,8 +172,12 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
             if (ok) {
                 int orow = row;
                 if (p.rows_in > 0) orow = (row / p.rows_in) * p.rows_out + p.row_off + row % p.rows_in;
-                if (p.resid) v += p.resid[(size_t)orow * p.ldr + col];
-                p.C32[(size_t)orow * p.ldc + col] = v;
+                if (p.ksplit > 1) {
+                    unsafeAtomicAdd(p.C32 + (size_t)orow * p.ldc + col, v);       // hardware global_atomic_add_f32
+                } else {
+                    if (p.resid) v += p.resid[(size_t)orow * p.ldr + col];
+                    p.C32[(size_t)orow * p.ldc + col] = v;
+                }
             }
         } else if (EPI == EPI_F16) {
             if (ok) {

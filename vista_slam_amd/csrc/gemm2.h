@@ -29,7 +29,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_base
 }
 
 template <bool SPLIT, int BM, int BN>
-constexpr int gemm2_smem_bytes() { return 2 * (SPLIT ? 2 : 1) * (BM + BN) * 64; }
+constexpr int gemm2_smem_bytes(int nstg = 2) { return nstg * (SPLIT ? 2 : 1) * (BM + BN) * 64; }
 
 // LDS byte offset of 16-B chunk `chunk` of tile row `row` (SPLIT: 8 chunks/row = 4 hi + 4 lo)
 template <bool SPLIT>
@@ -39,7 +39,11 @@ __device__ __forceinline__ int lds2_off(int row, int chunk) {
 
 // ABL (bench-only ablations, 0 in the product): 1 = no DMA inside the K loop, 2 = DMA + barriers only,
 // 3 = MFMA on stale registers (no LDS reads).
-template <bool SPLIT, int AMODE, int EPI, int BM, int BN, int WAVES_M, int WAVES_N, int ABL = 0>
+// NSTG: LDS stages.  2 = issue tile k+1, compute k, drain, barrier.  >2 = ring: the DMA runs NSTG-1 K tiles
+// ahead and stays in flight across the barrier (counted vmcnt + raw s_barrier in one asm statement) -
+// no gain on the big throughput shapes (DMA-throughput bound) but it is what makes the small-M /
+// split-K family (SLAM-scale GEMMs, a handful of K tiles per block) latency-tolerant.
+template <bool SPLIT, int AMODE, int EPI, int BM, int BN, int WAVES_M, int WAVES_N, int ABL = 0, int NSTG = 2>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WAVES_M * WAVES_N;
@@ -58,14 +62,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int l31 = lane & 31, lhi = lane >> 5;
 
-    // ---- block id -> tile (XCD-aware, band-major)
+    // ---- block id -> (tile, K slice) (XCD-aware, band-major; the slices of one tile are consecutive ids)
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    const int nwg = tiles_m * tiles_n;
+    const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+    const int nwg = tiles_m * tiles_n * ksplit;
     int t;
     {
         const int bid = blockIdx.x, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
     }
+    const int kslice = t % ksplit;
+    t /= ksplit;
     int bm, bn;
     {
         const int band = t / (4 * tiles_n);
@@ -145,26 +152,36 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nkt = p.K / GEMM_BK;
-    // RING3 (bench experiment, ABL bit 3): three LDS stages, the DMA runs two K tiles ahead and stays in
-    // flight across the barrier (counted vmcnt, raw s_barrier) instead of draining every K tile.
-    constexpr bool RING3 = (ABL & 8) != 0;
-    constexpr int GPW = SA + SB;                   // DMA instructions per wave per K tile (exact when slots divide evenly)
-    issue_tile(0, 0);
-    if (RING3) {
-        if (nkt > 1) issue_tile(1, 1);
+    // K tiles of this block's slice
+    const int nkt_all = p.K / GEMM_BK;
+    const int kt0 = (int)((int64_t)kslice * nkt_all / ksplit);
+    const int nkt = (int)((int64_t)(kslice + 1) * nkt_all / ksplit) - kt0;
+    constexpr bool RING = NSTG > 2;
+    constexpr int GPW = SA + SB;                   // DMA instructions per wave per K tile
+    static_assert(!RING || (NSA % NW == 0 && NSB % NW == 0), "ring needs the same DMA count in every wave");
+    static_assert(NSTG >= 2 && NSTG <= 5, "2..5 stages");
+    if (RING) {
+#pragma unroll
+        for (int s0 = 0; s0 < NSTG - 1; ++s0)
+            if (s0 < nkt) issue_tile(kt0 + s0, s0);
     } else {
+        issue_tile(kt0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
     for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = RING3 ? kt % 3 : (kt & 1);
-        if (RING3) {
-            if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            if (kt + 2 < nkt) issue_tile(kt + 2, (kt + 2) % 3);
-        } else if (kt + 1 < nkt && (ABL & 3) != 1) issue_tile(kt + 1, cur ^ 1);
+        const int cur = RING ? kt % NSTG : (kt & 1);
+        if (RING) {
+            // tile kt has landed once at most `rem` younger tiles of this wave are outstanding
+            int rem = nkt - 1 - kt; if (rem > NSTG - 2) rem = NSTG - 2;
+            if (rem == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GPW) : "memory");
+            else if (rem == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * GPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * GPW) : "memory");
+            // the barrier also says every wave finished tile kt-1: its stage is free for tile kt+NSTG-1
+            if (kt + NSTG - 1 < nkt) issue_tile(kt0 + kt + NSTG - 1, (kt + NSTG - 1) % NSTG);
+        } else if (kt + 1 < nkt && (ABL & 3) != 1) issue_tile(kt0 + kt + 1, cur ^ 1);
         const char* sA = smem + cur * STAGE;
         const char* sB = sA + A_TILE;
         half8 a_hi[MT], a_lo[MT], b_hi[NT], b_lo[NT];
@@ -215,7 +232,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
         }
-        if (!RING3) {
+        if (!RING) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
@@ -225,5 +242,5 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
-            epilogue_tile<SPLIT, EPI>(p, acc[i][j], m0 + wm * WM + i * 32, n0 + wn * WN + j * 32 + l31, lane);
+            epilogue_tile<SPLIT, EPI>(p, acc[i][j], m0 + wm * WM + i * 32, n0 + wn * WN + j * 32 + l31, lane, kslice == 0);
 }

@@ -381,17 +381,18 @@ extern "C" int sta_finalize_weights(sta_handle* h) {
 }
 
 // ------------------------------------------------------------------------------------------ launch helpers
-template <bool SPLIT, int AMODE, int EPI, int BM, int BN, int WMS, int WNS>
+template <bool SPLIT, int AMODE, int EPI, int BM, int BN, int WMS, int WNS, int NSTG = 2>
 static int launch_gemm2(const GemmParams& p, hipStream_t st) {
     static bool attr_done = false;
-    constexpr int smem = gemm2_smem_bytes<SPLIT, BM, BN>();
+    constexpr int smem = gemm2_smem_bytes<SPLIT, BM, BN>(NSTG);
     if (!attr_done) {
-        HIPCHK(hipFuncSetAttribute((const void*)gemm2_kernel<SPLIT, AMODE, EPI, BM, BN, WMS, WNS>,
+        HIPCHK(hipFuncSetAttribute((const void*)gemm2_kernel<SPLIT, AMODE, EPI, BM, BN, WMS, WNS, 0, NSTG>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_done = true;
     }
     int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm2_kernel<SPLIT, AMODE, EPI, BM, BN, WMS, WNS>), dim3((unsigned)(tm * tn)), dim3(WMS * WNS * 64), smem, st, p);
+    const int ks = p.ksplit > 1 ? p.ksplit : 1;
+    hipLaunchKernelGGL((gemm2_kernel<SPLIT, AMODE, EPI, BM, BN, WMS, WNS, 0, NSTG>), dim3((unsigned)(tm * tn * ks)), dim3(WMS * WNS * 64), smem, st, p);
     return 0;
 }
 
@@ -448,10 +449,25 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
             if (cost < best) { best = cost; variant = c.variant; }
         }
     }
+    // Small-M (SLAM-scale: 224x224, batch 1 -> M = 196..394 rows): 128x64 tiles, 3-stage DMA ring, and for
+    // the in-place residual GEMMs (proj / fc2: out += A W^T + b) split-K with fp32 atomics so that ~256
+    // workgroups stream the weights once instead of 16-64 workgroups looping over all of K.
+    const int64_t tiles_192 = (int64_t)((p.M + 191) / 192) * ((p.N + 127) / 128);
+    if ((p.M <= 640 || tiles_192 < 128) && p.N % 64 == 0) {
+        variant = 6;
+        const int tiles = ((p.M + 127) / 128) * (p.N / 64);
+        if (AMODE == A_DENSE && EPI == EPI_F32 && p.resid == p.C32 && p.rows_in == 0 && tiles < 256) {
+            int ks = (256 + tiles - 1) / tiles;
+            const int max_ks = p.K / 128;                 // keep >= 4 K tiles per slice
+            if (ks > max_ks) ks = max_ks;
+            if (ks > 1) p.ksplit = ks;
+        }
+    }
     if (h->gemm_variant == 2 && p.N % 128 == 0) variant = (p.N % 256 == 0 && EPI != EPI_QKV) ? 2 : 3;
     if (h->gemm_variant == 3 && p.N % 128 == 0) variant = (p.N % 256 == 0 && EPI != EPI_QKV) ? 4 : 5;
     if (h->gemm_variant == 4 && p.N % 128 == 0) variant = 5;
     if (h->gemm_variant == 1) variant = 1;
+    if (variant != 6) p.ksplit = 1;
     if (variant == 2) {
         if (split) CHK((launch_gemm2<true, AMODE, EPI, 256, 256, 2, 4>(p, st)));
         else CHK((launch_gemm2<false, AMODE, EPI, 256, 256, 2, 4>(p, st)));
@@ -464,6 +480,9 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
     } else if (variant == 5) {
         if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4>(p, st)));
         else CHK((launch_gemm2<false, AMODE, EPI, 192, 128, 2, 4>(p, st)));
+    } else if (variant == 6) {
+        if (split) CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 2, 2, 3>(p, st)));
+        else CHK((launch_gemm2<false, AMODE, EPI, 128, 64, 2, 2, 3>(p, st)));
     } else {
         int tm = (p.M + GEMM_BM - 1) / GEMM_BM, tn = (p.N + GEMM_BN - 1) / GEMM_BN;
         dim3 grid((unsigned)(tm * tn));
@@ -1084,7 +1103,7 @@ __global__ void fill_rand_f16_kernel(f16* p, int64_t n, uint32_t seed, float sca
 template <int BM, int BN, int WMS, int WNS, int ABL>
 static int bench_launch2(bool split, const GemmParams& p, hipStream_t st) {
     if (split) {
-        constexpr int smem = gemm2_smem_bytes<true, BM, BN>() * ((ABL & 8) ? 3 : 2) / 2;
+        constexpr int smem = gemm2_smem_bytes<true, BM, BN>();
         HIPCHK(hipFuncSetAttribute((const void*)gemm2_kernel<true, A_DENSE, EPI_F32, BM, BN, WMS, WNS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         hipLaunchKernelGGL((gemm2_kernel<true, A_DENSE, EPI_F32, BM, BN, WMS, WNS, ABL>), dim3((unsigned)(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN))), dim3(WMS * WNS * 64), smem, st, p);
     } else {
@@ -1136,7 +1155,8 @@ extern "C" int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, int
         }
         if (tile == 2) return bench_launch2<256, 256, 2, 4, 0>(split, p, st);
         if (tile == 3) return bench_launch2<256, 128, 4, 2, 0>(split, p, st);
-        if (tile == 10) return bench_launch2<256, 128, 4, 2, 8>(split, p, st);   // 3-stage ring experiment
+        if (tile == 10) return split ? launch_gemm2<true, A_DENSE, EPI_F32, 256, 128, 4, 2, 3>(p, st)
+                                     : launch_gemm2<false, A_DENSE, EPI_F32, 256, 128, 4, 2, 3>(p, st);   // 3-stage ring experiment
         if (tile == 5) return bench_launch2<192, 256, 2, 4, 0>(split, p, st);
         if (tile == 6) return bench_launch2<192, 128, 2, 4, 0>(split, p, st);
         if (tile == 7) return bench_launch2<192, 128, 2, 2, 0>(split, p, st);
