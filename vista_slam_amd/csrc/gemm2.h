@@ -37,8 +37,8 @@ __device__ __forceinline__ int lds2_off(int row, int chunk) {
     return SPLIT ? row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4) : row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
 }
 
-// ABL (bench-only ablations, 0 in the product): 1 = no DMA inside the K loop, 2 = DMA + barriers only,
-// 3 = MFMA on stale registers (no LDS reads).
+// ABL (bench-only ablation bit mask, 0 in the product): 1 = no DMA inside the K loop, 2 = no LDS fragment
+// reads (MFMA on stale registers), 4 = no MFMA (fragments kept alive); barriers always stay.
 // NSTG: LDS stages.  2 = issue tile k+1, compute k, drain, barrier.  >2 = ring: the DMA runs NSTG-1 K tiles
 // ahead and stays in flight across the barrier (counted vmcnt + raw s_barrier in one asm statement) -
 // no gain on the big throughput shapes (DMA-throughput bound) but it is what makes the small-M /
@@ -170,6 +170,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
         __syncthreads();
     }
 
+    // STAGGER (ABL bit 3, experiment): the two waves that share a SIMD (w and w + NW/2) issue their DMA at
+    // different points of the K tile - the older half before K step 0, the younger half between the two
+    // K steps - so that one of them always has MFMAs to feed the matrix pipe while the other sits in the
+    // (slow, back-pressured) LDS-DMA issue.
+    const bool late_dma = (ABL & 8) && !RING && wave >= NW / 2;
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = RING ? kt % NSTG : (kt & 1);
         if (RING) {
@@ -181,21 +186,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
             else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * GPW) : "memory");
             // the barrier also says every wave finished tile kt-1: its stage is free for tile kt+NSTG-1
             if (kt + NSTG - 1 < nkt) issue_tile(kt0 + kt + NSTG - 1, (kt + NSTG - 1) % NSTG);
-        } else if (kt + 1 < nkt && (ABL & 3) != 1) issue_tile(kt0 + kt + 1, cur ^ 1);
+        } else if (kt + 1 < nkt && !(ABL & 1) && !late_dma) issue_tile(kt0 + kt + 1, cur ^ 1);
         const char* sA = smem + cur * STAGE;
         const char* sB = sA + A_TILE;
         half8 a_hi[MT], a_lo[MT], b_hi[NT], b_lo[NT];
-        if ((ABL & 3) == 3) {
+        if (ABL & 2) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) { a_hi[i] = (half8)(f16)(0.001f * (lane + i)); a_lo[i] = a_hi[i]; asm volatile("" : "+v"(a_hi[i]), "+v"(a_lo[i])); }
 #pragma unroll
             for (int j = 0; j < NT; ++j) { b_hi[j] = (half8)(f16)(0.002f * (lane + j)); b_lo[j] = b_hi[j]; asm volatile("" : "+v"(b_hi[j]), "+v"(b_lo[j])); }
         }
 #pragma unroll
-        for (int ks = 0; ks < 2 && (ABL & 3) != 2; ++ks) {
+        for (int ks = 0; ks < 2; ++ks) {
             const int chunk = ks * 2 + lhi;
 #pragma unroll
-            for (int i = 0; i < MT && (ABL & 3) != 3; ++i) {
+            for (int i = 0; i < MT && !(ABL & 2); ++i) {
                 const int ra = wm * WM + i * 32 + l31;
                 a_hi[i] = *reinterpret_cast<const half8*>(sA + lds2_off<SPLIT>(ra, chunk));
                 if (SPLIT) a_lo[i] = *reinterpret_cast<const half8*>(sA + lds2_off<SPLIT>(ra, 4 + chunk));
@@ -208,10 +213,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
                 }
             }
 #pragma unroll
-            for (int j = 0; j < NT && (ABL & 3) != 3; ++j) {
+            for (int j = 0; j < NT && !(ABL & 2); ++j) {
                 const int rb = wn * WN + j * 32 + l31;
                 b_hi[j] = *reinterpret_cast<const half8*>(sB + lds2_off<SPLIT>(rb, chunk));
                 if (SPLIT) b_lo[j] = *reinterpret_cast<const half8*>(sB + lds2_off<SPLIT>(rb, 4 + chunk));
+            }
+            if (ABL & 4) {      // keep the fragment loads alive, skip the matrix work
+#pragma unroll
+                for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(a_hi[i]), "v"(a_lo[i]));
+#pragma unroll
+                for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(b_hi[j]), "v"(b_lo[j]));
+                continue;
             }
             // product-major order: consecutive MFMAs hit different accumulators (MT*NT apart)
             if (SPLIT) {
@@ -231,6 +243,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+            if ((ABL & 8) && ks == 0 && late_dma && kt + 1 < nkt) issue_tile(kt0 + kt + 1, cur ^ 1);
         }
         if (!RING) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

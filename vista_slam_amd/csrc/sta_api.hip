@@ -1151,12 +1151,22 @@ extern "C" int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, int
                     default: return bench_launch2<256, 256, 2, 4, 7>(split, p, st);
                 }
             }
-            if (abl == 1) return bench_launch2<256, 128, 4, 2, 1>(split, p, st); if (abl == 2) return bench_launch2<256, 128, 4, 2, 2>(split, p, st); return bench_launch2<256, 128, 4, 2, 3>(split, p, st);
+            switch (abl) {
+                case 1: return bench_launch2<192, 128, 2, 4, 1>(split, p, st);
+                case 2: return bench_launch2<192, 128, 2, 4, 2>(split, p, st);
+                case 3: return bench_launch2<192, 128, 2, 4, 3>(split, p, st);
+                case 4: return bench_launch2<192, 128, 2, 4, 4>(split, p, st);
+                case 5: return bench_launch2<192, 128, 2, 4, 5>(split, p, st);
+                case 6: return bench_launch2<192, 128, 2, 4, 6>(split, p, st);
+                default: return bench_launch2<192, 128, 2, 4, 7>(split, p, st);
+            }
         }
         if (tile == 2) return bench_launch2<256, 256, 2, 4, 0>(split, p, st);
         if (tile == 3) return bench_launch2<256, 128, 4, 2, 0>(split, p, st);
         if (tile == 10) return split ? launch_gemm2<true, A_DENSE, EPI_F32, 256, 128, 4, 2, 3>(p, st)
                                      : launch_gemm2<false, A_DENSE, EPI_F32, 256, 128, 4, 2, 3>(p, st);   // 3-stage ring experiment
+        if (tile == 11) return bench_launch2<256, 256, 2, 4, 8>(split, p, st);   // staggered DMA issue
+        if (tile == 12) return bench_launch2<192, 128, 2, 4, 8>(split, p, st);
         if (tile == 5) return bench_launch2<192, 256, 2, 4, 0>(split, p, st);
         if (tile == 6) return bench_launch2<192, 128, 2, 4, 0>(split, p, st);
         if (tile == 7) return bench_launch2<192, 128, 2, 2, 0>(split, p, st);
