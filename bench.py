@@ -67,7 +67,12 @@ def slam_probe(model, dev, iters=20):
     pose_ms, _ = timed(lambda: model.head_pose_s(d1[-1][:, 0, :]))
     dpt_ms, _ = timed(lambda: model.head_pts([fa] + [t[:, 1:, :] for t in d1], ts))
     pair_ms = dec_ms + pose_ms + 2 * dpt_ms
-    return {"encode_ms": round(enc_ms, 3), "decode_ms": round(dec_ms, 3), "pose_ms": round(pose_ms, 3),
+    # f2: the same keyframe (5 accepted edges) through the batched native scheduler (sta_regress_views)
+    from vista_slam_amd.slam_scheduler import regress_views
+    sched_ms, _ = timed(lambda: regress_views(model, fa, [fb] * 5, [True] * 5, 0.0, 224, 224))
+    return {"scheduler_5edges_ms": round(sched_ms, 3),
+            "keyframes_per_s_scheduler": round(1e3 / (enc_ms + sched_ms), 2),
+            "encode_ms": round(enc_ms, 3), "decode_ms": round(dec_ms, 3), "pose_ms": round(pose_ms, 3),
             "dpt_ms_per_view": round(dpt_ms, 3), "accepted_pair_ms": round(pair_ms, 3),
             "keyframes_per_s_est_5pairs": round(1e3 / (enc_ms + 5 * pair_ms), 2),
             "note": "frontend-only estimate for a TUM-style keyframe (1 encode + 5 accepted pairs); the reference's CPU stages (ORB/DBoW3, PGO) are not included"}
@@ -102,6 +107,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-slam-probe", action="store_true")
     ap.add_argument("--gemm-variant", type=int, default=0, help="experiments only: force a GEMM tile family (0 = product selection)")
+    ap.add_argument("--slices", type=int, default=1, help="batch slices run concurrently on internal streams (1 or 2)")
     args = ap.parse_args()
 
     import torch
@@ -123,6 +129,7 @@ def main():
     if args.gemm_variant:
         from vista_slam_amd import _lib
         _lib.check(model.lib.sta_set_gemm_variant(model._h, args.gemm_variant))
+    model.set_concurrency(args.slices)
     B = args.pairs
     imgs = Wt.synth_images(2 * B, H, W_, seed=43, tag=rank)          # different pairs on every rank
     img_a = torch.from_numpy(imgs[:B]).to(dev)

@@ -77,6 +77,12 @@ int sta_destroy(sta_handle* h);
 /* Change the arithmetic policy after creation (weights hold both split planes). */
 int sta_set_precision(sta_handle* h, int precision);
 
+/* Batch-slice concurrency of sta_forward_pair*: 1 = one slice on the caller's stream (default); 2 = the batch is cut
+ * in two slices that run on two library-owned streams, forked from / joined to the caller's stream by events, so the
+ * hardware overlaps one slice's GEMM tail rounds and HBM-bound kernels with the other's MFMA main loops.  Results are
+ * identical per pair (no cross-pair arithmetic).  No reference counterpart (torch runs one stream). */
+int sta_set_concurrency(sta_handle* h, int n_slices);
+
 /* Number of state_dict entries the handle expects / has received so far. */
 int sta_num_expected_tensors(const sta_handle* h);
 int sta_num_loaded_tensors(const sta_handle* h);
@@ -136,14 +142,34 @@ int sta_forward_pair_u8hwc(sta_handle* h, const uint8_t* img_a, const uint8_t* i
 /* reductions that consume the path's output for every accepted pair, one fused pass.
  * sta_estimate_intrinsics <- estimate_intrinsic_from_pts3d(pts3d, confidence, shared_intrinsic)
  * (vista_slam/utils/slam_utils.py:8-79; slam.py:184) and, in the same read, depths = pts[...,2]
- * (slam.py:185) and conf.mean() per image (pose_graph.py:37).  K_out is [3,3] (shared) or [B,3,3];
- * depth_out [B,H,W] and conf_mean_out [B] may be NULL.
+ * (slam.py:185) and conf.mean() per image (pose_graph.py:37).  shared = 0: K_out [B,3,3]; shared = 1: one K [3,3] over
+ * all B images; shared = g >= 2: one K per group of g consecutive images, K_out [B/g,3,3] (g = 2: the two views of a
+ * pair).  depth_out [B,H,W] and conf_mean_out [B] may be NULL.
  * sta_estimate_scale <- estimate_scale_with_depth_and_confidence(Di, Dj, ci, cj) (slam_utils.py:168-190),
  * s_out is one device float. */
 int sta_estimate_intrinsics(sta_handle* h, const float* pts, const float* conf, int B, int H, int W, int shared,
                             float* K_out, float* depth_out, float* conf_mean_out, void* stream);
 int sta_estimate_scale(sta_handle* h, const float* Di, const float* Dj, const float* ci, const float* cj, int64_t n,
                        float* s_out, void* stream);
+
+/* keyframe scheduler = OnlineSLAM.regress_two_views (vista_slam/slam.py:153-189) for ALL k candidate
+ * edges (i, j_e) of a new keyframe i (the neighbour loop slam.py:263-265 and the loop-closure loop :273-277) in one
+ * batched launch sequence instead of k sequential B=1 calls, with the reference's early reject kept:
+ *   decode (i, j_e) for e < k  ->  pose head on the ij side (slam.py:165)  ->  one k-float D2H read (the reference
+ *   synchronises at the same point, slam.py:169)  ->  edge e is REJECTED iff pose_conf[e] < rel_pose_thres and
+ *   !adjacent[e] (adjacent[e] = (i - j_e == 1), slam.py:169)  ->  DPT heads for both views of the accepted edges only
+ *   ->  shared-per-pair intrinsics and depths (slam.py:182-185).
+ * feat_i [N,1024] device, feat_j[e] [N,1024] device (encoder features cached by add_view, slam.py:142-151).
+ * pose [k,16] device (pose_ij, 4x4 row-major, every edge).  pose_conf_host [k], slot_host [k], n_accepted: HOST
+ * outputs, valid on return (the call synchronises `stream` once): slot_host[e] = -1 for a rejected edge, else the
+ * compact index s of edge e in the per-accepted-edge outputs, all device:
+ *   pts [n_acc,2,H,W,3] (view order [ij, ji] = torch.cat order of slam.py:182), conf [n_acc,2,H,W],
+ *   K [n_acc,3,3] (shared over the pair's two views), depth [n_acc,2,H,W].
+ * The buffers must be sized for k edges.  k <= 16. */
+int sta_regress_views(sta_handle* h, const float* feat_i, const float* const* feat_j, int k,
+                      const uint8_t* adjacent, float rel_pose_thres, int H, int W,
+                      float* pose, float* pose_conf_host, int* slot_host, int* n_accepted,
+                      float* pts, float* conf, float* K, float* depth, void* stream);
 
 /* In-place 2-D RoPE on fp32 tokens (B,N,Hh,D) with element strides (stride of D must be 1,
  * stride of Hh must be D; same contract as kernels.cu:91-94); pos int64 [B,N,2] contiguous. */

@@ -191,6 +191,101 @@ def test_u8_hwc_input_matches_normalised_fp32(G):
         assert rel_l2(m2[k].cpu().numpy(), m1[k].cpu().numpy()) < 1e-5 and rel_l2(s2[k].cpu().numpy(), s1[k].cpu().numpy()) < 1e-5
 
 
+def test_two_slice_concurrency_matches_single_stream(G):
+    """sta_set_concurrency(2): two batch slices on internal streams, forked/joined on the caller's stream,
+    give the single-stream outputs (odd batch -> uneven slices; full-config weights at 224x224)."""
+    import torch
+    from helpers import rel_l2
+    from vista_slam_amd import weights as W
+    for cfg, B, H, Wd in (("tiny", 5, 48, 64), ("full", 3, 224, 224)):
+        m = G.model(cfg, 1.0, "f16x3")
+        G.set_variant(m, 0)
+        imgs = torch.from_numpy(W.synth_images(2 * B, H, Wd, seed=43, tag=9)).cuda()
+        m.set_concurrency(1)
+        a1, a2 = m.forward_pair(imgs[:B], imgs[B:])
+        torch.cuda.synchronize()
+        ref = {k: (a1[k].clone(), a2[k].clone()) for k in ("pts3d_pred", "conf", "relative_pose", "relative_pose_conf")}
+        m.set_concurrency(2)
+        try:
+            b1, b2 = m.forward_pair(imgs[:B], imgs[B:])
+            torch.cuda.synchronize()
+            for k, (r1, r2) in ref.items():
+                assert rel_l2(b1[k].cpu().numpy(), r1.cpu().numpy()) < 2e-5, (cfg, k)
+                assert rel_l2(b2[k].cpu().numpy(), r2.cpu().numpy()) < 2e-5, (cfg, k)
+        finally:
+            m.set_concurrency(1)
+
+
+def _sequential_regress(m, feats, pos, i, j, thres, H, Wd):
+    """The reference call pattern of regress_two_views (slam.py:153-189) through the drop-in shim, one edge, B=1."""
+    import torch
+    from vista_slam_amd import post
+    d_ij, d_ji = m._decode_stereo(feats[i], feats[j], pos, pos)
+    pose = m.head_pose_s(d_ij[-1][:, 0, :])
+    c = float(pose["conf"][0])
+    if c < thres and i - j != 1:
+        return pose["pose"][0], c, None, None, None
+    ts = torch.tensor([[H, Wd]])
+    ji = m.head_pts([feats[j]] + [t[:, 1:, :] for t in d_ji], ts)
+    ij = m.head_pts([feats[i]] + [t[:, 1:, :] for t in d_ij], ts)
+    pcls = torch.cat([ij["pts3d"], ji["pts3d"]], 0)
+    confs = torch.cat([ij["conf"], ji["conf"]], 0)
+    intri = post.estimate_intrinsic_from_pts3d(m, pcls, confs, shared_intrinsic=True)
+    return pose["pose"][0], c, confs, intri, pcls[..., 2]
+
+
+@pytest.mark.parametrize("cfg,H,Wd,nview", [("tiny", 48, 64, 6), ("full", 224, 224, 4)])
+def test_keyframe_scheduler_f2_matches_sequential_edges(G, cfg, H, Wd, nview):
+    """f2: one batched sta_regress_views call == the reference's per-edge regress_two_views sequence, incl. the
+    early reject (threshold set between the observed confidences so both branches are exercised) and the
+    adjacent-edge exemption."""
+    import torch
+    from helpers import rel_l2
+    from vista_slam_amd import weights as W
+    from vista_slam_amd.slam_scheduler import regress_views
+    m = G.model(cfg, 1.0, "f16x3")
+    G.set_variant(m, 0)
+    imgs = torch.from_numpy(W.synth_images(nview, H, Wd, seed=43, tag=21)).cuda()
+    feats, pos = [], None
+    for v in range(nview):
+        f, pos = m._encode_image(imgs[v:v + 1], None, normalize=False)
+        feats.append(f)
+    i = nview - 1
+    js = list(range(i))
+    probe = [_sequential_regress(m, feats, pos, i, j, -1.0, H, Wd)[1] for j in js]
+    thres = float(sorted(probe)[len(probe) // 2]) + 1e-7          # rejects about half of the non-adjacent edges
+    seq = [_sequential_regress(m, feats, pos, i, j, thres, H, Wd) for j in js]
+    res = regress_views(m, feats[i], [feats[j] for j in js], [i - j == 1 for j in js], thres, H, Wd)
+    torch.cuda.synchronize()
+    n_rej = 0
+    for j, r, (pose, c, confs, intri, depths) in zip(js, res, seq):
+        assert abs(r.rel_pose_conf - c) <= 2e-6 * max(1.0, abs(c)), (j, r.rel_pose_conf, c)
+        assert rel_l2(r.pose.cpu().numpy(), pose.cpu().numpy()) < 2e-5
+        assert r.accepted == (confs is not None), (j, r.rel_pose_conf, thres)
+        if confs is None:
+            n_rej += 1
+            assert r.confs is None and r.intri is None and r.depths is None
+            continue
+        assert rel_l2(r.confs.cpu().numpy(), confs.cpu().numpy()) < 2e-5
+        assert rel_l2(r.depths.cpu().numpy(), depths.cpu().numpy()) < 2e-5
+        assert rel_l2(r.intri.cpu().numpy(), intri.cpu().numpy()) < 2e-5
+    assert res[-1].accepted                      # the adjacent edge is never rejected (slam.py:169)
+    assert 0 < n_rej < len(js)
+
+
+def test_keyframe_scheduler_f2_all_rejected_and_errors(G):
+    import torch
+    from vista_slam_amd import weights as W
+    from vista_slam_amd.slam_scheduler import regress_views
+    m = G.model("tiny", 1.0, "f16x3")
+    imgs = torch.from_numpy(W.synth_images(3, 48, 64, seed=43, tag=22)).cuda()
+    feats = [m._encode_image(imgs[v:v + 1], None, normalize=False)[0] for v in range(3)]
+    res = regress_views(m, feats[2], [feats[0]], [False], 2.0, 48, 64)       # sigmoid conf < 2: always rejected
+    assert not res[0].accepted and res[0].depths is None and 0.0 < res[0].rel_pose_conf < 1.0
+    with pytest.raises(AssertionError):
+        regress_views(m, feats[2], [feats[0][:, :5]], [False], 0.5, 48, 64)
+
+
 def test_post_sta_reductions_f1(G):
     """f1: fused intrinsics / depth / mean-confidence pass and the scale estimate vs reference goldens."""
     import torch

@@ -438,8 +438,10 @@ __global__ __launch_bounds__(256) void intrinsics_partial_kernel(const float* pt
         red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// shared: 0 = one K per image, 1 = one K over all B images, g >= 2 = one K per group of g consecutive images
+// (g = 2: the two views of a pair, slam.py:184 shared_intrinsic=True) -> K [B/g,3,3].
 __global__ void intrinsics_final_kernel(const double* partial, int B, int nblk, int H, int W, int shared,
-                                        float* K /*[3,3] or [B,3,3]*/, float* conf_mean /*[B] or null*/) {
+                                        float* K /*[3,3] or [B,3,3] or [B/g,3,3]*/, float* conf_mean /*[B] or null*/) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double tot[5] = {0, 0, 0, 0, 0};
     for (int b = 0; b < B; ++b) {
@@ -447,6 +449,13 @@ __global__ void intrinsics_final_kernel(const double* partial, int B, int nblk, 
         for (int j = 0; j < nblk; ++j) for (int k = 0; k < 5; ++k) s[k] += partial[((int64_t)b * nblk + j) * 5 + k];
         if (conf_mean) conf_mean[b] = (float)(s[4] / ((double)H * W));
         for (int k = 0; k < 5; ++k) tot[k] += s[k];
+        if (shared >= 2 && (b + 1) % shared == 0) {
+            float* Kb = K + (b / shared) * 9;
+            Kb[0] = (float)(tot[0] / tot[1]); Kb[1] = 0.f; Kb[2] = W / 2.0f;
+            Kb[3] = 0.f; Kb[4] = (float)(tot[2] / tot[3]); Kb[5] = H / 2.0f;
+            Kb[6] = 0.f; Kb[7] = 0.f; Kb[8] = 1.f;
+            for (int k = 0; k < 5; ++k) tot[k] = 0;
+        }
         if (!shared) {
             float* Kb = K + b * 9;
             Kb[0] = (float)(s[0] / s[1]); Kb[1] = 0.f; Kb[2] = W / 2.0f;
@@ -454,7 +463,7 @@ __global__ void intrinsics_final_kernel(const double* partial, int B, int nblk, 
             Kb[6] = 0.f; Kb[7] = 0.f; Kb[8] = 1.f;
         }
     }
-    if (shared) {
+    if (shared == 1) {
         K[0] = (float)(tot[0] / tot[1]); K[1] = 0.f; K[2] = W / 2.0f;
         K[3] = 0.f; K[4] = (float)(tot[2] / tot[3]); K[5] = H / 2.0f;
         K[6] = 0.f; K[7] = 0.f; K[8] = 1.f;
@@ -534,4 +543,14 @@ __global__ void repack_weight_kernel(const float* src, f16* hi, f16* lo, int64_t
 __global__ void expand_bias_kernel(const float* b, float* out, int cout, int reps) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < cout * reps) out[i] = b[i % cout];
+}
+
+// Gather of up to 64 equally-typed chunks (16-byte units) in one launch: blockIdx.y = chunk.  Used by the keyframe
+// scheduler (sta_regress_views) to batch per-view feature tensors that live at unrelated addresses.
+struct GatherChunks { const uint4* src[64]; uint4* dst[64]; int64_t n16[64]; };
+__global__ __launch_bounds__(256) void gather_chunks_kernel(GatherChunks g) {
+    const uint4* s = g.src[blockIdx.y];
+    uint4* d = g.dst[blockIdx.y];
+    const int64_t n = g.n16[blockIdx.y];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = s[i];
 }

@@ -81,6 +81,8 @@ struct sta_handle {
     bool timing = false; hipEvent_t ev[5]; bool ev_ok = false;
     // per-launch timing of the dominant kernel (gemm_kernel<*, A_DENSE, EPI_F32>) for the roofline report
     bool ktime = false; std::vector<hipEvent_t> kev; int kn = 0; std::vector<double> kflops, kbytes; std::vector<int> kvar;
+    // optional two-slice concurrency (sta_set_concurrency)
+    int n_streams = 1; hipStream_t aux[2] = {nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     bool dry = false;   // planning pass: run the orchestration without launching to size the workspace
 };
 
@@ -111,6 +113,16 @@ struct Bump {
         return p;
     }
 };
+
+static int ensure_streams(sta_handle* h) {
+    if (h->aux[0]) return 0;
+    HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+    }
+    return 0;
+}
 
 static int ensure_ws(sta_handle* h, int64_t bytes) {
     if (bytes <= h->ws_cap) return 0;
@@ -313,6 +325,10 @@ extern "C" int sta_destroy(sta_handle* h) {
     if (h->zero_page) hipFree(h->zero_page);
     if (h->ev_ok) for (auto& e : h->ev) hipEventDestroy(e);
     for (auto& e : h->kev) hipEventDestroy(e);
+    if (h->aux[0]) {
+        hipEventDestroy(h->ev_fork);
+        for (int i = 0; i < 2; ++i) { hipStreamDestroy(h->aux[i]); hipEventDestroy(h->ev_join[i]); }
+    }
     delete h;
     return 0;
 }
@@ -321,6 +337,12 @@ extern "C" int sta_set_precision(sta_handle* h, int precision) {
     REQUIRE(h, "null handle");
     REQUIRE(precision == STA_PREC_F16 || precision == STA_PREC_F16X3, "unknown precision %d", precision);
     h->prec = precision;
+    return 0;
+}
+extern "C" int sta_set_concurrency(sta_handle* h, int n_slices) {
+    REQUIRE(h, "null handle");
+    REQUIRE(n_slices == 1 || n_slices == 2, "n_slices must be 1 or 2");
+    h->n_streams = n_slices;
     return 0;
 }
 extern "C" int sta_set_gemm_variant(sta_handle* h, int variant) {
@@ -952,34 +974,64 @@ static int forward_pair_any(sta_handle* h, const void* img_a, const void* img_b,
     const sta_config& c = h->cfg;
     const int hp = H / 16, wp = W / 16, N = hp * wp, Np = N + 1, E = c.enc_embed_dim, D = c.dec_embed_dim, S = 2 * B;
     CHK(ensure_rope(h, hp > wp ? hp : wp));
-    const int64_t feat_b = (int64_t)S * N * E * 4, x_b = (int64_t)S * Np * D * 4;
     if (h->timing && !h->ev_ok) { for (auto& e : h->ev) HIPCHK(hipEventCreate(&e)); h->ev_ok = true; }
     const int dd = c.dec_depth;
     const int hidx[3] = {dd * 2 / 4, dd * 3 / 4, dd};   // hooks [d/2+1, 3d/4+1, d+1] - 1 (dpt_head.py:112)
-    return plan_and_run(h, [&](Bump& ws) -> int {
-        const bool rec = h->timing && !h->dry;
+    // one batch slice of pairs, every launch on stream `st`
+    auto run_slice = [&](Bump& ws, const void* ia, const void* ib, int Bs, float* const p[2], float* const cf[2],
+                         float* const po[2], float* const pc[2], hipStream_t st, bool rec) -> int {
+        const int Ss = 2 * Bs;
+        const int64_t feat_b = (int64_t)Ss * N * E * 4, x_b = (int64_t)Ss * Np * D * 4;
         float* feat = (float*)ws.take(feat_b);
         float* x = (float*)ws.take(x_b);
         float* hk[3] = {(float*)ws.take(x_b), (float*)ws.take(x_b), (float*)ws.take(x_b)};
         const int64_t mark = ws.off;
         if (rec) HIPCHK(hipEventRecord(h->ev[0], st));
-        const void* imgs[2] = {img_a, img_b};
-        CHK(encode_impl(h, ws, imgs, u8hwc, 2, B, H, W, feat, st));
+        const void* imgs[2] = {ia, ib};
+        CHK(encode_impl(h, ws, imgs, u8hwc, 2, Bs, H, W, feat, st));
         if (rec) HIPCHK(hipEventRecord(h->ev[1], st));
         ws.rewind(mark);
         std::vector<float*> w1(dd + 1, nullptr), w2(dd + 1, nullptr);
-        for (int k = 0; k < 3; ++k) { w1[hidx[k]] = hk[k]; w2[hidx[k]] = hk[k] + (size_t)B * Np * D; }
-        CHK(decode_impl(h, ws, feat, feat + (size_t)B * N * E, B, hp, wp, x, w1.data(), w2.data(), st));
+        for (int k = 0; k < 3; ++k) { w1[hidx[k]] = hk[k]; w2[hidx[k]] = hk[k] + (size_t)Bs * Np * D; }
+        CHK(decode_impl(h, ws, feat, feat + (size_t)Bs * N * E, Bs, hp, wp, x, w1.data(), w2.data(), st));
         if (rec) HIPCHK(hipEventRecord(h->ev[2], st));
         // pose heads read token 0 of the dec_norm'ed last layer (sta_model.py:273,277)
         ws.rewind(mark);
-        CHK(pose_impl(h, ws, hk[2], B, (int64_t)Np * D, pose[0], pose_conf[0], st));
-        CHK(pose_impl(h, ws, hk[2] + (size_t)B * Np * D, B, (int64_t)Np * D, pose[1], pose_conf[1], st));
+        CHK(pose_impl(h, ws, hk[2], Bs, (int64_t)Np * D, po[0], pc[0], st));
+        CHK(pose_impl(h, ws, hk[2] + (size_t)Bs * Np * D, Bs, (int64_t)Np * D, po[1], pc[1], st));
         if (rec) HIPCHK(hipEventRecord(h->ev[3], st));
         ws.rewind(mark);
         CHK(dpt_impl(h, ws, feat, (int64_t)N * E, hk[0] + D, (int64_t)Np * D, hk[1] + D, (int64_t)Np * D, hk[2] + D, (int64_t)Np * D,
-                     S, H, W, pts[0], conf[0], B, pts[1], conf[1], st));
+                     Ss, H, W, p[0], cf[0], Bs, p[1], cf[1], st));
         if (rec) HIPCHK(hipEventRecord(h->ev[4], st));
+        return 0;
+    };
+    const int nsl = (h->n_streams > 1 && B >= 2) ? 2 : 1;
+    if (nsl == 1)
+        return plan_and_run(h, [&](Bump& ws) -> int {
+            return run_slice(ws, img_a, img_b, B, pts, conf, pose, pose_conf, st, h->timing && !h->dry);
+        });
+    // Two batch slices on two internal streams: the hardware interleaves their workgroups, so the tail round of one
+    // slice's GEMM and its HBM-bound kernels overlap the other slice's MFMA-bound main loops.  Fork/join by events;
+    // the caller's stream sees one asynchronous operation.
+    CHK(ensure_streams(h));
+    const int64_t img_el = (int64_t)3 * H * W * (u8hwc ? 1 : 4), px = (int64_t)H * W;
+    return plan_and_run(h, [&](Bump& ws) -> int {
+        if (!h->dry) HIPCHK(hipEventRecord(h->ev_fork, st));
+        int b0 = 0;
+        for (int s = 0; s < 2; ++s) {
+            const int Bs = s == 0 ? B / 2 : B - B / 2;
+            hipStream_t ss = h->aux[s];
+            if (!h->dry) HIPCHK(hipStreamWaitEvent(ss, h->ev_fork, 0));
+            float* p[2] = {pts[0] + b0 * px * 3, pts[1] + b0 * px * 3};
+            float* cf[2] = {conf[0] + b0 * px, conf[1] + b0 * px};
+            float* po[2] = {pose[0] + b0 * 16, pose[1] + b0 * 16};
+            float* pc[2] = {pose_conf[0] + b0, pose_conf[1] + b0};
+            ws.off = ws.peak;    // slices own disjoint workspace regions
+            CHK(run_slice(ws, (const char*)img_a + b0 * img_el, (const char*)img_b + b0 * img_el, Bs, p, cf, po, pc, ss, false));
+            if (!h->dry) { HIPCHK(hipEventRecord(h->ev_join[s], ss)); HIPCHK(hipStreamWaitEvent(st, h->ev_join[s], 0)); }
+            b0 += Bs;
+        }
         return 0;
     });
 }
@@ -999,6 +1051,7 @@ extern "C" int sta_forward_pair_u8hwc(sta_handle* h, const uint8_t* img_a, const
 extern "C" int sta_estimate_intrinsics(sta_handle* h, const float* pts, const float* conf, int B, int H, int W, int shared,
                                        float* K_out, float* depth_out, float* conf_mean_out, void* stream) {
     REQUIRE(h && pts && conf && K_out && B > 0 && H > 0 && W > 0, "bad argument");
+    REQUIRE(shared >= 0 && (shared < 2 || B % shared == 0), "shared group size %d does not divide B=%d", shared, B);
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     const int64_t hw = (int64_t)H * W;
@@ -1009,6 +1062,111 @@ extern "C" int sta_estimate_intrinsics(sta_handle* h, const float* pts, const fl
         REQUIRE(!ws.overflow, "internal: workspace overflow");
         hipLaunchKernelGGL(intrinsics_partial_kernel, dim3(nblk, B), dim3(256), 0, st, pts, conf, B, H, W, depth_out, partial, nblk);
         hipLaunchKernelGGL(intrinsics_final_kernel, dim3(1), dim3(64), 0, st, partial, B, nblk, H, W, shared, K_out, conf_mean_out);
+        HIPCHK(hipGetLastError());
+        return 0;
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// f2: keyframe scheduler.  OnlineSLAM.step (slam.py:263-277) calls regress_two_views (slam.py:153-189) once per
+// candidate edge (i, j): B=1 decode -> pose head (ij only) -> early return when the pose confidence is below
+// rel_pose_thres and the views are not adjacent -> DPT on both views -> shared intrinsics + depths.
+// Here all k candidate edges of keyframe i are decoded in ONE batched launch sequence, the pose head runs first,
+// one k-float D2H read decides acceptance, and the DPT + post-STA reductions run batched over the accepted edges
+// only (so the DPT-skip saving of the reference is kept).
+static int launch_gather(const GatherChunks& g, int n, int64_t max16, hipStream_t st) {
+    int gx = (int)((max16 + 256 * 4 - 1) / (256 * 4)); if (gx < 1) gx = 1; if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(gather_chunks_kernel, dim3(gx, n), dim3(256), 0, st, g);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sta_regress_views(sta_handle* h, const float* feat_i, const float* const* feat_j, int k,
+                                 const uint8_t* adjacent, float rel_pose_thres, int H, int W,
+                                 float* pose, float* pose_conf_host, int* slot_host, int* n_accepted,
+                                 float* pts, float* conf, float* K, float* depth, void* stream) {
+    CHK(check_ready(h, k, H, W));
+    REQUIRE(k <= 16, "at most 16 candidate edges per keyframe (got %d)", k);
+    REQUIRE(feat_i && feat_j && adjacent && pose && pose_conf_host && slot_host && n_accepted && pts && conf && K && depth,
+            "null argument");
+    for (int e = 0; e < k; ++e) REQUIRE(feat_j[e] && ((uintptr_t)feat_j[e] & 15) == 0, "feat_j[%d] null or not 16-byte aligned", e);
+    REQUIRE(((uintptr_t)feat_i & 15) == 0, "feat_i not 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const sta_config& c = h->cfg;
+    const int hp = H / 16, wp = W / 16, N = hp * wp, Np = N + 1, E = c.enc_embed_dim, D = c.dec_embed_dim, S = 2 * k;
+    CHK(ensure_rope(h, hp > wp ? hp : wp));
+    const int dd = c.dec_depth;
+    const int hidx[3] = {dd * 2 / 4, dd * 3 / 4, dd};
+    const int64_t fe = (int64_t)N * E, xe = (int64_t)Np * D;
+    *n_accepted = 0;
+    return plan_and_run(h, [&](Bump& ws) -> int {
+        float* F = (float*)ws.take(S * fe * 4);              // [2k,N,E]: k copies of view i, then the k views j
+        float* x = (float*)ws.take(S * xe * 4);
+        float* hk[3] = {(float*)ws.take(S * xe * 4), (float*)ws.take(S * xe * 4), (float*)ws.take(S * xe * 4)};
+        float* cdev = (float*)ws.take(k * 4);
+        float* cf = (float*)ws.take(S * fe * 4);             // compacted DPT inputs of the accepted edges
+        float* ch[3] = {(float*)ws.take(S * xe * 4), (float*)ws.take(S * xe * 4), (float*)ws.take(S * xe * 4)};
+        const int64_t mark = ws.off;
+        if (!h->dry) {
+            GatherChunks g;
+            for (int e = 0; e < k; ++e) {
+                g.src[e] = (const uint4*)feat_i; g.dst[e] = (uint4*)(F + e * fe); g.n16[e] = fe / 4;
+                g.src[k + e] = (const uint4*)feat_j[e]; g.dst[k + e] = (uint4*)(F + (k + e) * fe); g.n16[k + e] = fe / 4;
+            }
+            CHK(launch_gather(g, 2 * k, fe / 4, st));
+        }
+        std::vector<float*> w1(dd + 1, nullptr), w2(dd + 1, nullptr);
+        for (int q = 0; q < 3; ++q) { w1[hidx[q]] = hk[q]; w2[hidx[q]] = hk[q] + (size_t)k * xe; }
+        CHK(decode_impl(h, ws, F, F + (size_t)k * fe, k, hp, wp, x, w1.data(), w2.data(), st));
+        ws.rewind(mark);
+        CHK(pose_impl(h, ws, hk[2], k, xe, pose, cdev, st));       // pose_ij only (slam.py:165)
+        int na = k;
+        int slots[16];
+        if (!h->dry) {
+            HIPCHK(hipMemcpyAsync(pose_conf_host, cdev, (size_t)k * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));                      // the reference syncs here too (slam.py:169)
+            na = 0;
+            for (int e = 0; e < k; ++e) {
+                const bool rej = pose_conf_host[e] < rel_pose_thres && !adjacent[e];   // slam.py:169
+                slots[e] = rej ? -1 : na++;
+                slot_host[e] = slots[e];
+            }
+            *n_accepted = na;
+            if (na == 0) return 0;
+            GatherChunks g;
+            int m = 0;
+            for (int e = 0; e < k; ++e) {
+                if (slots[e] < 0) continue;
+                const int s0 = 2 * slots[e];                       // image order per edge: [ij, ji] (slam.py:182)
+                for (int side = 0; side < 2; ++side) {
+                    g.src[m] = (const uint4*)(F + (size_t)(side * k + e) * fe); g.dst[m] = (uint4*)(cf + (size_t)(s0 + side) * fe); g.n16[m] = fe / 4; ++m;
+                }
+            }
+            CHK(launch_gather(g, m, fe / 4, st));
+            REQUIRE(xe % 4 == 0, "internal: hook slice not 16-byte sized");
+            for (int q = 0; q < 3; ++q) {
+                m = 0;
+                for (int e = 0; e < k; ++e) {
+                    if (slots[e] < 0) continue;
+                    const int s0 = 2 * slots[e];
+                    for (int side = 0; side < 2; ++side) {
+                        g.src[m] = (const uint4*)(hk[q] + (size_t)(side * k + e) * xe); g.dst[m] = (uint4*)(ch[q] + (size_t)(s0 + side) * xe); g.n16[m] = xe / 4; ++m;
+                    }
+                }
+                CHK(launch_gather(g, m, xe / 4, st));
+            }
+        }
+        ws.rewind(mark);
+        const int n = 2 * na;
+        CHK(dpt_impl(h, ws, cf, fe, ch[0] + D, xe, ch[1] + D, xe, ch[2] + D, xe, n, H, W, pts, conf, n, nullptr, nullptr, st));
+        ws.rewind(mark);
+        const int64_t hw = (int64_t)H * W;
+        int nblk = (int)((hw + 256 * 8 - 1) / (256 * 8)); if (nblk > 256) nblk = 256; if (nblk < 1) nblk = 1;
+        double* partial = (double*)ws.take((int64_t)n * nblk * 5 * 8);
+        if (h->dry) return 0;
+        REQUIRE(!ws.overflow, "internal: workspace overflow");
+        hipLaunchKernelGGL(intrinsics_partial_kernel, dim3(nblk, n), dim3(256), 0, st, pts, conf, n, H, W, depth, partial, nblk);
+        hipLaunchKernelGGL(intrinsics_final_kernel, dim3(1), dim3(64), 0, st, partial, n, nblk, H, W, 2, K, (float*)nullptr);
         HIPCHK(hipGetLastError());
         return 0;
     });
