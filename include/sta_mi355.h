@@ -152,6 +152,19 @@ int sta_estimate_intrinsics(sta_handle* h, const float* pts, const float* conf, 
 int sta_estimate_scale(sta_handle* h, const float* Di, const float* Dj, const float* ci, const float* cj, int64_t n,
                        float* s_out, void* stream);
 
+/* input step = SLAM_image_only.process_image (vista_slam/datasets/slam_images_only.py:19-33):
+ * `_crop_resize_if_necessary_image_only(rgb, resolution, w_edge, h_edge)` (datasets/base/base_view_graph_dataset.py:
+ * 171-225: centre crop with an edge margin, cropping.rescale_image_depthmap LANCZOS rescale to cover the resolution
+ * - vista_slam/utils/cropping.py:54-81 -, centre crop to the resolution) followed by ImgNorm (ToTensor +
+ * Normalize(0.5,0.5)) and ImgGray (ToTensor + Grayscale).  src: one uint8 RGB frame [Hs,Ws,3] on the device.
+ * Outputs (device, any may be NULL): u8_out [out_H,out_W,3] uint8 = the PIL image the reference hands to its
+ * transforms, bit-exact to Pillow's 8-bit LANCZOS resampler (feeds sta_encode_u8hwc directly); rgb_out
+ * [3,out_H,out_W] fp32 = value['rgb']; gray_out [out_H,out_W] fp32 = value['gray'].  Landscape / square frames and
+ * resolutions only (portrait -> error; the reference transposes the resolution there).  The coefficient tables of one
+ * geometry are cached in the handle; a geometry change synchronises `stream` once. */
+int sta_preprocess_frame(sta_handle* h, const uint8_t* src, int Hs, int Ws, int out_H, int out_W, int w_edge, int h_edge,
+                         uint8_t* u8_out, float* rgb_out, float* gray_out, void* stream);
+
 /* keyframe scheduler = OnlineSLAM.regress_two_views (vista_slam/slam.py:153-189) for ALL k candidate
  * edges (i, j_e) of a new keyframe i (the neighbour loop slam.py:263-265 and the loop-closure loop :273-277) in one
  * batched launch sequence instead of k sequential B=1 calls, with the reference's early reject kept:

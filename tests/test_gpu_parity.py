@@ -216,6 +216,73 @@ def test_two_slice_concurrency_matches_single_stream(G):
             m.set_concurrency(1)
 
 
+def _pre_goldens():
+    import glob
+    import os
+    return sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "pre_*.npz")))
+
+
+@pytest.mark.parametrize("path", _pre_goldens(), ids=[p.split("pre_")[-1][:-4] for p in _pre_goldens()])
+def test_input_step_f3_bit_exact_to_pillow_goldens(G, path):
+    """f3: fused crop -> LANCZOS -> crop -> ImgNorm / ImgGray kernels == real Pillow + reference cropping goldens,
+    bit for bit (uint8 image and both float tensors)."""
+    import numpy as np
+    import torch
+    from vista_slam_amd import weights as W
+    from vista_slam_amd.preprocess import process_image
+    g = np.load(path)
+    Hs, Ws = (int(v) for v in g["src_hw"])
+    ow, oh = (int(v) for v in g["target_wh"])
+    src = W.synth_frames_u8(Hs, Ws, seed=43, tag=int(g["tag"]))
+    m = G.model("tiny", 1.0, "f16x3")
+    out = process_image(m, src, (ow, oh), img_name="/some/dir/frame.png")
+    torch.cuda.synchronize()
+    assert out["img_name"] == "frame.png"
+    assert np.array_equal(out["u8"].cpu().numpy(), g["u8"])
+    assert np.array_equal(out["rgb"].cpu().numpy()[:, ::5, ::5], g["rgb_s"])
+    assert np.array_equal(out["gray"].cpu().numpy()[:, ::5, ::5], g["gray_s"])
+    assert abs(float(out["rgb"].double().sum()) - float(g["rgb_sum"])) < 1e-6 * out["rgb"].numel()
+
+
+def test_input_step_f3_vs_oracle_random_geometries_and_encoder_handoff(G):
+    """Random source sizes / edges / targets against the oracle (bit-exact), the cached-table switch between
+    geometries, error cases, and the hand-off: encode_u8hwc(u8) == _encode_image(rgb)."""
+    import numpy as np
+    import torch
+    from helpers import rel_l2
+    from oracle import preprocess_oracle as P
+    from vista_slam_amd import weights as W
+    from vista_slam_amd.preprocess import process_image
+    m = G.model("tiny", 1.0, "f16x3")
+    rng = np.random.default_rng(7)
+    for it in range(8):
+        Hs = int(rng.integers(120, 700)); Ws = int(Hs * rng.uniform(1.15, 2.2))
+        ow = 16 * int(rng.integers(4, 20)); oh = 16 * int(rng.integers(3, 1 + ow // 16))
+        if 0.9 < (Hs - 8) / (Ws - 8) < 1.1 and ow != oh:
+            continue
+        we, he = int(rng.integers(0, 12)), int(rng.integers(0, 12))
+        src = W.synth_frames_u8(Hs, Ws, seed=43, tag=50 + it)
+        want = P.process_image(src, ow, oh, we, he)
+        for _ in range(2):                                   # second call takes the cached-table path
+            out = process_image(m, src, (ow, oh), we, he)
+        torch.cuda.synchronize()
+        assert np.array_equal(out["u8"].cpu().numpy(), want["u8"]), (Hs, Ws, ow, oh, we, he)
+        assert np.array_equal(out["rgb"].cpu().numpy(), want["rgb"])
+        assert np.array_equal(out["gray"].cpu().numpy(), want["gray"])
+    src = W.synth_frames_u8(120, 160, seed=43, tag=70)
+    out = process_image(m, src, (64, 48))
+    fa, _ = m.encode_u8hwc(out["u8"][None])
+    fb, _ = m._encode_image(out["rgb"][None], None, normalize=False)
+    torch.cuda.synchronize()
+    assert rel_l2(fa.cpu().numpy(), fb.cpu().numpy()) < 2e-6
+    with pytest.raises(RuntimeError, match="portrait"):
+        process_image(m, W.synth_frames_u8(300, 200, seed=43, tag=71), (64, 48))
+    with pytest.raises(RuntimeError, match="square frame"):
+        process_image(m, W.synth_frames_u8(200, 200, seed=43, tag=72), (64, 48))
+    with pytest.raises(RuntimeError, match="landscape or square"):
+        process_image(m, src, (48, 64))
+
+
 def _sequential_regress(m, feats, pos, i, j, thres, H, Wd):
     """The reference call pattern of regress_two_views (slam.py:153-189) through the drop-in shim, one edge, B=1."""
     import torch

@@ -554,3 +554,66 @@ __global__ __launch_bounds__(256) void gather_chunks_kernel(GatherChunks g) {
     const int64_t n = g.n16[blockIdx.y];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = s[i];
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// f3 input step: crop -> LANCZOS rescale -> centre crop -> ImgNorm / ImgGray, fused
+// (base_view_graph_dataset.py:171-225, cropping.py:54-81, slam_images_only.py:19-33).  The rescale reproduces Pillow's
+// 8-bit resampler bit for bit: separable, horizontal pass into a uint8 intermediate, 22-bit fixed-point coefficients
+// (tables built on the host in double exactly like Resample.c precompute_coeffs), int32 accumulation from 2^21,
+// arithmetic shift, clamp.  Only the rows / columns the final crop keeps are computed.  HBM-bound, tiny.
+struct PreParams {
+    const uint8_t* src; int Ws;            // source frame [Hs,Ws,3]
+    int l, t;                              // first crop origin in the source
+    int ow, oh;                            // final size
+    const int* bh; const int* kh; int ksh; // horizontal bounds [ow][2] / coeffs [ow][ksh] (columns l2 .. l2+ow of the rescaled image)
+    const int* bv; const int* kv; int ksv; // vertical   bounds [oh][2] / coeffs [oh][ksv] (rows t2 .. t2+oh), ymin relative to y_first
+    int y_first, y_rows;                   // rows of the cropped source the vertical pass reads
+    uint8_t* tmp;                          // [y_rows][ow][4]
+    uint8_t* out_u8; float* out_rgb; float* out_gray;
+};
+__device__ __forceinline__ int pre_clip8(int acc) { acc >>= 22; return acc < 0 ? 0 : (acc > 255 ? 255 : acc); }
+
+__global__ __launch_bounds__(256) void pre_horizontal_kernel(PreParams p) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, yr = blockIdx.y;
+    if (x >= p.ow) return;
+    const int x0 = p.bh[2 * x], n = p.bh[2 * x + 1];
+    const int* k = p.kh + (size_t)x * p.ksh;
+    const uint8_t* row = p.src + ((size_t)(p.t + p.y_first + yr) * p.Ws + p.l + x0) * 3;
+    int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+    for (int i = 0; i < n; ++i) {
+        const int w = k[i];
+        a0 += row[3 * i] * w; a1 += row[3 * i + 1] * w; a2 += row[3 * i + 2] * w;
+    }
+    uchar4 o; o.x = (uint8_t)pre_clip8(a0); o.y = (uint8_t)pre_clip8(a1); o.z = (uint8_t)pre_clip8(a2); o.w = 0;
+    reinterpret_cast<uchar4*>(p.tmp)[(size_t)yr * p.ow + x] = o;
+}
+
+__global__ __launch_bounds__(256) void pre_vertical_kernel(PreParams p) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= p.ow) return;
+    const int y0 = p.bv[2 * y], n = p.bv[2 * y + 1];
+    const int* k = p.kv + (size_t)y * p.ksv;
+    const uchar4* col = reinterpret_cast<const uchar4*>(p.tmp) + (size_t)y0 * p.ow + x;
+    int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+    for (int i = 0; i < n; ++i) {
+        const int w = k[i];
+        const uchar4 v = col[(size_t)i * p.ow];
+        a0 += v.x * w; a1 += v.y * w; a2 += v.z * w;
+    }
+    const int r = pre_clip8(a0), g = pre_clip8(a1), b = pre_clip8(a2);
+    const size_t pix = (size_t)y * p.ow + x, hw = (size_t)p.oh * p.ow;
+    if (p.out_u8) { p.out_u8[pix * 3] = (uint8_t)r; p.out_u8[pix * 3 + 1] = (uint8_t)g; p.out_u8[pix * 3 + 2] = (uint8_t)b; }
+    // ToTensor: x/255 ; Normalize(0.5,0.5): (v-0.5)/0.5 ; Grayscale: 0.2989 R + 0.587 G + 0.114 B  (fp32, no contraction)
+    {
+#pragma clang fp contract(off)      // torch evaluates mul and add as separate fp32 ops: no FMA here
+        const float fr = (float)r / 255.0f, fg = (float)g / 255.0f, fb = (float)b / 255.0f;
+        if (p.out_rgb) {
+            p.out_rgb[pix] = (fr - 0.5f) / 0.5f; p.out_rgb[hw + pix] = (fg - 0.5f) / 0.5f; p.out_rgb[2 * hw + pix] = (fb - 0.5f) / 0.5f;
+        }
+        if (p.out_gray) {
+            const float m0 = 0.2989f * fr, m1 = 0.587f * fg, m2 = 0.114f * fb;
+            const float s01 = m0 + m1;
+            p.out_gray[pix] = s01 + m2;
+        }
+    }
+}

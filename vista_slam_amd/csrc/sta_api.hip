@@ -83,6 +83,8 @@ struct sta_handle {
     bool ktime = false; std::vector<hipEvent_t> kev; int kn = 0; std::vector<double> kflops, kbytes; std::vector<int> kvar;
     // optional two-slice concurrency (sta_set_concurrency)
     int n_streams = 1; hipStream_t aux[2] = {nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    // f3 input-step tables (one cached geometry)
+    int pre_key[6] = {0, 0, 0, 0, 0, 0}; int* pre_tab = nullptr; int64_t pre_cap = 0; int pre_meta[12] = {0};
     bool dry = false;   // planning pass: run the orchestration without launching to size the workspace
 };
 
@@ -323,6 +325,7 @@ extern "C" int sta_destroy(sta_handle* h) {
     if (h->ws) hipFree(h->ws);
     if (h->rope_tab) hipFree(h->rope_tab);
     if (h->zero_page) hipFree(h->zero_page);
+    if (h->pre_tab) hipFree(h->pre_tab);
     if (h->ev_ok) for (auto& e : h->ev) hipEventDestroy(e);
     for (auto& e : h->kev) hipEventDestroy(e);
     if (h->aux[0]) {
@@ -1046,6 +1049,110 @@ extern "C" int sta_forward_pair_u8hwc(sta_handle* h, const uint8_t* img_a, const
                                       void* stream) {
     REQUIRE((((uintptr_t)img_a | (uintptr_t)img_b) & 15) == 0, "u8 HWC images must be 16-byte aligned");
     return forward_pair_any(h, img_a, img_b, true, B, H, W, pts, conf, pose, pose_conf, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// f3: input step.  Host side = the integer geometry of _crop_resize_if_necessary_image_only
+// (base_view_graph_dataset.py:171-225) and Pillow's coefficient tables (Resample.c precompute_coeffs +
+// normalize_coeffs_8bpc), in double like the original; device side = elementwise.h pre_*_kernel.
+static double pre_lanczos(double x) {
+    auto sinc = [](double v) { if (v == 0.0) return 1.0; v = v * M_PI; return sin(v) / v; };
+    if (-3.0 <= x && x < 3.0) return sinc(x) * sinc(x / 3.0);
+    return 0.0;
+}
+// coefficients for output samples [o0, o0+cnt) of an in_size -> out_size resample; returns ksize
+static int pre_coeffs(int in_size, int out_size, int o0, int cnt, std::vector<int>& bounds, std::vector<int>& kk) {
+    double scale, filterscale;
+    filterscale = scale = (double)((float)in_size - 0.0f) / out_size;
+    if (filterscale < 1.0) filterscale = 1.0;
+    const double support = 3.0 * filterscale;
+    const int ksize = (int)ceil(support) * 2 + 1;
+    bounds.assign((size_t)cnt * 2, 0);
+    kk.assign((size_t)cnt * ksize, 0);
+    std::vector<double> w(ksize);
+    const double ss = 1.0 / filterscale;
+    for (int q = 0; q < cnt; ++q) {
+        const int xx = o0 + q;
+        const double center = 0.0 + (xx + 0.5) * scale;
+        double ww = 0.0;
+        int xmin = (int)(center - support + 0.5); if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5); if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        for (int x = 0; x < xmax; ++x) { w[x] = pre_lanczos((x + xmin - center + 0.5) * ss); ww += w[x]; }
+        for (int x = 0; x < xmax; ++x) {
+            double v = w[x];
+            if (ww != 0.0) v /= ww;
+            kk[(size_t)q * ksize + x] = v < 0 ? (int)(-0.5 + v * (1 << 22)) : (int)(0.5 + v * (1 << 22));
+        }
+        bounds[2 * q] = xmin; bounds[2 * q + 1] = xmax;
+    }
+    return ksize;
+}
+
+extern "C" int sta_preprocess_frame(sta_handle* h, const uint8_t* src, int Hs, int Ws, int out_H, int out_W, int w_edge, int h_edge,
+                                    uint8_t* u8_out, float* rgb_out, float* gray_out, void* stream) {
+    REQUIRE(h && src, "null argument");
+    REQUIRE(u8_out || rgb_out || gray_out, "no output requested");
+    REQUIRE(Hs > 0 && Ws > 0 && out_H > 0 && out_W > 0 && w_edge >= 0 && h_edge >= 0, "bad size");
+    REQUIRE(out_W >= out_H, "resolution must be landscape or square (W >= H), got %dx%d", out_W, out_H);
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int key[6] = {Hs, Ws, out_H, out_W, w_edge, h_edge};
+    if (memcmp(key, h->pre_key, sizeof(key)) != 0) {
+        const int cx = (int)(Ws / 2.0), cy = (int)(Hs / 2.0);
+        const int mx = cx < Ws - cx ? cx : Ws - cx, my = cy < Hs - cy ? cy : Hs - cy;
+        REQUIRE(mx > Ws / 5.0 && my > Hs / 5.0, "Bad principal point");
+        int l = cx - mx, t = cy - my, r = cx + mx, b = cy + my;
+        if (l < w_edge) l = w_edge; if (t < h_edge) t = h_edge;
+        if (r > Ws - w_edge) r = Ws - w_edge; if (b > Hs - h_edge) b = Hs - h_edge;
+        const int cw = r - l, ch = b - t;
+        REQUIRE(cw > 0 && ch > 0, "edge margins leave no image");
+        REQUIRE(!(ch > 1.1 * cw), "portrait frames are not supported (landscape / square only)");
+        REQUIRE(!(0.9 < (double)ch / cw && (double)ch / cw < 1.1 && out_W != out_H),
+                "square frame with a non-square resolution: the reference picks the orientation at random");
+        const double sx = (double)out_W / cw, sy = (double)out_H / ch;
+        const double scale_final = (sx > sy ? sx : sy) + 1e-8;                       // cropping.py:67
+        const int rw = (int)floor(cw * scale_final), rh = (int)floor(ch * scale_final);
+        const int l2 = (int)nearbyint(rw / 2.0 - out_W / 2.0), t2 = (int)nearbyint(rh / 2.0 - out_H / 2.0);   // np.round: half to even
+        REQUIRE(l2 >= 0 && t2 >= 0 && l2 + out_W <= rw && t2 + out_H <= rh, "internal: final crop outside the rescaled image");
+        std::vector<int> bh, kh, bv, kv;
+        const int ksh = pre_coeffs(cw, rw, l2, out_W, bh, kh);
+        const int ksv = pre_coeffs(ch, rh, t2, out_H, bv, kv);
+        const int y_first = bv[0], y_last = bv[2 * (out_H - 1)] + bv[2 * (out_H - 1) + 1];
+        for (int y = 0; y < out_H; ++y) bv[2 * y] -= y_first;
+        const int64_t total = (int64_t)bh.size() + kh.size() + bv.size() + kv.size();
+        HIPCHK(hipStreamSynchronize(st));                       // earlier frames may still read the old tables
+        if (total > h->pre_cap) {
+            if (h->pre_tab) HIPCHK(hipFree(h->pre_tab));
+            h->pre_tab = nullptr; h->pre_cap = 0;
+            HIPCHK(hipMalloc((void**)&h->pre_tab, (size_t)total * 4));
+            h->pre_cap = total;
+        }
+        std::vector<int> all; all.reserve(total);
+        all.insert(all.end(), bh.begin(), bh.end()); all.insert(all.end(), kh.begin(), kh.end());
+        all.insert(all.end(), bv.begin(), bv.end()); all.insert(all.end(), kv.begin(), kv.end());
+        HIPCHK(hipMemcpy(h->pre_tab, all.data(), (size_t)total * 4, hipMemcpyHostToDevice));
+        const int meta[12] = {l, t, ksh, ksv, y_first, y_last - y_first, (int)bh.size(), (int)kh.size(), (int)bv.size(), (int)kv.size(), 0, 0};
+        memcpy(h->pre_meta, meta, sizeof(meta));
+        memcpy(h->pre_key, key, sizeof(key));
+    }
+    const int* m = h->pre_meta;
+    return plan_and_run(h, [&](Bump& ws) -> int {
+        uint8_t* tmp = (uint8_t*)ws.take((int64_t)m[5] * out_W * 4);
+        if (h->dry) return 0;
+        REQUIRE(!ws.overflow, "internal: workspace overflow");
+        PreParams p;
+        p.src = src; p.Ws = Ws; p.l = m[0]; p.t = m[1]; p.ow = out_W; p.oh = out_H;
+        p.bh = h->pre_tab; p.kh = p.bh + m[6]; p.ksh = m[2];
+        p.bv = p.kh + m[7]; p.kv = p.bv + m[8]; p.ksv = m[3];
+        p.y_first = m[4]; p.y_rows = m[5]; p.tmp = tmp;
+        p.out_u8 = u8_out; p.out_rgb = rgb_out; p.out_gray = gray_out;
+        const int gx = (out_W + 255) / 256;
+        hipLaunchKernelGGL(pre_horizontal_kernel, dim3(gx, p.y_rows), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(pre_vertical_kernel, dim3(gx, out_H), dim3(256), 0, st, p);
+        HIPCHK(hipGetLastError());
+        return 0;
+    });
 }
 
 extern "C" int sta_estimate_intrinsics(sta_handle* h, const float* pts, const float* conf, int B, int H, int W, int shared,

@@ -245,6 +245,22 @@ def synth_images_u8(n: int, H: int, W: int, seed: int = 43, tag: int = 0) -> np.
     return np.ascontiguousarray(u8.reshape(n, 3, H, W).transpose(0, 2, 3, 1))
 
 
+def synth_frames_u8(H: int, W: int, seed: int = 43, tag: int = 0) -> np.ndarray:
+    """A camera-like uint8 HWC frame [H,W,3] for the input-step tests (f3): integer-only arithmetic (triangle waves of
+    several periods + sharp edges + hash noise), so the bytes are identical on every platform."""
+    y, x = np.meshgrid(np.arange(H, dtype=np.int64), np.arange(W, dtype=np.int64), indexing="ij")
+
+    def tri(v, p):
+        return np.abs(v % (2 * p) - p) * 255 // p
+    noise = synth_images_u8(1, H, W, seed, tag=1000 + tag)[0].astype(np.int64)
+    out = np.empty((H, W, 3), np.int64)
+    for c in range(3):
+        wave = tri(x * (c + 2) + y, 191) * 2 + tri(y * (3 - c) + x // 2, 113)
+        edge = (((x // 37) + (y // 29) + c) % 2) * 255                     # checkerboard: ringing-prone edges
+        out[..., c] = (wave + edge + noise[..., c]) // 5
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
 def smooth_images(n: int, H: int, W: int, seed: int = 43, tag: int = 0) -> np.ndarray:
     """Low-frequency synthetic images (sums of a few sinusoids) - a second, structured input
     distribution for parity tests (white noise excites every patch identically)."""
