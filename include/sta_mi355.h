@@ -165,6 +165,20 @@ int sta_estimate_scale(sta_handle* h, const float* Di, const float* Dj, const fl
 int sta_preprocess_frame(sta_handle* h, const uint8_t* src, int Hs, int Ws, int out_H, int out_W, int w_edge, int h_edge,
                          uint8_t* u8_out, float* rgb_out, float* gray_out, void* stream);
 
+/* output step of OnlineSLAM.save_data_all (vista_slam/slam.py:338-421).
+ * sta_world_pointcloud <- slam.py:396-408: local = K^-1 [x,y,1] * depth * scale (compute_local_pointclouds,
+ * vista_slam/utils/slam_utils.py:82-121), world = pose * [local,1], keep conf > conf_thres, colour = (img+1)/2;
+ * order = torch boolean-mask order (view-major, row-major).  Inputs (device): depths [N,H,W], scales [N], K [N,3,3],
+ * poses [N,4,4], confs [N,H,W], imgs [N,3,H,W] in [-1,1] (slam.imgs; may be NULL -> colour 0).  Outputs (device, any may
+ * be NULL, each sized for N*H*W points): pts_out [M,3] fp32, col_out [M,3] fp32, ply_records_out [M,27] bytes = the
+ * binary_little_endian vertex records (double x,y,z + uchar r,g,b) Open3D writes for pointcloud.ply.
+ * *count_host = M on return (the call synchronises `stream`).
+ * sta_mat_to_se3 <- pp.mat2SE3(pose) (slam.py:166): [B,4,4] -> [B,7] (tx,ty,tz,qx,qy,qz,qw), qw >= 0. */
+int sta_world_pointcloud(sta_handle* h, const float* depths, const float* scales, const float* K, const float* poses,
+                         const float* confs, const float* imgs, int N, int H, int W, float conf_thres,
+                         float* pts_out, float* col_out, uint8_t* ply_records_out, int64_t* count_host, void* stream);
+int sta_mat_to_se3(sta_handle* h, const float* poses, int B, float* se3_out, void* stream);
+
 /* keyframe scheduler = OnlineSLAM.regress_two_views (vista_slam/slam.py:153-189) for ALL k candidate
  * edges (i, j_e) of a new keyframe i (the neighbour loop slam.py:263-265 and the loop-closure loop :273-277) in one
  * batched launch sequence instead of k sequential B=1 calls, with the reference's early reject kept:

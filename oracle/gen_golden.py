@@ -206,6 +206,57 @@ def gen_post():
     print("[golden] post done", res["K_shared"].tolist(), float(res["scale"]), flush=True)
 
 
+def gen_fmt():
+    """Output step: the world point cloud of save_data_all (slam.py:396-408) from the reference's own
+    compute_local_pointclouds (slam_utils.py:82-121) + the bmm / mask code path restated verbatim in torch."""
+    import types
+    if "colorama" not in sys.modules:
+        col = types.ModuleType("colorama")
+        class _Any:
+            def __getattr__(self, _name):
+                return ""
+        col.Fore = _Any(); col.Style = _Any()
+        sys.modules["colorama"] = col
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_slam_utils", "/root/reference/vista_slam/utils/slam_utils.py")
+    su = importlib.util.module_from_spec(spec); spec.loader.exec_module(su)
+    g = torch.Generator().manual_seed(91)
+    N, H, W_ = 3, 24, 32
+    depths = 0.5 + 2.0 * torch.rand(N, H, W_, generator=g)
+    scales = 0.7 + 0.6 * torch.rand(N, 1, generator=g)
+    confs = 1.0 + 3.0 * torch.rand(N, H, W_, generator=g)
+    thres = 2.4
+    intr = torch.zeros(N, 3, 3)
+    for n in range(N):
+        intr[n] = torch.tensor([[30.0 + 3 * n, 0, W_ / 2.0], [0, 28.0 + 2 * n, H / 2.0], [0, 0, 1.0]])
+    q = torch.randn(N, 4, generator=g); q = q / q.norm(dim=1, keepdim=True)
+    x, y, z, w = q.unbind(1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                     2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                     2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1).view(N, 3, 3)
+    poses = torch.eye(4).repeat(N, 1, 1)
+    poses[:, :3, :3] = R
+    poses[:, :3, 3] = torch.randn(N, 3, generator=g)
+    imgs = torch.rand(N, 3, H, W_, generator=g) * 2 - 1                      # slam.imgs: normalised CHW frames
+    # ---- slam.py:368-408 ----
+    masks = confs > thres
+    images = imgs.float().permute(0, 2, 3, 1)
+    images = (images + 1.0) / 2.0
+    scaled_depths = depths * scales.unsqueeze(-1)
+    local_points = su.compute_local_pointclouds(scaled_depths, intr)
+    local_points_flat = local_points.view(N, -1, 3)
+    ones = torch.ones(N, local_points_flat.shape[1], 1)
+    points_hom = torch.cat([local_points_flat, ones], dim=-1)
+    world_points_hom = torch.bmm(points_hom.float(), poses.transpose(1, 2).float())
+    world_points = world_points_hom[..., :3].view(N, H, W_, 3)
+    points = world_points[masks].numpy()
+    colors = images[masks].numpy()
+    np.savez_compressed(os.path.join(OUT, "fmt.npz"), depths=depths.numpy(), scales=scales.numpy(), confs=confs.numpy(),
+                        thres=np.array(thres), intrinsics=intr.numpy(), poses=poses.numpy(), imgs=imgs.numpy(),
+                        points=points, colors=colors, quat_xyzw=q.numpy())
+    print("[golden] fmt done", points.shape, flush=True)
+
+
 CASES = {
     "sharpfull": [dict(name="full_224_b1_sharp", cfg=W.FULL, H=224, W_=224, B=1, sub=8, qk_gain=3.0)],
     "tiny": [
@@ -235,6 +286,8 @@ if __name__ == "__main__":
             gen_ops()
         elif s == "post":
             gen_post()
+        elif s == "fmt":
+            gen_fmt()
         else:
             for c in CASES[s]:
                 run_case(**c)

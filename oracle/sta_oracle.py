@@ -307,3 +307,39 @@ def estimate_scale_with_depth_and_confidence(Di, Dj, ci, cj):
     Di, Dj, ci, cj = (np.asarray(t, np.float32).reshape(-1) for t in (Di, Dj, ci, cj))
     w = np.maximum(ci * cj, np.float32(1e-6))
     return np.float32((w * Di * Dj).sum(dtype=np.float64) / (w * Di * Di).sum(dtype=np.float64))
+
+
+def world_pointcloud(depths, scales, intrinsics, poses, confs, imgs, thres):
+    """slam.py:396-408 + compute_local_pointclouds (slam_utils.py:82-121), numpy fp32: -> (points [M,3], colors [M,3])
+    in boolean-mask (view-major, row-major) order."""
+    N, H, W = depths.shape
+    y, x = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    pix = np.stack([x, y, np.ones_like(x)], -1).reshape(-1, 3)                       # (H*W, 3)
+    Kinv = np.linalg.inv(intrinsics.astype(np.float32)).astype(np.float32)
+    cam = np.einsum("nij,pj->npi", Kinv, pix).astype(np.float32)                     # [N, H*W, 3]
+    local = cam * (depths * scales.reshape(N, 1, 1)).reshape(N, -1, 1).astype(np.float32)
+    hom = np.concatenate([local, np.ones((N, H * W, 1), np.float32)], -1)
+    world = np.einsum("npj,nij->npi", hom, poses.astype(np.float32))[..., :3].reshape(N, H, W, 3)
+    mask = confs > thres
+    images = (imgs.transpose(0, 2, 3, 1).astype(np.float32) + np.float32(1.0)) / np.float32(2.0)
+    return world[mask].astype(np.float32), images[mask]
+
+
+def mat_to_se3(pose):
+    """pp.mat2SE3 (slam.py:166) by definition: (tx,ty,tz,qx,qy,qz,qw), qw >= 0 (Shepperd's method, float64)."""
+    pose = np.asarray(pose, np.float64).reshape(-1, 4, 4)
+    out = np.zeros((pose.shape[0], 7))
+    for b, P in enumerate(pose):
+        m = P[:3, :3]
+        tr = np.trace(m)
+        if tr > 0:
+            s = np.sqrt(tr + 1.0) * 2; q = [(m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s, 0.25 * s]
+        elif m[0, 0] > m[1, 1] and m[0, 0] > m[2, 2]:
+            s = np.sqrt(1.0 + m[0, 0] - m[1, 1] - m[2, 2]) * 2; q = [0.25 * s, (m[0, 1] + m[1, 0]) / s, (m[0, 2] + m[2, 0]) / s, (m[2, 1] - m[1, 2]) / s]
+        elif m[1, 1] > m[2, 2]:
+            s = np.sqrt(1.0 + m[1, 1] - m[0, 0] - m[2, 2]) * 2; q = [(m[0, 1] + m[1, 0]) / s, 0.25 * s, (m[1, 2] + m[2, 1]) / s, (m[0, 2] - m[2, 0]) / s]
+        else:
+            s = np.sqrt(1.0 + m[2, 2] - m[0, 0] - m[1, 1]) * 2; q = [(m[0, 2] + m[2, 0]) / s, (m[1, 2] + m[2, 1]) / s, 0.25 * s, (m[1, 0] - m[0, 1]) / s]
+        q = np.array(q); q = q / np.linalg.norm(q) * (1.0 if q[3] >= 0 else -1.0)
+        out[b, :3] = P[:3, 3]; out[b, 3:] = q
+    return out

@@ -283,6 +283,50 @@ def test_input_step_f3_vs_oracle_random_geometries_and_encoder_handoff(G):
         process_image(m, src, (48, 64))
 
 
+def test_output_step_f4_pointcloud_and_files(G, tmp_path):
+    """f4: world point cloud vs the reference golden (compute_local_pointclouds + bmm + mask order), PLY records,
+    the save_data_all file set re-read the way eval_recon.load_data does, and mat -> SE3."""
+    import numpy as np
+    import torch
+    from helpers import load_golden, max_rel
+    from vista_slam_amd import formats as F
+    m = G.model("tiny", 1.0, "f16x3")
+    g = load_golden("fmt")[0]
+    pts, col, rec = F.world_pointcloud(m, g["depths"], g["scales"], g["intrinsics"], g["poses"], g["confs"], g["imgs"],
+                                       float(g["thres"]), want_records=True)
+    assert pts.shape == g["points"].shape and len(rec) == len(g["points"])
+    assert max_rel(pts.cpu().numpy(), g["points"]) < 1e-5
+    assert np.abs(col.cpu().numpy() - g["colors"]).max() < 1e-6
+    assert np.array_equal(rec["x"], pts[:, 0].cpu().numpy().astype(np.float64))
+    assert np.array_equal(rec["blue"], np.rint(np.clip(col[:, 2].cpu().numpy(), 0, 1) * 255).astype(np.uint8))
+    out = str(tmp_path / "run")
+    vg = {0: [1], 1: [0, 2], 2: [1]}
+    F.save_data_all(m, out, poses=g["poses"], scales=g["scales"], depths=g["depths"], confs=g["confs"],
+                    intrinsics=g["intrinsics"], imgs=g["imgs"], conf_thres=float(g["thres"]), view_graph=vg,
+                    loop_min_dist=40, view_names=["a.png", "b.png", "c.png"], gt_poses=[np.eye(4)] * 3)
+    z = np.load(out + "/view_graph.npz", allow_pickle=True)                     # eval_recon.py:13-16
+    assert z["view_graph"].item() == vg and z["loop_min_dist"].item() == 40 and z["view_names"].tolist() == ["a.png", "b.png", "c.png"]
+    assert np.array_equal(np.load(out + "/trajectory.npy"), g["poses"]) and np.load(out + "/scales.npy")[..., None].shape == (3, 1, 1)
+    assert np.array_equal(np.load(out + "/depths.npy"), g["depths"]) and np.load(out + "/intrinsics.npy").shape == (3, 3, 3)
+    c = np.load(out + "/confs.npz")
+    assert np.array_equal(c["confs"], g["confs"]) and abs(c["thres"].item() - float(g["thres"])) < 1e-12
+    im = np.load(out + "/images.npy")
+    assert im.shape == (3, 24, 32, 3) and 0.0 <= im.min() and im.max() <= 1.0
+    assert np.load(out + "/gt_poses.npy").dtype == np.float32
+    back = F.read_ply(out + "/pointcloud.ply")
+    assert np.array_equal(back, rec)
+    # mat -> SE3: translation copied, unit quaternion reproducing R, qw >= 0
+    se3 = F.mat_to_se3(m, g["poses"]).cpu().numpy()
+    assert np.array_equal(se3[:, :3], g["poses"][:, :3, 3])
+    x, y, zq, w = se3[:, 3], se3[:, 4], se3[:, 5], se3[:, 6]
+    R = np.stack([1 - 2 * (y * y + zq * zq), 2 * (x * y - zq * w), 2 * (x * zq + y * w),
+                  2 * (x * y + zq * w), 1 - 2 * (x * x + zq * zq), 2 * (y * zq - x * w),
+                  2 * (x * zq - y * w), 2 * (y * zq + x * w), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+    assert np.abs(R - g["poses"][:, :3, :3]).max() < 2e-6 and (w >= 0).all()
+    q = g["quat_xyzw"] * np.sign(g["quat_xyzw"][:, 3:4])
+    assert np.abs(se3[:, 3:] - q).max() < 2e-6
+
+
 def _sequential_regress(m, feats, pos, i, j, thres, H, Wd):
     """The reference call pattern of regress_two_views (slam.py:153-189) through the drop-in shim, one edge, B=1."""
     import torch

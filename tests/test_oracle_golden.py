@@ -88,3 +88,16 @@ def test_post_sta_reductions_vs_reference_golden():
     assert max_rel(O.estimate_intrinsic_from_pts3d(g["pts"], g["conf"], False), g["K_per"]) < 2e-6
     s = O.estimate_scale_with_depth_and_confidence(g["pts"][0, ..., 2], g["pts"][1, ..., 2], g["conf"][0], g["conf"][1])
     assert abs(float(s) - float(g["scale"])) < 2e-6 * abs(float(g["scale"]))
+
+
+def test_oracle_world_pointcloud_and_se3_vs_reference_golden():
+    """f4: oracle restatement of slam.py:396-408 vs the golden made with the reference's compute_local_pointclouds."""
+    from helpers import load_golden, max_rel
+    from oracle import sta_oracle as O
+    g = load_golden("fmt")[0]
+    pts, col = O.world_pointcloud(g["depths"], g["scales"], g["intrinsics"], g["poses"], g["confs"], g["imgs"], float(g["thres"]))
+    assert pts.shape == g["points"].shape
+    assert max_rel(pts, g["points"]) < 1e-5 and np.abs(col - g["colors"]).max() < 1e-6
+    se3 = O.mat_to_se3(g["poses"])
+    q = g["quat_xyzw"] * np.sign(g["quat_xyzw"][:, 3:4])
+    assert np.abs(se3[:, 3:] - q).max() < 2e-6 and np.array_equal(se3[:, :3].astype(np.float32), g["poses"][:, :3, 3])

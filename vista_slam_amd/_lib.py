@@ -47,6 +47,8 @@ SIGNATURES = {
     "sta_estimate_intrinsics": (_i, [_vp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _vp]),
     "sta_estimate_scale": (_i, [_vp, _fp, _fp, _fp, _fp, _i64, _fp, _vp]),
     "sta_preprocess_frame": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _vp]),
+    "sta_world_pointcloud": (_i, [_vp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _f, _fp, _fp, _fp, C.POINTER(_i64), _vp]),
+    "sta_mat_to_se3": (_i, [_vp, _fp, _i, _fp, _vp]),
     "sta_regress_views": (_i, [_vp, _fp, C.POINTER(_vp), _i, C.c_char_p, _f, _i, _i, _fp, C.POINTER(C.c_float),
                                C.POINTER(_i), C.POINTER(_i), _fp, _fp, _fp, _fp, _vp]),
     "sta_rope2d_inplace": (_i, [_fp, _i64, _i64, _vp, _i, _i, _i, _i, _f, _f, _vp]),

@@ -617,3 +617,102 @@ __global__ __launch_bounds__(256) void pre_vertical_kernel(PreParams p) {
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// f4 output step: the world point cloud of OnlineSLAM.save_data_all (slam.py:396-408):
+//   local = K^-1 [x,y,1]^T * (depth * scale)   (compute_local_pointclouds, slam_utils.py:82-121)
+//   world = pose [local,1]^T ; keep conf > thres ; colour = (img + 1) / 2.
+// Stable stream compaction in view-major / row-major order (= torch boolean-mask order): per-block counts ->
+// single-block exclusive scan -> emit.  Emits fp32 points / colours and/or packed little-endian PLY vertex records
+// (3 x float64 + 3 x uint8 = 27 bytes, Open3D's binary layout for a coloured cloud).
+struct CloudParams {
+    const float* depth; const float* scale; const float* K; const float* pose; const float* conf; const float* img;
+    int N, H, W; float thres;
+    int* counts; int64_t* offs; int nblk;          // offs[nblk] = total
+    float* pts; float* col; uint8_t* rec;
+};
+__global__ __launch_bounds__(256) void cloud_count_kernel(CloudParams p) {
+    const int64_t total = (int64_t)p.N * p.H * p.W, i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool keep = i < total && p.conf[i] > p.thres;
+    const unsigned long long b = __ballot(keep);
+    __shared__ int wc[4];
+    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) p.counts[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+__global__ __launch_bounds__(1024) void cloud_scan_kernel(CloudParams p) {
+    __shared__ int64_t part[1024];
+    const int per = (p.nblk + 1023) / 1024, lo = threadIdx.x * per, hi = min(lo + per, p.nblk);
+    int64_t s = 0;
+    for (int i = lo; i < hi; ++i) s += p.counts[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { int64_t run = 0; for (int i = 0; i < 1024; ++i) { const int64_t v = part[i]; part[i] = run; run += v; } p.offs[p.nblk] = run; }
+    __syncthreads();
+    int64_t run = part[threadIdx.x];
+    for (int i = lo; i < hi; ++i) { p.offs[i] = run; run += p.counts[i]; }
+}
+__global__ __launch_bounds__(256) void cloud_emit_kernel(CloudParams p) {
+    const int64_t hw = (int64_t)p.H * p.W, total = p.N * hw, i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool keep = i < total && p.conf[i] > p.thres;
+    const unsigned long long b = __ballot(keep);
+    __shared__ int wc[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wc[wave] = __popcll(b);
+    __syncthreads();
+    if (!keep) return;
+    int rank = __popcll(b & ((1ull << lane) - 1));
+    for (int w = 0; w < wave; ++w) rank += wc[w];
+    const int64_t o = p.offs[blockIdx.x] + rank;
+    const int n = (int)(i / hw), pix = (int)(i - n * hw), y = pix / p.W, x = pix - y * p.W;
+    const float* K = p.K + n * 9;
+    // 3x3 inverse by the adjugate (torch.inverse uses LU: same value to fp32 rounding)
+    const float a = K[0], bb = K[1], c = K[2], d = K[3], e = K[4], f = K[5], g = K[6], h = K[7], k = K[8];
+    const float A = e * k - f * h, B = -(d * k - f * g), C = d * h - e * g;
+    const float idet = 1.0f / (a * A + bb * B + c * C);
+    const float i00 = A * idet, i01 = -(bb * k - c * h) * idet, i02 = (bb * f - c * e) * idet;
+    const float i10 = B * idet, i11 = (a * k - c * g) * idet, i12 = -(a * f - c * d) * idet;
+    const float i20 = C * idet, i21 = -(a * h - bb * g) * idet, i22 = (a * e - bb * d) * idet;
+    const float z = p.depth[i] * p.scale[n];
+    const float fx = (float)x, fy = (float)y;
+    const float lx = (i00 * fx + i01 * fy + i02) * z, ly = (i10 * fx + i11 * fy + i12) * z, lz = (i20 * fx + i21 * fy + i22) * z;
+    const float* P = p.pose + n * 16;
+    const float wx = P[0] * lx + P[1] * ly + P[2] * lz + P[3];
+    const float wy = P[4] * lx + P[5] * ly + P[6] * lz + P[7];
+    const float wz = P[8] * lx + P[9] * ly + P[10] * lz + P[11];
+    float cr = 0.f, cg = 0.f, cb = 0.f;
+    if (p.img) {
+        const float* im = p.img + (int64_t)n * 3 * hw + pix;
+        cr = (im[0] + 1.0f) / 2.0f; cg = (im[hw] + 1.0f) / 2.0f; cb = (im[2 * hw] + 1.0f) / 2.0f;
+    }
+    if (p.pts) { p.pts[o * 3] = wx; p.pts[o * 3 + 1] = wy; p.pts[o * 3 + 2] = wz; }
+    if (p.col) { p.col[o * 3] = cr; p.col[o * 3 + 1] = cg; p.col[o * 3 + 2] = cb; }
+    if (p.rec) {
+        uint8_t* r = p.rec + o * 27;
+        const double dv[3] = {(double)wx, (double)wy, (double)wz};
+        const uint8_t* src = reinterpret_cast<const uint8_t*>(dv);
+#pragma unroll
+        for (int q = 0; q < 24; ++q) r[q] = src[q];
+        r[24] = (uint8_t)rintf(fminf(fmaxf(cr, 0.f), 1.f) * 255.f);
+        r[25] = (uint8_t)rintf(fminf(fmaxf(cg, 0.f), 1.f) * 255.f);
+        r[26] = (uint8_t)rintf(fminf(fmaxf(cb, 0.f), 1.f) * 255.f);
+    }
+}
+
+// pp.mat2SE3 (slam.py:166): [B,4,4] rigid transforms -> [B,7] = (tx,ty,tz, qx,qy,qz,qw), unit quaternion with the
+// largest-magnitude component computed first (Shepperd) and qw >= 0.
+__global__ void mat_to_se3_kernel(const float* pose, int B, float* out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* P = pose + b * 16;
+    const float m00 = P[0], m01 = P[1], m02 = P[2], m10 = P[4], m11 = P[5], m12 = P[6], m20 = P[8], m21 = P[9], m22 = P[10];
+    float qx, qy, qz, qw;
+    const float tr = m00 + m11 + m22;
+    if (tr > 0.f) { const float s = sqrtf(tr + 1.f) * 2.f; qw = 0.25f * s; qx = (m21 - m12) / s; qy = (m02 - m20) / s; qz = (m10 - m01) / s; }
+    else if (m00 > m11 && m00 > m22) { const float s = sqrtf(1.f + m00 - m11 - m22) * 2.f; qw = (m21 - m12) / s; qx = 0.25f * s; qy = (m01 + m10) / s; qz = (m02 + m20) / s; }
+    else if (m11 > m22) { const float s = sqrtf(1.f + m11 - m00 - m22) * 2.f; qw = (m02 - m20) / s; qx = (m01 + m10) / s; qy = 0.25f * s; qz = (m12 + m21) / s; }
+    else { const float s = sqrtf(1.f + m22 - m00 - m11) * 2.f; qw = (m10 - m01) / s; qx = (m02 + m20) / s; qy = (m12 + m21) / s; qz = 0.25f * s; }
+    const float nrm = rsqrtf(qx * qx + qy * qy + qz * qz + qw * qw) * (qw < 0.f ? -1.f : 1.f);
+    float* o = out + b * 7;
+    o[0] = P[3]; o[1] = P[7]; o[2] = P[11]; o[3] = qx * nrm; o[4] = qy * nrm; o[5] = qz * nrm; o[6] = qw * nrm;
+}

@@ -1155,6 +1155,47 @@ extern "C" int sta_preprocess_frame(sta_handle* h, const uint8_t* src, int Hs, i
     });
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// f4: output step (slam.py:338-421).
+extern "C" int sta_world_pointcloud(sta_handle* h, const float* depths, const float* scales, const float* K, const float* poses,
+                                    const float* confs, const float* imgs, int N, int H, int W, float conf_thres,
+                                    float* pts_out, float* col_out, uint8_t* ply_records_out, int64_t* count_host, void* stream) {
+    REQUIRE(h && depths && scales && K && poses && confs && count_host, "null argument");
+    REQUIRE(N > 0 && H > 0 && W > 0, "bad size");
+    REQUIRE(pts_out || col_out || ply_records_out, "no output requested");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = (int64_t)N * H * W;
+    REQUIRE((total + 255) / 256 < (int64_t)1 << 30, "point cloud too large");
+    const int nblk = (int)((total + 255) / 256);
+    *count_host = 0;
+    return plan_and_run(h, [&](Bump& ws) -> int {
+        int* counts = (int*)ws.take((int64_t)nblk * 4);
+        int64_t* offs = (int64_t*)ws.take((int64_t)(nblk + 1) * 8);
+        if (h->dry) return 0;
+        REQUIRE(!ws.overflow, "internal: workspace overflow");
+        CloudParams p;
+        p.depth = depths; p.scale = scales; p.K = K; p.pose = poses; p.conf = confs; p.img = imgs;
+        p.N = N; p.H = H; p.W = W; p.thres = conf_thres; p.counts = counts; p.offs = offs; p.nblk = nblk;
+        p.pts = pts_out; p.col = col_out; p.rec = ply_records_out;
+        hipLaunchKernelGGL(cloud_count_kernel, dim3(nblk), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(cloud_scan_kernel, dim3(1), dim3(1024), 0, st, p);
+        hipLaunchKernelGGL(cloud_emit_kernel, dim3(nblk), dim3(256), 0, st, p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(count_host, offs + nblk, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return 0;
+    });
+}
+
+extern "C" int sta_mat_to_se3(sta_handle* h, const float* poses, int B, float* se3_out, void* stream) {
+    REQUIRE(h && poses && se3_out && B > 0, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(mat_to_se3_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, poses, B, se3_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int sta_estimate_intrinsics(sta_handle* h, const float* pts, const float* conf, int B, int H, int W, int shared,
                                        float* K_out, float* depth_out, float* conf_mean_out, void* stream) {
     REQUIRE(h && pts && conf && K_out && B > 0 && H > 0 && W > 0, "bad argument");
