@@ -177,6 +177,9 @@ def main():
                  5: f"gemm2_kernel<{sp}, 0, 0, 192, 128, 2, 4, 0>"}
         fam = max(names, key=lambda k: model.kernel_timing_read(k)[1])
         n, ms, fl, by = model.kernel_timing_read(fam)
+        import ctypes as _C
+        ghz = _C.c_float(0.0)
+        model.lib.sta_kernel_clock_read(model._h, _C.byref(ghz))      # in-kernel s_memtime / s_memrealtime probe
         model.kernel_timing(False)
         if n > 0 and ms > 0:
             ach = fl / (ms * 1e-3) / 1e12
@@ -187,6 +190,10 @@ def main():
                     "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
                     "mfma_products_per_flop": 3 if args.precision == "f16x3" else 1,
                     "issued_frac": round(ach * (3 if args.precision == "f16x3" else 1) / PEAK_F16_MFMA_TFLOPS, 4)}
+            if fam == 5 and ghz.value > 0:
+                # DVFS: the chip clocks to its power budget; peak available at the clock the kernel actually ran at
+                roof["effective_clock_ghz"] = round(ghz.value, 3)
+                roof["issued_frac_at_clock"] = round(roof["issued_frac"] * 2.4 / ghz.value, 4)
 
     if rank == 0:
         pairs = B * world * args.steps

@@ -226,12 +226,19 @@ int sta_get_stage_ms(sta_handle* h, float ms[4]);
 int sta_kernel_timing(sta_handle* h, int enable);
 int sta_kernel_timing_read(sta_handle* h, int tile_family, int* launches, double* total_ms, double* total_flops,
                            double* total_algorithmic_bytes);
+/* Effective shader clock (GHz) inside the timed launches of the dominant kernel since sta_kernel_timing(h, 1):
+ * s_memtime cycles per 100 MHz s_memrealtime tick, summed over every 64th workgroup.  The chip clocks to its power
+ * budget, so the MFMA peak actually available to a kernel is 2.5 PF x clock / 2.4 GHz. */
+int sta_kernel_clock_read(sta_handle* h, float* ghz_out);
 
 /* Time `iters` back-to-back launches of the dominant GEMM kernel (M x N x K, this handle's
  * precision, random operands) with hipEvents on `stream`; average ms per launch in *ms_out.
  * tile: 0 = product selection, 1 = 128x128, 2 = 256x256, 3 = 256x128.  ablation (tile 2/3 only,
  * bench-only kernel variants): 0 none, 1 no DMA in the K loop, 2 DMA+barriers only, 3 MFMA only. */
 int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, int tile, int ablation, float* ms_out, void* stream);
+/* Effective shader clock (GHz) observed inside the kernel of the last sta_bench_gemm call (s_memtime cycles per
+ * 100 MHz s_memrealtime tick, sampled on every 64th workgroup): the chip clocks to its power budget (DVFS). */
+float sta_bench_gemm_last_ghz(void);
 
 const char* sta_last_error(void);
 const char* sta_version(void);

@@ -59,7 +59,9 @@ SIGNATURES = {
     "sta_get_stage_ms": (_i, [_vp, C.POINTER(_f)]),
     "sta_kernel_timing": (_i, [_vp, _i]),
     "sta_kernel_timing_read": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "sta_kernel_clock_read": (_i, [_vp, C.POINTER(C.c_float)]),
     "sta_bench_gemm": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(_f), _vp]),
+    "sta_bench_gemm_last_ghz": (C.c_float, []),
     "sta_last_error": (C.c_char_p, []),
     "sta_version": (C.c_char_p, []),
     # ---- debug / kernel-level test entry points

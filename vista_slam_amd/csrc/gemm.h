@@ -51,6 +51,7 @@ struct GemmParams {
     int ct_k, ct_cout, ct_h, ct_w;
     // ---- misc
     const f16* zero_page;                                // >= 64 B of zeros (OOB taps of the direct-to-LDS conv loader)
+    unsigned long long* clk_dbg = nullptr;               // bench only: block 0 stores {shader cycles, 100 MHz ticks} of its lifetime
 };
 
 #define GEMM_BM 128

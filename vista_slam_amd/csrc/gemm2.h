@@ -61,6 +61,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int l31 = lane & 31, lhi = lane >> 5;
+    unsigned long long clk0 = 0, rt0 = 0;
+    if (p.clk_dbg) { clk0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 
     // ---- block id -> (tile, K slice) (XCD-aware, band-major; the slices of one tile are consecutive ids)
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
@@ -256,4 +258,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
 #pragma unroll
         for (int i = 0; i < MT; ++i)
             epilogue_tile<SPLIT, EPI>(p, acc[i][j], m0 + wm * WM + i * 32, n0 + wn * WN + j * 32 + l31, lane, kslice == 0);
+    if (p.clk_dbg && tid == 0 && (blockIdx.x & 63) == 0) {      // effective shader clock = cycles / (ticks / 100 MHz)
+        atomicAdd(p.clk_dbg, __builtin_readcyclecounter() - clk0);
+        atomicAdd(p.clk_dbg + 1, __builtin_amdgcn_s_memrealtime() - rt0);
+    }
 }

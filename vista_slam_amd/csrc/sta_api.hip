@@ -80,6 +80,7 @@ struct sta_handle {
     // timing
     bool timing = false; hipEvent_t ev[5]; bool ev_ok = false;
     // per-launch timing of the dominant kernel (gemm_kernel<*, A_DENSE, EPI_F32>) for the roofline report
+    unsigned long long* clk_buf = nullptr;   // {shader cycles, 100 MHz ticks} summed over sampled workgroups of the timed GEMMs
     bool ktime = false; std::vector<hipEvent_t> kev; int kn = 0; std::vector<double> kflops, kbytes; std::vector<int> kvar;
     // optional two-slice concurrency (sta_set_concurrency)
     int n_streams = 1; hipStream_t aux[2] = {nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
@@ -326,6 +327,7 @@ extern "C" int sta_destroy(sta_handle* h) {
     if (h->rope_tab) hipFree(h->rope_tab);
     if (h->zero_page) hipFree(h->zero_page);
     if (h->pre_tab) hipFree(h->pre_tab);
+    if (h->clk_buf) hipFree(h->clk_buf);
     if (h->ev_ok) for (auto& e : h->ev) hipEventDestroy(e);
     for (auto& e : h->kev) hipEventDestroy(e);
     if (h->aux[0]) {
@@ -493,6 +495,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
     if (h->gemm_variant == 4 && p.N % 128 == 0) variant = 5;
     if (h->gemm_variant == 1) variant = 1;
     if (variant != 6) p.ksplit = 1;
+    if (timed && variant == 5) p.clk_dbg = h->clk_buf;   // effective-clock probe of the dominant kernel (bench only)
     if (variant == 2) {
         if (split) CHK((launch_gemm2<true, AMODE, EPI, 256, 256, 2, 4>(p, st)));
         else CHK((launch_gemm2<false, AMODE, EPI, 256, 256, 2, 4>(p, st)));
@@ -1331,7 +1334,20 @@ extern "C" int sta_estimate_scale(sta_handle* h, const float* Di, const float* D
 
 extern "C" int sta_kernel_timing(sta_handle* h, int enable) {
     REQUIRE(h, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (enable && !h->clk_buf) { HIPCHK(hipMalloc((void**)&h->clk_buf, 16)); }
+    if (h->clk_buf) HIPCHK(hipMemset(h->clk_buf, 0, 16));
     h->ktime = enable != 0; h->kn = 0;
+    return 0;
+}
+extern "C" int sta_kernel_clock_read(sta_handle* h, float* ghz_out) {
+    REQUIRE(h && ghz_out, "null argument");
+    REQUIRE(h->clk_buf, "kernel timing was never enabled");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    unsigned long long hc[2] = {0, 0};
+    HIPCHK(hipMemcpy(hc, h->clk_buf, 16, hipMemcpyDeviceToHost));
+    *ghz_out = hc[1] ? (float)((double)hc[0] / ((double)hc[1] / 100e6) * 1e-9) : 0.f;
     return 0;
 }
 extern "C" int sta_kernel_timing_read(sta_handle* h, int variant, int* launches, double* total_ms, double* total_flops, double* total_bytes) {
@@ -1421,6 +1437,9 @@ static int bench_launch2(bool split, const GemmParams& p, hipStream_t st) {
 }
 
 // tile: 0 = automatic product selection, 1 = 128x128, 2 = 256x256, 3 = 256x128; abl: gemm2 ablation (tile 2/3 only)
+static float g_bench_ghz = 0.f;
+extern "C" float sta_bench_gemm_last_ghz() { return g_bench_ghz; }
+
 extern "C" int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, int tile, int abl, float* ms_out, void* stream) {
     REQUIRE(h && ms_out && iters > 0, "bad argument");
     HIPCHK(hipSetDevice(h->device));
@@ -1434,6 +1453,7 @@ extern "C" int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, int
     Lin Wt; Wt.N = N; Wt.K = K; Wt.w = ws.act(N, K, true);
     Wt.bias = (float*)ws.take((int64_t)N * 4);
     float* C = (float*)ws.take((int64_t)M * N * 4);
+    unsigned long long* clk = (unsigned long long*)ws.take(16);
     REQUIRE(!ws.overflow, "internal: bench workspace overflow");
     // random operands (both hi and lo halves of every row block get full-range random bits: the data
     // dependence of MFMA power is what matters for a throughput number)
@@ -1493,6 +1513,16 @@ extern "C" int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, int
     HIPCHK(hipGetLastError());
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     *ms_out = ms / iters;
+    // effective shader clock during this kernel (DVFS: the chip clocks to its power budget): a few extra launches
+    // with the in-kernel probe on (s_memtime vs the constant 100 MHz s_memrealtime), sampled on every 64th block
+    HIPCHK(hipMemsetAsync(clk, 0, 16, st));
+    p.clk_dbg = clk;
+    for (int i = 0; i < 3; ++i) CHK(once());
+    p.clk_dbg = nullptr;
+    unsigned long long hc[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(hc, clk, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    g_bench_ghz = hc[1] ? (float)((double)hc[0] / ((double)hc[1] / 100e6) * 1e-9) : 0.f;
     hipEventDestroy(e0); hipEventDestroy(e1);
     return 0;
 }

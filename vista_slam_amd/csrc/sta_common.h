@@ -18,6 +18,17 @@ __device__ __forceinline__ void split_f16(float x, f16& hi, f16& lo) {
     x = fminf(fmaxf(x, -STA_F16_MAX), STA_F16_MAX);
     hi = (f16)x;
     lo = (f16)(x - (float)hi);
+#ifdef STA_EMU_LO_MANT
+    // experiment only (never defined in the product build): keep STA_EMU_LO_MANT explicit mantissa bits of the
+    // residual plane, i.e. emulate an fp8-class `lo` to measure what a 2-unit (f16 + MX-fp8 correction) scheme would cost
+    {
+        unsigned u = __float_as_uint(x - (float)hi);
+        const int drop = 23 - STA_EMU_LO_MANT;
+        u += 1u << (drop - 1);
+        u &= ~((1u << drop) - 1u);
+        lo = (f16)__uint_as_float(u);
+    }
+#endif
 }
 __device__ __forceinline__ f16 to_f16_sat(float x) {
     return (f16)fminf(fmaxf(x, -STA_F16_MAX), STA_F16_MAX);
