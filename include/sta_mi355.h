@@ -77,8 +77,8 @@ int sta_destroy(sta_handle* h);
 /* Change the arithmetic policy after creation (weights hold both split planes). */
 int sta_set_precision(sta_handle* h, int precision);
 
-/* Batch-slice concurrency of sta_forward_pair*: 1 = one slice on the caller's stream (default); 2 = the batch is cut
- * in two slices that run on two library-owned streams, forked from / joined to the caller's stream by events, so the
+/* Batch-slice concurrency of sta_forward_pair*: 1 = one slice on the caller's stream (default); n = 2..4: the batch is cut
+ * in n slices that run on n library-owned streams, forked from / joined to the caller's stream by events, so the
  * hardware overlaps one slice's GEMM tail rounds and HBM-bound kernels with the other's MFMA main loops.  Results are
  * identical per pair (no cross-pair arithmetic).  No reference counterpart (torch runs one stream). */
 int sta_set_concurrency(sta_handle* h, int n_slices);

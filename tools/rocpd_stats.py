@@ -14,14 +14,20 @@ def short(name):
 
 
 def main(paths):
+    by_grid = "--by-grid" in paths            # split every kernel by its launch grid (one row per GEMM shape)
+    paths = [p for p in paths if not p.startswith("--")]
     rows = {}
     for p in paths:
         db = sqlite3.connect(p)
         cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
         namecol = "name" if "name" in cols else [c for c in cols if "name" in c][0]
-        for name, start, end in db.execute(f"select {namecol}, start, end from kernels"):
+        gcol = next((c for c in cols if "grid" in c.lower() and c.lower().endswith("x")), None)
+        wcol = next((c for c in cols if "workgroup" in c.lower() and c.lower().endswith("x")), None)
+        sel = f"select {namecol}, start, end" + (f", {gcol}" if by_grid and gcol else ", 0") + (f", {wcol}" if by_grid and wcol else ", 1") + " from kernels"
+        for name, start, end, g, w in db.execute(sel):
             d = (end - start) / 1e3
-            r = rows.setdefault(short(name), [0, 0.0, 1e30, 0.0])
+            key = short(name)[:88] + (f" grid={int(g) // max(int(w), 1)}" if by_grid else "")
+            r = rows.setdefault(key, [0, 0.0, 1e30, 0.0])
             r[0] += 1; r[1] += d; r[2] = min(r[2], d); r[3] = max(r[3], d)
     tot = sum(r[1] for r in rows.values())
     print(f"{'kernel':110s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s}")

@@ -17,6 +17,9 @@
 // Cross attention = same kernel with kv_shift selecting the other view's K/V.
 #pragma once
 #include "sta_common.h"
+#include <type_traits>
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_base);   // gemm2.h
 
 struct AttnParams {
     const f16* Q_hi; const f16* Q_lo; const f16* K_hi; const f16* K_lo; const f16* Vt_hi; const f16* Vt_lo;
@@ -33,7 +36,7 @@ template <bool SPLIT>
 constexpr int attn_smem_bytes() { return 2 * (SPLIT ? 4 : 2) * ATT_TILE_BYTES; }
 
 template <bool SPLIT>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NPL = SPLIT ? 2 : 1;
     constexpr int STAGE = 2 * NPL * ATT_TILE_BYTES;   // K planes then V^T planes
@@ -72,38 +75,30 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         }
     }
 
-    // ---- staging assignment: 2 x 16 B chunks of K and of V^T per plane per tile
-    int st_row[2], st_ch[2];
+    // ---- K / V^T tiles go global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write).
+    // A plane tile = 64 rows x 128 B = 8 slots of 1 KiB (8 rows); wave w moves slots 2w, 2w+1 of every plane tile.
+    // The DMA writes lane-linear (lane l -> row l>>3, chunk l&7 of its slot); the bank swizzle chunk ^ (row>>1)&7
+    // is applied to the SOURCE chunk each lane fetches (same involution the fragment reads apply).
+    int ksrc_l[2], vsrc_l[2];                   // per-lane element offsets inside a K tile / V^T tile
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { int c = tid + 256 * i; st_row[i] = c >> 3; st_ch[i] = c & 7; }
-    uint4 rk_hi[2], rk_lo[2], rv_hi[2], rv_lo[2];
-    auto load_tile = [&](int kv0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            size_t ko = koff + (size_t)(kv0 + st_row[i]) * 64 + st_ch[i] * 8;
-            size_t vo = voff + (size_t)st_row[i] * p.npad + kv0 + st_ch[i] * 8;
-            rk_hi[i] = ldg16(p.K_hi + ko);
-            rv_hi[i] = ldg16(p.Vt_hi + vo);
-            if (SPLIT) { rk_lo[i] = ldg16(p.K_lo + ko); rv_lo[i] = ldg16(p.Vt_lo + vo); }
-        }
-    };
-    auto store_tile = [&](int stage) {
-        char* sK = smem + stage * STAGE;
+    for (int i = 0; i < 2; ++i) {
+        const int row = (2 * wave + i) * 8 + (lane >> 3);
+        const int sch = (lane & 7) ^ ((row >> 1) & 7);
+        ksrc_l[i] = row * 64 + sch * 8;         // K row = key (64 d = 128 B)
+        vsrc_l[i] = row * p.npad + sch * 8;     // V^T row = d, columns = keys
+    }
+    auto issue_tile = [&](int stage, int kv0) {
+        char* sK = smem + stage * STAGE + (2 * wave) * 1024;
         char* sV = sK + NPL * ATT_TILE_BYTES;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            int r = st_row[i], ch = st_ch[i];
-            int ko = r * 128 + ((ch ^ ((r >> 1) & 7)) << 4);
-            *reinterpret_cast<uint4*>(sK + ko) = rk_hi[i];
-            if (SPLIT) *reinterpret_cast<uint4*>(sK + ATT_TILE_BYTES + ko) = rk_lo[i];
-            int sw = (r >> 1) & 15;
-            int v0 = r * 128 + (((2 * ch) ^ sw) << 3);
-            int v1 = r * 128 + (((2 * ch + 1) ^ sw) << 3);
-            *reinterpret_cast<uint2*>(sV + v0) = make_uint2(rv_hi[i].x, rv_hi[i].y);
-            *reinterpret_cast<uint2*>(sV + v1) = make_uint2(rv_hi[i].z, rv_hi[i].w);
+            const size_t ko = koff + (size_t)kv0 * 64 + ksrc_l[i];
+            const size_t vo = voff + (size_t)kv0 + vsrc_l[i];
+            glds16(p.K_hi + ko, sK + i * 1024);
+            glds16(p.Vt_hi + vo, sV + i * 1024);
             if (SPLIT) {
-                *reinterpret_cast<uint2*>(sV + ATT_TILE_BYTES + v0) = make_uint2(rv_lo[i].x, rv_lo[i].y);
-                *reinterpret_cast<uint2*>(sV + ATT_TILE_BYTES + v1) = make_uint2(rv_lo[i].z, rv_lo[i].w);
+                glds16(p.K_lo + ko, sK + ATT_TILE_BYTES + i * 1024);
+                glds16(p.Vt_lo + vo, sV + ATT_TILE_BYTES + i * 1024);
             }
         }
     };
@@ -113,18 +108,24 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;       // running max in scaled (log2) units
+    const bool wave_active = q0 < p.nq;         // decoder: 769 = 6 x 128 + 1 queries -> the last block has one live wave
 
-    const int ntiles = (p.nk + ATT_KV - 1) / ATT_KV;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+    // per-lane fragment byte offset inside a plane tile: row l31 (+32 rows = +4096 B: same swizzle since 16 & 7 == 0),
+    // chunk c = 2*kk + lhi -> (c ^ swz) << 4  (identical for K rows = keys and V^T rows = d)
+    int foff_l[4];
+    {
+        const int swz = (l31 >> 1) & 7;
+#pragma unroll
+        for (int c2 = 0; c2 < 4; ++c2) foff_l[c2] = l31 * 128 + (((c2 * 2 + lhi) ^ swz) << 4);
+    }
 
-    for (int it = 0; it < ntiles; ++it) {
-        const int cur = it & 1;
-        const int kv0 = it * ATT_KV;
-        if (it + 1 < ntiles) load_tile(kv0 + ATT_KV);
-        const char* sK = smem + cur * STAGE;
+    // one KV tile held in LDS stage `stage_c` (compile-time: the stage / t / d displacements fold into the ds_read
+    // offset field); TAIL = last, partly valid tile (keys >= nk masked to -inf)
+    auto tile_body = [&](auto stage_c, auto tail_c, int kv0) {
+        constexpr int STG = decltype(stage_c)::value;
+        constexpr bool TAIL = decltype(tail_c)::value;
+        const char* sK = smem + STG * STAGE;
         const char* sV = sK + NPL * ATT_TILE_BYTES;
 
         // ---- S^T = K Q^T  (rows = keys, cols = queries)
@@ -133,14 +134,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[t][r] = 0.f;
-            const int key = t * 32 + l31;
-            const int ksw = (key >> 1) & 7;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                int off = key * 128 + (((kk * 2 + lhi) ^ ksw) << 4);
-                half8 kf = *reinterpret_cast<const half8*>(sK + off);
+                half8 kf = *reinterpret_cast<const half8*>(sK + t * 4096 + foff_l[kk]);
                 if (SPLIT) {
-                    half8 kl = *reinterpret_cast<const half8*>(sK + ATT_TILE_BYTES + off);
+                    half8 kl = *reinterpret_cast<const half8*>(sK + ATT_TILE_BYTES + t * 4096 + foff_l[kk]);
                     sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qf_hi[kk], sacc[t], 0, 0, 0);
                     sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf_lo[kk], sacc[t], 0, 0, 0);
                 }
@@ -148,31 +146,33 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
             }
         }
 
-        // ---- online softmax (per lane = one query; this lane holds 32 of the tile's 64 keys)
-        const bool tail = kv0 + ATT_KV > p.nk;
+        // ---- online softmax (per lane = one query; this lane holds 32 of the tile's 64 keys:
+        //      register r of sacc[t] <-> key t*32 + (r&3) + 8*(r>>2) + 4*lhi)
+        if (TAIL) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    if (key >= p.nk) sacc[t][r] = -INFINITY;
+                }
+        }
         float mx = -INFINITY;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float sv = sacc[t][r] * p.scale_log2e;
-                if (tail) {
-                    int key = kv0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    if (key >= p.nk) sv = -INFINITY;
-                }
-                sacc[t][r] = sv;
-                mx = fmaxf(mx, sv);
-            }
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[t][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
+        const float m_new = fmaxf(m_run, mx * p.scale_log2e);          // scale > 0: max commutes with it
         // raw v_exp_f32: arguments are <= 0 (or -inf), results in [0,1]; no denormal/overflow handling needed
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        const float neg_m = -m_new;
         float psum = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float pv = __builtin_amdgcn_exp2f(sacc[t][r] - m_new);
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[t][r], p.scale_log2e, neg_m));
                 sacc[t][r] = pv;
                 psum += pv;
             }
@@ -185,44 +185,67 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
                 for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
         }
 
-        // ---- O^T += V^T P^T   (k index of the MFMA = 8*lhi + j  <->  key t*32 + 16w + 8(j>>2) + 4lhi + (j&3))
+        // ---- O^T += V^T P^T.  The accumulator layout gives lane-half lhi the keys {8m + 4lhi .. +3}; one
+        // v_permlane32_swap per packed register pair regroups them so that half 0 holds the 8 consecutive keys
+        // 16w .. 16w+7 and half 1 holds 16w+8 .. 16w+15 = the natural k order of the MFMA, i.e. the V^T A-operand is
+        // one contiguous 16-B fragment read (same swizzle as K).
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int w = 0; w < 2; ++w) {
-                half8 pb_hi, pb_lo;
+                union { half8 h; unsigned u[4]; } ph, pl;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    float pv = sacc[t][8 * w + j];
-                    f16 ph = (f16)pv;
-                    pb_hi[j] = ph;
-                    if (SPLIT) pb_lo[j] = (f16)(pv - (float)ph);
+                    const float pv = sacc[t][8 * w + j];
+                    const f16 hh = (f16)pv;
+                    ph.h[j] = hh;
+                    if (SPLIT) pl.h[j] = (f16)(pv - (float)hh);
                 }
-                const int c0 = t * 8 + w * 4 + lhi;
+                // u[0..1] = X (registers 8w..8w+3), u[2..3] = Y (8w+4..8w+7): swap X.high-lanes <-> Y.low-lanes
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    auto r1 = __builtin_amdgcn_permlane32_swap(ph.u[e], ph.u[2 + e], false, false);
+                    ph.u[e] = r1[0]; ph.u[2 + e] = r1[1];
+                    if (SPLIT) {
+                        auto r2 = __builtin_amdgcn_permlane32_swap(pl.u[e], pl.u[2 + e], false, false);
+                        pl.u[e] = r2[0]; pl.u[2 + e] = r2[1];
+                    }
+                }
+                // after the swap: half 0 = [own X, partner X] = keys 16w+0..7; half 1 = [partner Y, own Y] = 16w+8..15,
+                // in registers (u0,u1 | u2,u3) = k slots (0..3 | 4..7)
+                const int c2 = t * 2 + w;            // 16-key group of the tile -> chunks 2*c2 + lhi
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
-                    const int drow = d * 32 + l31;
-                    const int sw = (drow >> 1) & 15;
-                    const int o0 = drow * 128 + ((c0 ^ sw) << 3);
-                    const int o1 = drow * 128 + (((c0 + 2) ^ sw) << 3);
-                    H8 vf;
-                    uint2 a = *reinterpret_cast<const uint2*>(sV + o0);
-                    uint2 b = *reinterpret_cast<const uint2*>(sV + o1);
-                    vf.u = make_uint4(a.x, a.y, b.x, b.y);
+                    half8 vf = *reinterpret_cast<const half8*>(sV + d * 4096 + foff_l[c2]);
                     if (SPLIT) {
-                        H8 vl;
-                        uint2 al = *reinterpret_cast<const uint2*>(sV + ATT_TILE_BYTES + o0);
-                        uint2 bl = *reinterpret_cast<const uint2*>(sV + ATT_TILE_BYTES + o1);
-                        vl.u = make_uint4(al.x, al.y, bl.x, bl.y);
-                        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl.h, pb_hi, oacc[d], 0, 0, 0);
-                        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf.h, pb_lo, oacc[d], 0, 0, 0);
+                        half8 vl = *reinterpret_cast<const half8*>(sV + ATT_TILE_BYTES + d * 4096 + foff_l[c2]);
+                        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph.h, oacc[d], 0, 0, 0);
+                        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pl.h, oacc[d], 0, 0, 0);
                     }
-                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf.h, pb_hi, oacc[d], 0, 0, 0);
+                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, ph.h, oacc[d], 0, 0, 0);
                 }
             }
-
-        if (it + 1 < ntiles) store_tile(cur ^ 1);
+    };
+    using std::integral_constant;
+    auto step = [&](auto stage_c, int it, int ntiles_) {
+        constexpr int STG = decltype(stage_c)::value;
+        const int kv0 = it * ATT_KV;
+        if (it + 1 < ntiles_) issue_tile(STG ^ 1, kv0 + ATT_KV);      // stage STG^1 was released by the last barrier
+        if (wave_active) {
+            if (kv0 + ATT_KV > p.nk) tile_body(stage_c, integral_constant<bool, true>{}, kv0);
+            else tile_body(stage_c, integral_constant<bool, false>{}, kv0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+    };
+
+    const int ntiles = (p.nk + ATT_KV - 1) / ATT_KV;
+    issue_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int it = 0; it < ntiles; it += 2) {
+        step(integral_constant<int, 0>{}, it, ntiles);
+        if (it + 1 < ntiles) step(integral_constant<int, 1>{}, it + 1, ntiles);
     }
 
     // ---- normalise and store: lane owns query q, d = dt*32 + (r&3) + 8*(r>>2) + 4*lhi

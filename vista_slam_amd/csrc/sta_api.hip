@@ -83,7 +83,7 @@ struct sta_handle {
     unsigned long long* clk_buf = nullptr;   // {shader cycles, 100 MHz ticks} summed over sampled workgroups of the timed GEMMs
     bool ktime = false; std::vector<hipEvent_t> kev; int kn = 0; std::vector<double> kflops, kbytes; std::vector<int> kvar;
     // optional two-slice concurrency (sta_set_concurrency)
-    int n_streams = 1; hipStream_t aux[2] = {nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    int n_streams = 1; hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     // f3 input-step tables (one cached geometry)
     int pre_key[6] = {0, 0, 0, 0, 0, 0}; int* pre_tab = nullptr; int64_t pre_cap = 0; int pre_meta[12] = {0};
     bool dry = false;   // planning pass: run the orchestration without launching to size the workspace
@@ -120,7 +120,7 @@ struct Bump {
 static int ensure_streams(sta_handle* h) {
     if (h->aux[0]) return 0;
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
         HIPCHK(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
     }
@@ -332,7 +332,7 @@ extern "C" int sta_destroy(sta_handle* h) {
     for (auto& e : h->kev) hipEventDestroy(e);
     if (h->aux[0]) {
         hipEventDestroy(h->ev_fork);
-        for (int i = 0; i < 2; ++i) { hipStreamDestroy(h->aux[i]); hipEventDestroy(h->ev_join[i]); }
+        for (int i = 0; i < 4; ++i) { hipStreamDestroy(h->aux[i]); hipEventDestroy(h->ev_join[i]); }
     }
     delete h;
     return 0;
@@ -346,7 +346,7 @@ extern "C" int sta_set_precision(sta_handle* h, int precision) {
 }
 extern "C" int sta_set_concurrency(sta_handle* h, int n_slices) {
     REQUIRE(h, "null handle");
-    REQUIRE(n_slices == 1 || n_slices == 2, "n_slices must be 1 or 2");
+    REQUIRE(n_slices >= 1 && n_slices <= 4, "n_slices must be 1..4");
     h->n_streams = n_slices;
     return 0;
 }
@@ -1012,12 +1012,12 @@ static int forward_pair_any(sta_handle* h, const void* img_a, const void* img_b,
         if (rec) HIPCHK(hipEventRecord(h->ev[4], st));
         return 0;
     };
-    const int nsl = (h->n_streams > 1 && B >= 2) ? 2 : 1;
+    const int nsl = h->n_streams < B ? h->n_streams : B;
     if (nsl == 1)
         return plan_and_run(h, [&](Bump& ws) -> int {
             return run_slice(ws, img_a, img_b, B, pts, conf, pose, pose_conf, st, h->timing && !h->dry);
         });
-    // Two batch slices on two internal streams: the hardware interleaves their workgroups, so the tail round of one
+    // Batch slices on internal streams: the hardware interleaves their workgroups, so the tail round of one
     // slice's GEMM and its HBM-bound kernels overlap the other slice's MFMA-bound main loops.  Fork/join by events;
     // the caller's stream sees one asynchronous operation.
     CHK(ensure_streams(h));
@@ -1025,8 +1025,8 @@ static int forward_pair_any(sta_handle* h, const void* img_a, const void* img_b,
     return plan_and_run(h, [&](Bump& ws) -> int {
         if (!h->dry) HIPCHK(hipEventRecord(h->ev_fork, st));
         int b0 = 0;
-        for (int s = 0; s < 2; ++s) {
-            const int Bs = s == 0 ? B / 2 : B - B / 2;
+        for (int s = 0; s < nsl; ++s) {
+            const int Bs = (B * (s + 1)) / nsl - (B * s) / nsl;
             hipStream_t ss = h->aux[s];
             if (!h->dry) HIPCHK(hipStreamWaitEvent(ss, h->ev_fork, 0));
             float* p[2] = {pts[0] + b0 * px * 3, pts[1] + b0 * px * 3};
