@@ -57,6 +57,10 @@ int sta_debug_head_final(sta_handle* h, const float* x, const float* w, const fl
 /* PoseHead_small.svd_orthogonalize (pose_head.py:38-57) of B row-major 3x3 matrices. */
 int sta_debug_svd_orthogonalize(sta_handle* h, const float* m, float* r, int B, void* stream);
 
+/* Per-launch record of the timed dominant-kernel family since sta_kernel_timing(h, 1): algorithmic FLOPs, HIP-event
+ * duration (ms) and tile family of up to `cap` launches (tools/inmodel_vs_micro.py). */
+int sta_kernel_timing_dump(sta_handle* h, int cap, double* flops, float* ms, int* variant, int* n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,7 @@ SIGNATURES = {
     "sta_version": (C.c_char_p, []),
     # ---- debug / kernel-level test entry points
     "sta_set_gemm_variant": (_i, [_vp, _i]),
+    "sta_kernel_timing_dump": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(_i), C.POINTER(_i)]),
     "sta_debug_gemm": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _vp]),
     "sta_debug_qkv_rope": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _vp]),
     "sta_debug_attention": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _vp]),

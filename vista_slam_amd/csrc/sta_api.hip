@@ -1366,6 +1366,19 @@ extern "C" int sta_kernel_timing_read(sta_handle* h, int variant, int* launches,
     return 0;
 }
 
+extern "C" int sta_kernel_timing_dump(sta_handle* h, int cap, double* flops, float* ms, int* variant, int* n_out) {
+    REQUIRE(h && flops && ms && variant && n_out, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    int n = 0;
+    for (int i = 0; i < h->kn && n < cap; ++i, ++n) {
+        HIPCHK(hipEventSynchronize(h->kev[2 * i + 1]));
+        HIPCHK(hipEventElapsedTime(&ms[n], h->kev[2 * i], h->kev[2 * i + 1]));
+        flops[n] = h->kflops[i]; variant[n] = h->kvar[i];
+    }
+    *n_out = n;
+    return 0;
+}
+
 extern "C" int sta_enable_stage_timing(sta_handle* h, int on) { REQUIRE(h, "null handle"); h->timing = on != 0; return 0; }
 extern "C" int sta_get_stage_ms(sta_handle* h, float ms[4]) {
     REQUIRE(h && h->ev_ok, "stage timing not recorded");
@@ -1495,6 +1508,7 @@ extern "C" int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, int
         if (tile == 12) return bench_launch2<192, 128, 2, 4, 8>(split, p, st);
         if (tile == 5) return bench_launch2<192, 256, 2, 4, 0>(split, p, st);
         if (tile == 6) return bench_launch2<192, 128, 2, 4, 0>(split, p, st);
+        if (tile == 13) { GemmParams q = p; q.resid = q.C32; q.ldr = q.ldc; return bench_launch2<192, 128, 2, 4, 0>(split, q, st); }   // in-place residual like attn.proj / mlp.fc2
         if (tile == 7) return bench_launch2<192, 128, 2, 2, 0>(split, p, st);
         if (tile == 8) return bench_launch2<128, 192, 2, 2, 0>(split, p, st);
         if (tile == 9) return bench_launch2<128, 128, 2, 2, 0>(split, p, st);
