@@ -207,10 +207,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
                 a_hi[i] = *reinterpret_cast<const half8*>(sA + lds2_off<SPLIT>(ra, chunk));
                 if (SPLIT) a_lo[i] = *reinterpret_cast<const half8*>(sA + lds2_off<SPLIT>(ra, 4 + chunk));
                 if (AMODE == A_CONV3) {
-                    if (p.relu_in) {   // relu(hi + lo): the sign of hi decides
-                        const short8 neg = a_hi[i] < (half8)(f16)0;
-                        a_hi[i] = __builtin_bit_cast(half8, (short8)(__builtin_bit_cast(short8, a_hi[i]) & ~neg));
-                        if (SPLIT) a_lo[i] = __builtin_bit_cast(half8, (short8)(__builtin_bit_cast(short8, a_lo[i]) & ~neg));
+                    if (p.relu_in) {   // relu(hi + lo): the sign of hi decides.  Packed-half integer form, 5 VALU per
+                        // 32-bit word for both planes (the vector compare scalarises to ~11 per word):
+                        // s = sign bits at bit 0 / 16, m = 0xFFFF in every negative half, x &= ~m
+                        union { half8 h; unsigned u[4]; } ah, al;
+                        ah.h = a_hi[i]; al.h = a_lo[i];
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const unsigned sgn = (ah.u[w] >> 15) & 0x00010001u;
+                            const unsigned m = (sgn << 16) - sgn;        // 0xFFFF per set sign (mod 2^32)
+                            ah.u[w] &= ~m;
+                            if (SPLIT) al.u[w] &= ~m;
+                        }
+                        a_hi[i] = ah.h; if (SPLIT) a_lo[i] = al.h;
                     }
                 }
             }
