@@ -54,7 +54,10 @@ def test_attention(G, prec, kw):
                                 dict(relu_in=1, act=2, resid=True, Cin=96, Co=256, H=9, W_=12), dict(H=1, W_=1),
                                 dict(relu_in=1, act=2, resid=True, Cin=96, Co=256, H=19, W_=23, variant=2),
                                 dict(Cin=64, Co=128, H=17, W_=9, variant=2), dict(stride=2, Cin=32, Co=256, H=15, W_=14, variant=2),
-                                dict(relu_in=1, act=2, resid=True, Cin=96, Co=256, H=19, W_=23, variant=3), dict(Cin=64, Co=128, H=17, W_=9, variant=3)])
+                                dict(relu_in=1, act=2, resid=True, Cin=96, Co=256, H=19, W_=23, variant=3), dict(Cin=64, Co=128, H=17, W_=9, variant=3),
+                                # tiny grids with a long K loop: split-K partial sums + splitk_finish_kernel (SLAM-scale DPT levels)
+                                dict(Cin=128, Co=64, H=6, W_=6), dict(relu_in=1, act=2, resid=True, Cin=256, Co=256, H=7, W_=7, n=3),
+                                dict(stride=2, Cin=768, Co=256, H=14, W_=14, n=1)])
 def test_conv3x3(G, prec, kw):
     r = G.check_conv3(prec, **kw)
     assert r["rel_l2"] < TOL[prec], r

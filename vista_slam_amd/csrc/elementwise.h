@@ -716,3 +716,30 @@ __global__ void mat_to_se3_kernel(const float* pose, int B, float* out) {
     float* o = out + b * 7;
     o[0] = P[3]; o[1] = P[7]; o[2] = P[11]; o[3] = qx * nrm; o[4] = qy * nrm; o[5] = qz * nrm; o[6] = qw * nrm;
 }
+
+// Second half of a split-K GEMM / conv with the fp16-plane epilogue (small SLAM-scale grids): the K slices atomically
+// summed fp32 partials into skbuf [M,N]; this applies bias, activation and the residual planes exactly like
+// epilogue_tile<EPI_F16> and writes the blocked output planes.  One thread = 4 consecutive columns of one row.
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* skbuf, const float* bias, int M, int N, int act,
+                                                            const f16* R1, const f16* R2, f16* C, int64_t c_rp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n4 = N >> 2;
+    if (i >= (int64_t)M * n4) return;
+    const int row = (int)(i / n4), col = (int)(i - (int64_t)row * n4) * 4;
+    const float4 a = *reinterpret_cast<const float4*>(skbuf + (size_t)row * N + col);
+    float v[4] = {a.x, a.y, a.z, a.w};
+    const size_t o = blk_off<SPLIT>(row, col, c_rp);
+    H4 oh, ol;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = v[e] + (bias ? bias[col + e] : 0.f);
+        if (act == 1) x = gelu_erf(x);
+        else if (act == 2) x = fmaxf(x, 0.f);
+        if (R1) { x += (float)R1[o + e]; if (SPLIT) x += (float)R1[o + 32 + e]; }
+        if (R2) { x += (float)R2[o + e]; if (SPLIT) x += (float)R2[o + 32 + e]; }
+        if (SPLIT) split_f16(x, oh.e[e], ol.e[e]); else oh.e[e] = to_f16_sat(x);
+    }
+    *reinterpret_cast<uint2*>(C + o) = oh.u;
+    if (SPLIT) *reinterpret_cast<uint2*>(C + o + 32) = ol.u;
+}

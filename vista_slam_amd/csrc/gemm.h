@@ -41,6 +41,8 @@ struct GemmParams {
     // ---- EPI_F16
     f16* C_hi; f16* C_lo; int ldc16; int act;            // blocked output planes with c_rp rows (ldc16 unused)
     int64_t c_rp;
+    float* skbuf = nullptr;                              // EPI_F16 split-K: fp32 partial sums [M,N] (zeroed); splitk_finish_kernel
+                                                         //     applies bias / activation / residual planes and writes the planes
     const f16* R1_hi; const f16* R1_lo; const f16* R2_hi; const f16* R2_lo;
     // ---- EPI_QKV
     f16* Q_hi; f16* Q_lo; f16* K_hi; f16* K_lo; f16* Vt_hi; f16* Vt_lo;
@@ -181,7 +183,9 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
                 }
             }
         } else if (EPI == EPI_F16) {
-            if (ok) {
+            if (ok && p.ksplit > 1) {
+                unsafeAtomicAdd(p.skbuf + (size_t)row * p.N + col, acc[r]);
+            } else if (ok) {
                 if (p.act == ACT_GELU) v = gelu_erf(v);
                 else if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
                 const size_t o = blk_off<SPLIT>(row, col, p.c_rp);

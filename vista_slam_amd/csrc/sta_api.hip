@@ -54,6 +54,8 @@ struct Slot {
     bool loaded = false;
 };
 
+static const int64_t SKBUF_ELEMS = (int64_t)4 << 20;   // 16 MiB: M*N of the largest split-K plane-epilogue GEMM
+
 struct sta_handle {
     sta_config cfg;
     int device = 0;
@@ -74,6 +76,7 @@ struct sta_handle {
     float* stage = nullptr; int64_t stage_elems = 0;
     char* ws = nullptr; int64_t ws_cap = 0;
     f16* zero_page = nullptr;
+    float* skbuf = nullptr;   // fp32 partial sums of split-K GEMMs with the plane epilogue (SKBUF_ELEMS floats)
     int gemm_variant = 0;   // 0 auto, 1 force 128x128 kernel, 2 force 256-row kernel (tests/bench only)
     // rope table
     float* rope_tab = nullptr; int rope_P = 0;
@@ -312,6 +315,7 @@ extern "C" int sta_create(const sta_config* cfg, int device, sta_handle** out) {
     int64_t big = (int64_t)768 * 768 * 9;
     if (big > h->stage_elems) h->stage_elems = big;
     if (hipMalloc((void**)&h->stage, (size_t)h->stage_elems * 4) != hipSuccess) { sta_destroy(h); return set_err("staging alloc failed"); }
+    if (hipMalloc((void**)&h->skbuf, (size_t)SKBUF_ELEMS * 4) != hipSuccess) { sta_destroy(h); return set_err("split-K buffer alloc failed"); }
     if (hipMalloc((void**)&h->zero_page, 256) != hipSuccess || hipMemset(h->zero_page, 0, 256) != hipSuccess) { sta_destroy(h); return set_err("zero page alloc failed"); }
     *out = h;
     return 0;
@@ -326,6 +330,7 @@ extern "C" int sta_destroy(sta_handle* h) {
     if (h->ws) hipFree(h->ws);
     if (h->rope_tab) hipFree(h->rope_tab);
     if (h->zero_page) hipFree(h->zero_page);
+    if (h->skbuf) hipFree(h->skbuf);
     if (h->pre_tab) hipFree(h->pre_tab);
     if (h->clk_buf) hipFree(h->clk_buf);
     if (h->ev_ok) for (auto& e : h->ev) hipEventDestroy(e);
@@ -489,6 +494,18 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
             if (ks > max_ks) ks = max_ks;
             if (ks > 1) p.ksplit = ks;
         }
+        // plane-epilogue GEMMs / convs on tiny grids (DPT levels at SLAM scale: 16-64 workgroups looping over K = 2304 ..
+        // 6912): split K into fp32 partial sums, a finishing kernel applies bias / activation / residuals.  Worth two
+        // extra tiny launches only when the K loop is long and the grid leaves most of the chip idle.
+        if (EPI == EPI_F16 && tiles <= 96 && p.K >= 1024 && p.N % 4 == 0 && (int64_t)p.M * p.N <= SKBUF_ELEMS) {
+            int ks = (256 + tiles - 1) / tiles;
+            const int max_ks = p.K / 256;                 // keep >= 8 K tiles per slice
+            if (ks > max_ks) ks = max_ks;
+            if (ks > 1) {
+                p.ksplit = ks; p.skbuf = h->skbuf;
+                HIPCHK(hipMemsetAsync(h->skbuf, 0, (size_t)p.M * p.N * 4, st));
+            }
+        }
     }
     if (h->gemm_variant == 2 && p.N % 128 == 0) variant = (p.N % 256 == 0 && EPI != EPI_QKV) ? 2 : 3;
     if (h->gemm_variant == 3 && p.N % 128 == 0) variant = (p.N % 256 == 0 && EPI != EPI_QKV) ? 4 : 5;
@@ -511,6 +528,13 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
     } else if (variant == 6) {
         if (split) CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 2, 2, 3>(p, st)));
         else CHK((launch_gemm2<false, AMODE, EPI, 128, 64, 2, 2, 3>(p, st)));
+        if (EPI == EPI_F16 && p.ksplit > 1) {
+            const int64_t n4 = (int64_t)p.M * (p.N / 4);
+            const int blocks = (int)((n4 + 255) / 256);
+            if (split) hipLaunchKernelGGL(splitk_finish_kernel<true>, dim3(blocks), dim3(256), 0, st, p.skbuf, p.bias, p.M, p.N, p.act, p.R1_hi, p.R2_hi, p.C_hi, p.c_rp);
+            else hipLaunchKernelGGL(splitk_finish_kernel<false>, dim3(blocks), dim3(256), 0, st, p.skbuf, p.bias, p.M, p.N, p.act, p.R1_hi, p.R2_hi, p.C_hi, p.c_rp);
+            HIPCHK(hipGetLastError());
+        }
     } else {
         int tm = (p.M + GEMM_BM - 1) / GEMM_BM, tn = (p.N + GEMM_BN - 1) / GEMM_BN;
         dim3 grid((unsigned)(tm * tn));
