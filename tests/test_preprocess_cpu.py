@@ -47,3 +47,30 @@ def test_portrait_and_ambiguous_square_are_rejected():
 def test_identity_size_is_identity():
     img = W.synth_frames_u8(64, 96, seed=43, tag=9)
     assert np.array_equal(P.lanczos_resize_u8(img, 96, 64), img)
+
+
+def test_oracle_lanczos_equals_live_pillow_on_random_geometries():
+    """Beyond the committed goldens: the restated resampler against the Pillow installed in this image
+    (a pip dependency of the reference, not reference code) on random up / down-scaling geometries."""
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(11)
+    for it in range(10):
+        Hs, Ws = int(rng.integers(20, 300)), int(rng.integers(20, 400))
+        oh, ow = int(rng.integers(8, 260)), int(rng.integers(8, 330))
+        img = W.synth_frames_u8(Hs, Ws, seed=43, tag=100 + it)
+        want = np.asarray(PIL.fromarray(img).resize((ow, oh), resample=PIL.Resampling.LANCZOS))
+        got = P.lanczos_resize_u8(img, ow, oh)
+        assert np.array_equal(got, want), (Hs, Ws, oh, ow)
+
+
+def test_ply_writer_round_trip(tmp_path):
+    """f4 host formatting (no GPU): header + 27-byte records survive a write / read cycle."""
+    from vista_slam_amd import formats as F
+    rec = np.zeros(5, dtype=F.PLY_RECORD)
+    rec["x"] = np.arange(5) * 0.5; rec["y"] = -np.arange(5); rec["z"] = 1e-3
+    rec["red"] = [0, 1, 127, 254, 255]; rec["green"] = 7; rec["blue"] = 9
+    path = str(tmp_path / "c.ply")
+    F.write_ply(path, rec)
+    head = open(path, "rb").read(200).decode("ascii", "ignore")
+    assert head.startswith("ply\nformat binary_little_endian 1.0\n") and "element vertex 5\n" in head and "property double x" in head
+    assert np.array_equal(F.read_ply(path), rec)
