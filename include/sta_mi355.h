@@ -49,7 +49,9 @@ typedef struct sta_handle sta_handle;
  * gfx950 has no TF32/XF32 MFMA (the reference runs TF32: sta_model.py:5). */
 enum {
     STA_PREC_F16   = 1,  /* fp16 x fp16 -> fp32 MFMA, one product  (10-bit mantissa == TF32 class) */
-    STA_PREC_F16X3 = 3   /* 2-term fp16 split of both operands, 3 products (~21-bit, fp32 class)   */
+    STA_PREC_F16X3 = 3,  /* 2-term fp16 split of both operands, 3 products (~21-bit, fp32 class)   */
+    STA_PREC_F16MX = 4   /* opt-in: f16x3 everywhere except the transformer linears, whose two correction
+                          * products run as one block-scaled fp8 MFMA (GEMM error ~1e-5, 1.5x less MFMA work) */
 };
 
 enum { STA_DTYPE_F32 = 0 };

@@ -5,8 +5,10 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"f16x3": 2e-5, "f16": 3e-3}
-PRECS = ["f16x3", "f16"]
+# f16mx: dense GEMMs carry their correction products as one block-scaled fp8 MFMA (~1e-5 per GEMM); every other
+# kernel runs its f16x3 path in that mode
+TOL = {"f16x3": 2e-5, "f16": 3e-3, "f16mx": 6e-5}
+PRECS = ["f16x3", "f16", "f16mx"]
 
 
 @pytest.fixture(scope="module")

@@ -58,6 +58,21 @@ def test_full_sharp_attention_golden(G):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("case,tol", [("tiny_32x32_b1", 1e-4), ("tiny_48x64_b2", 1e-4), ("full_224_b1", 1e-4), ("full_384x512_b1", 1e-4),
+                                      ("full_224_b1_sharp", 3e-4),
+                                      # the two sharpened tiny-config stress sets amplify every rounding error ~100x (f16x3: 2e-4 there):
+                                      # beyond what this opt-in mode promises, bounded here so a regression still shows
+                                      ("tiny_48x64_b2_sharp", 5e-3), ("tiny_48x80_smooth_sharp", 2e-2)])
+def test_goldens_f16mx_opt_in_precision(G, case, tol):
+    """Opt-in precision f16mx (transformer linears: f16 main product + one block-scaled fp8 correction MFMA): the
+    reference-architecture goldens hold 1e-4 (bar 1e-3), i.e. ~10x the f16x3 error and ~30x below one-product f16."""
+    if case.startswith("full"):
+        G.drop_models()
+    r = G.run_golden_case(case, "f16mx")
+    bad = {k: v for k, v in r.items() if v > tol}
+    assert not bad, bad
+
+
 def test_error_paths(G):
     """Same failure behaviour as the reference: H,W % 16 (patch_embed.py:20-21), strict state_dict."""
     import numpy as np

@@ -11,7 +11,8 @@ LIB_PATH = os.path.join(PKG, "libsta_mi355.so")
 
 STA_PREC_F16 = 1
 STA_PREC_F16X3 = 3
-PRECISIONS = {"f16": STA_PREC_F16, "f16x3": STA_PREC_F16X3}
+STA_PREC_F16MX = 4
+PRECISIONS = {"f16": STA_PREC_F16, "f16x3": STA_PREC_F16X3, "f16mx": STA_PREC_F16MX}
 
 
 class StaConfig(C.Structure):

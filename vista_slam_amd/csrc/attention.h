@@ -31,6 +31,7 @@ struct AttnParams {
     int S, heads, nq, nk, npad;
     int kv_shift;            // K/V come from sequence (s + kv_shift) % S
     float scale_log2e;       // head_dim^-0.5 * log2(e)
+    int o_mx;                // write the output planes in the f16mx row format (the consumer is an f16mx GEMM)
 };
 
 #define ATT_KV 64
@@ -262,14 +263,19 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
         for (int d = 0; d < 2; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                const int dcol = d * 32 + 8 * g + 4 * lhi;
+                const size_t o = blk_off<SPLIT>(orow, h * 64 + dcol, orows);    // blocked planes [ldo/32][S*nq][hi32|lo32]
+                if (SPLIT && p.o_mx) {
+                    const float y[4] = {oacc[d][g * 4] * inv, oacc[d][g * 4 + 1] * inv, oacc[d][g * 4 + 2] * inv, oacc[d][g * 4 + 3] * inv};
+                    store_mx4(p.O_hi, o, split_mx4<false>(y));
+                    continue;
+                }
                 H4 oh, ol;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = oacc[d][g * 4 + e] * inv;
                     if (SPLIT) split_f16(v, oh.e[e], ol.e[e]); else oh.e[e] = to_f16_sat(v);
                 }
-                const int dcol = d * 32 + 8 * g + 4 * lhi;
-                const size_t o = blk_off<SPLIT>(orow, h * 64 + dcol, orows);    // blocked planes [ldo/32][S*nq][hi32|lo32]
                 *reinterpret_cast<uint2*>(p.O_hi + o) = oh.u;
                 if (SPLIT) *reinterpret_cast<uint2*>(p.O_hi + o + 32) = ol.u;
             }

@@ -14,6 +14,7 @@ struct LnParams {
     const float* g1; const float* b1; f16* o1_hi; f16* o1_lo;
     const float* g2; const float* b2; f16* o2_hi; f16* o2_lo;   // optional (g2 == nullptr)
     float* o32; int ldo32;                                       // optional fp32 output with set 1
+    int mx;                                                      // planes in the f16mx row format (sta_common.h)
 };
 
 template <bool SPLIT>
@@ -54,24 +55,32 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
                 float y[4] = {n[0] * g.x + b.x, n[1] * g.y + b.y, n[2] * g.z + b.z, n[3] * g.w + b.w};
                 if (p.o32) *reinterpret_cast<float4*>(p.o32 + (size_t)row * p.ldo32 + idx) = make_float4(y[0], y[1], y[2], y[3]);
                 if (p.o1_hi) {
-                    H4 h, l;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e]); else h.e[e] = to_f16_sat(y[e]); }
                     const size_t o = blk_off<SPLIT>(row, idx, p.M);
-                    *reinterpret_cast<uint2*>(p.o1_hi + o) = h.u;
-                    if (SPLIT) *reinterpret_cast<uint2*>(p.o1_hi + o + 32) = l.u;
+                    if (SPLIT && p.mx) {
+                        store_mx4(p.o1_hi, o, split_mx4<false>(y));
+                    } else {
+                        H4 h, l;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e]); else h.e[e] = to_f16_sat(y[e]); }
+                        *reinterpret_cast<uint2*>(p.o1_hi + o) = h.u;
+                        if (SPLIT) *reinterpret_cast<uint2*>(p.o1_hi + o + 32) = l.u;
+                    }
                 }
             }
             if (p.g2) {
                 float4 g = *reinterpret_cast<const float4*>(p.g2 + idx);
                 float4 b = *reinterpret_cast<const float4*>(p.b2 + idx);
                 float y[4] = {n[0] * g.x + b.x, n[1] * g.y + b.y, n[2] * g.z + b.z, n[3] * g.w + b.w};
-                H4 h, l;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e]); else h.e[e] = to_f16_sat(y[e]); }
                 const size_t o = blk_off<SPLIT>(row, idx, p.M);
-                *reinterpret_cast<uint2*>(p.o2_hi + o) = h.u;
-                if (SPLIT) *reinterpret_cast<uint2*>(p.o2_hi + o + 32) = l.u;
+                if (SPLIT && p.mx) {
+                    store_mx4(p.o2_hi, o, split_mx4<false>(y));
+                } else {
+                    H4 h, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e]); else h.e[e] = to_f16_sat(y[e]); }
+                    *reinterpret_cast<uint2*>(p.o2_hi + o) = h.u;
+                    if (SPLIT) *reinterpret_cast<uint2*>(p.o2_hi + o + 32) = l.u;
+                }
             }
         }
     }
@@ -82,7 +91,8 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
 template <bool SPLIT>
 __global__ void rows_to_planes_kernel(const float* x, int64_t bstride, int rows, int C, int64_t total4,
                                       f16* o_hi, f16* o_lo, int64_t obstride /* output batch stride in rows; 0 = rows */,
-                                      int64_t orows /* rows of the blocked output planes; 0 = row-major [.,C] (Q/K buffers) */) {
+                                      int64_t orows /* rows of the blocked output planes; 0 = row-major [.,C] (Q/K buffers) */,
+                                      int mx = 0 /* blocked output in the f16mx row format */) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
     const int c4 = C / 4;
@@ -95,7 +105,9 @@ __global__ void rows_to_planes_kernel(const float* x, int64_t bstride, int rows,
 #pragma unroll
         for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e]); else h.e[e] = to_f16_sat(y[e]); }
         const int64_t orow = obstride ? b * obstride + rr : r;
-        if (orows) {
+        if (SPLIT && mx && orows) {
+            store_mx4(o_hi, blk_off<SPLIT>(orow, c, orows), split_mx4<false>(y));
+        } else if (orows) {
             const size_t o = blk_off<SPLIT>(orow, c, orows);
             *reinterpret_cast<uint2*>(o_hi + o) = h.u;
             if (SPLIT) *reinterpret_cast<uint2*>(o_hi + o + 32) = l.u;
@@ -520,7 +532,7 @@ __global__ void rope2d_inplace_kernel(float* tok, int64_t sb, int64_t sn, const 
 //   mode 1: conv [Co,Ci,kh,kw] -> [Co][kh][kw][Ci]
 //   mode 2: transposed conv [Ci,Co,k,k] -> [(dy*k+dx)*Co+co][Ci]
 __global__ void repack_weight_kernel(const float* src, f16* hi, f16* lo, int64_t total, int mode,
-                                     int d0, int d1, int d2, int d3, int64_t N, int64_t K, int64_t n_off) {
+                                     int d0, int d1, int d2, int d3, int64_t N, int64_t K, int64_t n_off, int mx = 0) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
     for (; i < total; i += step) {
@@ -536,7 +548,8 @@ __global__ void repack_weight_kernel(const float* src, f16* hi, f16* lo, int64_t
         // logical packed index i = n*K + k  ->  blocked [K/32][N][hi32|lo32]
         const int64_t nl = i / K, k = i - nl * K, n = nl + n_off;
         const size_t o = ((size_t)(k >> 5) * N + n) * 64 + (k & 31);
-        hi[o] = h; hi[o + 32] = l;
+        if (mx) store_mx1<true>(hi, o, src[si]);          // f16mx weight rows: [hi f16 | e4m3(hi*2^4) | e4m3(lo*2^15)]
+        else { hi[o] = h; hi[o + 32] = l; }
     }
 }
 

@@ -33,6 +33,7 @@ struct GemmParams {
     // ---- B operand (weights, [N,K] planes) and bias
     const f16* B_hi; const f16* B_lo; const float* bias;
     int M, N, K;
+    int mx;                                              // A and B are f16mx rows (sta_common.h); dense GEMMs only
     // ---- EPI_F32
     float* C32; int ldc; const float* resid; int ldr;
     int rows_in, rows_out, row_off;                      // out_row = (m/rows_in)*rows_out + row_off + m%rows_in
@@ -40,6 +41,7 @@ struct GemmParams {
                                                          //     holds the residual); bias is added by slice 0 only
     // ---- EPI_F16
     f16* C_hi; f16* C_lo; int ldc16; int act;            // blocked output planes with c_rp rows (ldc16 unused)
+    int c_mx;                                            // EPI_F16 output in the f16mx row format (consumer = f16mx GEMM)
     int64_t c_rp;
     float* skbuf = nullptr;                              // EPI_F16 split-K: fp32 partial sums [M,N] (zeroed); splitk_finish_kernel
                                                          //     applies bias / activation / residual planes and writes the planes
@@ -191,7 +193,8 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
                 const size_t o = blk_off<SPLIT>(row, col, p.c_rp);
                 if (p.R1_hi) { v += (float)p.R1_hi[o]; if (SPLIT) v += (float)p.R1_hi[o + 32]; }
                 if (p.R2_hi) { v += (float)p.R2_hi[o]; if (SPLIT) v += (float)p.R2_hi[o + 32]; }
-                if (SPLIT) { f16 h, l; split_f16(v, h, l); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
+                if (SPLIT && p.c_mx) store_mx1<false>(p.C_hi, o, v);
+                else if (SPLIT) { f16 h, l; split_f16(v, h, l); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
                 else p.C_hi[o] = to_f16_sat(v);
             }
         } else {  // EPI_CONVT

@@ -43,7 +43,7 @@ __device__ __forceinline__ int lds2_off(int row, int chunk) {
 // ahead and stays in flight across the barrier (counted vmcnt + raw s_barrier in one asm statement) -
 // no gain on the big throughput shapes (DMA-throughput bound) but it is what makes the small-M /
 // split-K family (SLAM-scale GEMMs, a handful of K tiles per block) latency-tolerant.
-template <bool SPLIT, int AMODE, int EPI, int BM, int BN, int WAVES_M, int WAVES_N, int ABL = 0, int NSTG = 2>
+template <bool SPLIT, int AMODE, int EPI, int BM, int BN, int WAVES_M, int WAVES_N, int ABL = 0, int NSTG = 2, bool MX = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WAVES_M * WAVES_N;
@@ -191,6 +191,56 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
         } else if (kt + 1 < nkt && !(ABL & 1) && !late_dma) issue_tile(kt0 + kt + 1, cur ^ 1);
         const char* sA = smem + cur * STAGE;
         const char* sB = sA + A_TILE;
+        if (MX) {
+            // precision f16mx (sta_common.h): per K tile and accumulator 2 f16 MFMAs (hi x hi, K steps 0 / 1) + ONE
+            // block-scaled fp8 MFMA that carries both correction products.  Operand semantics of
+            // v_mfma_scale_f32_32x32x64_f8f6f4 as decoded on hardware (tools/probes/mx_probe*.hip): byte q of lane
+            // (row, half) of A meets byte q of lane (col, half) of B; scale block b = bytes [16b, 16b+16) of both lane
+            // halves, scaled by the E8M0 byte of lane (row, half b).  The second half of every row block holds the
+            // (hi8, lo8) / (lo8, hi8) byte pairs, so a lane's operand is simply 32 contiguous bytes = 16 k, and all
+            // blocks carry the one combined scale 2^-15.
+            typedef int int4v __attribute__((ext_vector_type(4)));
+            typedef int int8v __attribute__((ext_vector_type(8)));
+            half8 ah[MT], bh[NT];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int chunk = ks * 2 + lhi;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) ah[i] = *reinterpret_cast<const half8*>(sA + lds2_off<true>(wm * WM + i * 32 + l31, chunk));
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bh[j] = *reinterpret_cast<const half8*>(sB + lds2_off<true>(wn * WN + j * 32 + l31, chunk));
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+            union U8 { struct { int4v x, y; } q; int8v v; };
+            U8 a8[MT], b8[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int ra = wm * WM + i * 32 + l31;
+                a8[i].q.x = *reinterpret_cast<const int4v*>(sA + lds2_off<true>(ra, 4 + 2 * lhi));
+                a8[i].q.y = *reinterpret_cast<const int4v*>(sA + lds2_off<true>(ra, 5 + 2 * lhi));
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int rb = wn * WN + j * 32 + l31;
+                b8[j].q.x = *reinterpret_cast<const int4v*>(sB + lds2_off<true>(rb, 4 + 2 * lhi));
+                b8[j].q.y = *reinterpret_cast<const int4v*>(sB + lds2_off<true>(rb, 5 + 2 * lhi));
+            }
+            constexpr int sc_a = 127 - STA_MX_A_SLO, sc_b = 127 - STA_MX_W_SHI;       // 2^-11 * 2^-4 = the shared 2^-15
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i].v, b8[j].v, acc[i][j], 0, 0, 0, sc_a, 0, sc_b);
+            if (!RING) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            continue;
+        }
         half8 a_hi[MT], a_lo[MT], b_hi[NT], b_lo[NT];
         if (ABL & 2) {
 #pragma unroll
@@ -237,7 +287,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
                 continue;
             }
             // product-major order: consecutive MFMAs hit different accumulators (MT*NT apart)
-            if (SPLIT) {
+            if (SPLIT && (ABL & 16)) {
+                // bench-only what-if (results are NOT a GEMM): the two correction products of both K steps replaced by
+                // ONE block-scaled fp8 MFMA (32x32x64, 2x rate) per accumulator per K tile - the instruction mix of an
+                // "f16 + MX-fp8 corrections" scheme, to price it before building it (operands: whatever bits are there)
+                if (ks == 1) {
+                    typedef int int8v __attribute__((ext_vector_type(8)));
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            union { struct { half8 x, y; } h; int8v v; } ua, ub;
+                            ua.h.x = a_lo[i]; ua.h.y = a_hi[i]; ub.h.x = b_hi[j]; ub.h.y = b_lo[j];
+                            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ua.v, ub.v, acc[i][j], 0, 0, 0, 0x7f, 0, 0x7f);
+                        }
+                }
+            } else if (SPLIT) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll

@@ -35,7 +35,7 @@ static inline Planes slice_rows(const Planes& p, int64_t r0) {
     q.hi = p.hi + r0 * es; if (p.lo) q.lo = q.hi + 32;
     return q;
 }
-struct Lin { Planes w; float* bias = nullptr; int N = 0, K = 0; };
+struct Lin { Planes w; Planes wmx; float* bias = nullptr; int N = 0, K = 0; };   // wmx: second packed copy in the f16mx row format (transformer linears)
 struct LNp { float* g = nullptr; float* b = nullptr; };
 struct EncBlk { LNp n1, n2; Lin qkv, proj, fc1, fc2; };
 struct DecBlk { LNp n1, n2, n3, ny; Lin qkv, proj, cq, ckv, cproj, fc1, fc2; };
@@ -49,6 +49,7 @@ struct Slot {
     SlotKind kind = SK_DROP;
     float* dst32 = nullptr;          // SK_F32 / SK_B_CONVT destination (+offset applied)
     f16* dst_hi = nullptr; f16* dst_lo = nullptr;   // packed destination (+row offset applied)
+    f16* dst_mx = nullptr;           // f16mx copy of the same weight (transformer linears)
     int reps = 1;                    // SK_B_CONVT: k*k
     int64_t N = 0, K = 0, n_off = 0; // packed-weight geometry: rows of the whole Lin, contraction length, row offset
     bool loaded = false;
@@ -142,10 +143,11 @@ static int ensure_ws(sta_handle* h, int64_t bytes) {
 }
 
 // ------------------------------------------------------------------------------------------ schema
-static int make_lin(sta_handle* h, Lin& L, int N, int K, bool bias = true) {
+static int make_lin(sta_handle* h, Lin& L, int N, int K, bool bias = true, bool mx = false) {
     L.N = N; L.K = K;
     CHK(dalloc(h, (void**)&L.w.hi, (int64_t)N * K * 4 + 256));     // blocked [K/32][N][hi32|lo32]
     L.w.lo = L.w.hi + 32; L.w.rp = N;
+    if (mx) { CHK(dalloc(h, (void**)&L.wmx.hi, (int64_t)N * K * 4 + 256)); L.wmx.lo = L.wmx.hi + 32; L.wmx.rp = N; }   // [K/32][N][hi32 | hi8 x32 | lo8 x32]
     if (bias) CHK(dalloc(h, (void**)&L.bias, (int64_t)N * 4));
     return 0;
 }
@@ -154,7 +156,7 @@ static int make_ln(sta_handle* h, LNp& n, int C) {
 }
 static void slot_w(sta_handle* h, const std::string& name, std::vector<int64_t> shape, SlotKind k, Lin& L, int row_off = 0) {
     Slot s; s.shape = std::move(shape); s.kind = k;
-    s.dst_hi = L.w.hi; s.dst_lo = L.w.lo; s.N = L.N; s.K = L.K; s.n_off = row_off;
+    s.dst_hi = L.w.hi; s.dst_lo = L.w.lo; s.dst_mx = L.wmx.hi; s.N = L.N; s.K = L.K; s.n_off = row_off;
     h->slots[name] = s;
 }
 static void slot_f32(sta_handle* h, const std::string& name, std::vector<int64_t> shape, float* dst) {
@@ -163,8 +165,8 @@ static void slot_f32(sta_handle* h, const std::string& name, std::vector<int64_t
 static void slot_drop(sta_handle* h, const std::string& name, std::vector<int64_t> shape) {
     Slot s; s.shape = std::move(shape); s.kind = SK_DROP; h->slots[name] = s;
 }
-static int reg_linear(sta_handle* h, const std::string& name, Lin& L, int N, int K) {
-    CHK(make_lin(h, L, N, K));
+static int reg_linear(sta_handle* h, const std::string& name, Lin& L, int N, int K, bool mx = false) {
+    CHK(make_lin(h, L, N, K, true, mx));
     slot_w(h, name + ".weight", {N, K}, SK_W_ID, L);
     slot_f32(h, name + ".bias", {N}, L.bias);
     return 0;
@@ -208,11 +210,11 @@ static int build_schema(sta_handle* h) {
         EncBlk& b = h->enc[i];
         snprintf(nm, sizeof nm, "enc_blocks.%d.", i); std::string p(nm);
         CHK(reg_ln(h, p + "norm1", b.n1, E));
-        CHK(reg_linear(h, p + "attn.qkv", b.qkv, 3 * E, E));
-        CHK(reg_linear(h, p + "attn.proj", b.proj, E, E));
+        CHK(reg_linear(h, p + "attn.qkv", b.qkv, 3 * E, E, true));
+        CHK(reg_linear(h, p + "attn.proj", b.proj, E, E, true));
         CHK(reg_ln(h, p + "norm2", b.n2, E));
-        CHK(reg_linear(h, p + "mlp.fc1", b.fc1, R * E, E));
-        CHK(reg_linear(h, p + "mlp.fc2", b.fc2, E, R * E));
+        CHK(reg_linear(h, p + "mlp.fc1", b.fc1, R * E, E, true));
+        CHK(reg_linear(h, p + "mlp.fc2", b.fc2, E, R * E, true));
     }
     slot_drop(h, "enc_norm.weight", {E}); slot_drop(h, "enc_norm.bias", {E});   // never applied (sta_model.py:259,267)
     CHK(reg_linear(h, "decoder_embed", h->dec_embed, D, E));
@@ -221,20 +223,20 @@ static int build_schema(sta_handle* h) {
         DecBlk& b = h->dec[i];
         snprintf(nm, sizeof nm, "dec_block.%d.", i); std::string p(nm);
         CHK(reg_ln(h, p + "norm1", b.n1, D));
-        CHK(reg_linear(h, p + "attn.qkv", b.qkv, 3 * D, D));
-        CHK(reg_linear(h, p + "attn.proj", b.proj, D, D));
-        CHK(reg_linear(h, p + "cross_attn.projq", b.cq, D, D));
+        CHK(reg_linear(h, p + "attn.qkv", b.qkv, 3 * D, D, true));
+        CHK(reg_linear(h, p + "attn.proj", b.proj, D, D, true));
+        CHK(reg_linear(h, p + "cross_attn.projq", b.cq, D, D, true));
         // projk + projv packed as one [2D, D] GEMM
-        CHK(make_lin(h, b.ckv, 2 * D, D));
+        CHK(make_lin(h, b.ckv, 2 * D, D, true, true));
         slot_w(h, p + "cross_attn.projk.weight", {D, D}, SK_W_ID, b.ckv, 0);
         slot_f32(h, p + "cross_attn.projk.bias", {D}, b.ckv.bias);
         slot_w(h, p + "cross_attn.projv.weight", {D, D}, SK_W_ID, b.ckv, D);
         slot_f32(h, p + "cross_attn.projv.bias", {D}, b.ckv.bias + D);
-        CHK(reg_linear(h, p + "cross_attn.proj", b.cproj, D, D));
+        CHK(reg_linear(h, p + "cross_attn.proj", b.cproj, D, D, true));
         CHK(reg_ln(h, p + "norm2", b.n2, D));
         CHK(reg_ln(h, p + "norm3", b.n3, D));
-        CHK(reg_linear(h, p + "mlp.fc1", b.fc1, R * D, D));
-        CHK(reg_linear(h, p + "mlp.fc2", b.fc2, D, R * D));
+        CHK(reg_linear(h, p + "mlp.fc1", b.fc1, R * D, D, true));
+        CHK(reg_linear(h, p + "mlp.fc2", b.fc2, D, R * D, true));
         CHK(reg_ln(h, p + "norm_y", b.ny, D));
     }
     CHK(reg_ln(h, "dec_norm", h->dec_norm, D));
@@ -300,7 +302,7 @@ extern "C" int sta_create(const sta_config* cfg, int device, sta_handle** out) {
     REQUIRE(cfg->enc_embed_dim % 128 == 0 && cfg->enc_embed_dim <= 1024, "enc_embed_dim must be a multiple of 128, <= 1024");
     REQUIRE(cfg->dec_embed_dim % 128 == 0 && cfg->dec_embed_dim <= 1024, "dec_embed_dim must be a multiple of 128, <= 1024");
     REQUIRE(cfg->dec_depth > 9, "dec_depth must be > 9 (heads/dpt_head.py:102)");
-    REQUIRE(cfg->precision == STA_PREC_F16 || cfg->precision == STA_PREC_F16X3, "unknown precision %d", cfg->precision);
+    REQUIRE(cfg->precision == STA_PREC_F16 || cfg->precision == STA_PREC_F16X3 || cfg->precision == STA_PREC_F16MX, "unknown precision %d", cfg->precision);
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     REQUIRE(device >= 0 && device < ndev, "device %d out of range (%d visible)", device, ndev);
@@ -345,7 +347,7 @@ extern "C" int sta_destroy(sta_handle* h) {
 
 extern "C" int sta_set_precision(sta_handle* h, int precision) {
     REQUIRE(h, "null handle");
-    REQUIRE(precision == STA_PREC_F16 || precision == STA_PREC_F16X3, "unknown precision %d", precision);
+    REQUIRE(precision == STA_PREC_F16 || precision == STA_PREC_F16X3 || precision == STA_PREC_F16MX, "unknown precision %d", precision);
     h->prec = precision;
     return 0;
 }
@@ -393,6 +395,7 @@ extern "C" int sta_load_tensor(sta_handle* h, const char* name, const void* host
                 int mode = s.kind == SK_W_ID ? 0 : (s.kind == SK_W_CONV ? 1 : 2);
                 int d0 = (int)s.shape[0], d1 = ndim > 1 ? (int)s.shape[1] : 1, d2 = ndim > 2 ? (int)s.shape[2] : 1, d3 = ndim > 3 ? (int)s.shape[3] : 1;
                 repack_weight_kernel<<<blocks, 256>>>(h->stage, s.dst_hi, s.dst_lo, n, mode, d0, d1, d2, d3, s.N, s.K, s.n_off);
+                if (s.dst_mx) repack_weight_kernel<<<blocks, 256>>>(h->stage, s.dst_mx, s.dst_mx + 32, n, mode, d0, d1, d2, d3, s.N, s.K, s.n_off, 1);
             }
             HIPCHK(hipGetLastError());
             HIPCHK(hipDeviceSynchronize());
@@ -413,18 +416,18 @@ extern "C" int sta_finalize_weights(sta_handle* h) {
 }
 
 // ------------------------------------------------------------------------------------------ launch helpers
-template <bool SPLIT, int AMODE, int EPI, int BM, int BN, int WMS, int WNS, int NSTG = 2>
+template <bool SPLIT, int AMODE, int EPI, int BM, int BN, int WMS, int WNS, int NSTG = 2, bool MX = false>
 static int launch_gemm2(const GemmParams& p, hipStream_t st) {
     static bool attr_done = false;
     constexpr int smem = gemm2_smem_bytes<SPLIT, BM, BN>(NSTG);
     if (!attr_done) {
-        HIPCHK(hipFuncSetAttribute((const void*)gemm2_kernel<SPLIT, AMODE, EPI, BM, BN, WMS, WNS, 0, NSTG>,
+        HIPCHK(hipFuncSetAttribute((const void*)gemm2_kernel<SPLIT, AMODE, EPI, BM, BN, WMS, WNS, 0, NSTG, MX>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_done = true;
     }
     int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
-    hipLaunchKernelGGL((gemm2_kernel<SPLIT, AMODE, EPI, BM, BN, WMS, WNS, 0, NSTG>), dim3((unsigned)(tm * tn * ks)), dim3(WMS * WNS * 64), smem, st, p);
+    hipLaunchKernelGGL((gemm2_kernel<SPLIT, AMODE, EPI, BM, BN, WMS, WNS, 0, NSTG, MX>), dim3((unsigned)(tm * tn * ks)), dim3(WMS * WNS * 64), smem, st, p);
     return 0;
 }
 
@@ -440,7 +443,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
     REQUIRE(p.M > 0 && p.N > 0, "empty GEMM");
     if (AMODE == A_CONV3) REQUIRE(p.Cin % GEMM_BK == 0, "conv Cin=%d must be a multiple of %d", p.Cin, GEMM_BK);
     if (h->dry) return 0;
-    const bool split = h->prec == STA_PREC_F16X3;
+    const bool split = h->prec != STA_PREC_F16;
     const bool timed = h->ktime && AMODE == A_DENSE && EPI == EPI_F32;
     if (timed) {
         if ((int)h->kev.size() < 2 * (h->kn + 1)) {
@@ -499,7 +502,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
         // extra tiny launches only when the K loop is long and the grid leaves most of the chip idle (swept: <= 96 / 160 /
         // 256 tiles -> DPT 1.00 / 0.85 / 0.83 ms per view).  An in-kernel fix-up (last slice finishes the tile behind a
         // device-scope fence + ticket) was 1.7x SLOWER than this: the fence writes back / invalidates the XCD's L2.
-        if (EPI == EPI_F16 && tiles <= 192 && p.K >= 1024 && p.N % 4 == 0 && (int64_t)p.M * p.N <= SKBUF_ELEMS) {
+        if (EPI == EPI_F16 && !p.c_mx && tiles <= 192 && p.K >= 1024 && p.N % 4 == 0 && (int64_t)p.M * p.N <= SKBUF_ELEMS) {
             int ks = (256 + tiles - 1) / tiles;
             const int max_ks = p.K / 256;                 // keep >= 8 K tiles per slice
             if (ks > max_ks) ks = max_ks;
@@ -514,6 +517,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
     if (h->gemm_variant == 4 && p.N % 128 == 0) variant = 5;
     if (h->gemm_variant == 1) variant = 1;
     if (variant != 6) p.ksplit = 1;
+    if (p.mx && variant != 6) variant = 5;     // f16mx kernels exist for the 192x128 and the small-grid families
     if (timed && variant == 5) p.clk_dbg = h->clk_buf;   // effective-clock probe of the dominant kernel (bench only)
     if (variant == 2) {
         if (split) CHK((launch_gemm2<true, AMODE, EPI, 256, 256, 2, 4>(p, st)));
@@ -525,10 +529,12 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
         if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 256, 2, 4>(p, st)));
         else CHK((launch_gemm2<false, AMODE, EPI, 192, 256, 2, 4>(p, st)));
     } else if (variant == 5) {
-        if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4>(p, st)));
+        if (AMODE == A_DENSE && EPI != EPI_CONVT && p.mx) CHK((launch_gemm2<true, A_DENSE, (EPI == EPI_CONVT ? EPI_F32 : EPI), 192, 128, 2, 4, 2, true>(p, st)));
+        else if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4>(p, st)));
         else CHK((launch_gemm2<false, AMODE, EPI, 192, 128, 2, 4>(p, st)));
     } else if (variant == 6) {
-        if (split) CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 2, 2, 3>(p, st)));
+        if (AMODE == A_DENSE && EPI != EPI_CONVT && p.mx) CHK((launch_gemm2<true, A_DENSE, (EPI == EPI_CONVT ? EPI_F32 : EPI), 128, 64, 2, 2, 3, true>(p, st)));
+        else if (split) CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 2, 2, 3>(p, st)));
         else CHK((launch_gemm2<false, AMODE, EPI, 128, 64, 2, 2, 3>(p, st)));
         if (EPI == EPI_F16 && p.ksplit > 1) {
             const int64_t n4 = (int64_t)p.M * (p.N / 4);
@@ -556,32 +562,37 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
     return 0;
 }
 
-static GemmParams gp_dense(const Planes& A, int lda, const Lin& W, int M) {
+// mx: A is in the f16mx row format and the f16mx copy of the weight is used (transformer linears in precision f16mx)
+static GemmParams gp_dense(const Planes& A, int lda, const Lin& W, int M, bool mx = false) {
     GemmParams p; memset(&p, 0, sizeof p);
     p.A_hi = A.hi; p.A_lo = A.lo; p.lda = lda; p.a_rp = A.rp;
-    p.B_hi = W.w.hi; p.B_lo = W.w.lo; p.bias = W.bias;
+    p.B_hi = mx ? W.wmx.hi : W.w.hi; p.B_lo = mx ? W.wmx.lo : W.w.lo; p.bias = W.bias;
+    p.mx = mx ? 1 : 0;
     p.M = M; p.N = W.N; p.K = W.K;
     return p;
 }
 
 // out fp32 = A*W^T + bias (+resid), optional row remap
+static bool use_mx(const sta_handle* h, const Lin& W) { return h->prec == STA_PREC_F16MX && W.wmx.hi != nullptr; }
+
 static int gemm_f32(sta_handle* h, const Planes& A, const Lin& W, int M, float* out, int ldc,
                     const float* resid, hipStream_t st, int rows_in = 0, int rows_out = 0, int row_off = 0) {
-    GemmParams p = gp_dense(A, W.K, W, M);
+    GemmParams p = gp_dense(A, W.K, W, M, use_mx(h, W));
     p.C32 = out; p.ldc = ldc; p.resid = resid; p.ldr = ldc;
     p.rows_in = rows_in; p.rows_out = rows_out; p.row_off = row_off;
     return launch_gemm<A_DENSE, EPI_F32>(h, p, st);
 }
-static int gemm_f16(sta_handle* h, const Planes& A, const Lin& W, int M, const Planes& out, int act, hipStream_t st) {
-    GemmParams p = gp_dense(A, W.K, W, M);
-    p.C_hi = out.hi; p.C_lo = out.lo; p.ldc16 = W.N; p.act = act; p.c_rp = out.rp;
+// c_mx: the output planes feed an f16mx GEMM (mlp.fc1 -> GELU -> mlp.fc2)
+static int gemm_f16(sta_handle* h, const Planes& A, const Lin& W, int M, const Planes& out, int act, hipStream_t st, bool c_mx = false) {
+    GemmParams p = gp_dense(A, W.K, W, M, use_mx(h, W));
+    p.C_hi = out.hi; p.C_lo = out.lo; p.ldc16 = W.N; p.act = act; p.c_rp = out.rp; p.c_mx = c_mx ? 1 : 0;
     REQUIRE(h->dry || (A.rp >= M && out.rp >= M), "internal: plane rows mismatch in gemm_f16");
     return launch_gemm<A_DENSE, EPI_F16>(h, p, st);
 }
 struct QKVOut { Planes q, k, vt; int npad; };
 static int gemm_qkv(sta_handle* h, const Planes& A, const Lin& W, int M, int nq, int nk, int nv,
                     const QKVOut& o, int ntok, int heads, int wp, int has_pose, hipStream_t st) {
-    GemmParams p = gp_dense(A, W.K, W, M);
+    GemmParams p = gp_dense(A, W.K, W, M, use_mx(h, W));
     p.Q_hi = o.q.hi; p.Q_lo = o.q.lo; p.K_hi = o.k.hi; p.K_lo = o.k.lo; p.Vt_hi = o.vt.hi; p.Vt_lo = o.vt.lo;
     p.nq = nq; p.nk = nk; p.nv = nv; p.ntok = ntok; p.npad = o.npad; p.heads = heads; p.wp = wp; p.has_pose_tok = has_pose;
     p.rope_tab = h->rope_tab;
@@ -614,30 +625,32 @@ static int conv3(sta_handle* h, const Planes& in, int nimg, int Hi, int Wi, int 
 }
 
 static int run_ln(sta_handle* h, const float* x, int M, int C, const LNp& a, const Planes& oa,
-                  const LNp* b, const Planes* ob, float* o32, hipStream_t st) {
+                  const LNp* b, const Planes* ob, float* o32, hipStream_t st, bool allow_mx = true) {
     if (h->dry) return 0;
     LnParams p; memset(&p, 0, sizeof p);
+    p.mx = (allow_mx && h->prec == STA_PREC_F16MX) ? 1 : 0;     // every LayerNorm on the path feeds a transformer linear
     p.x = x; p.ldx = C; p.M = M; p.C = C; p.eps = h->cfg.ln_eps;
     p.g1 = a.g; p.b1 = a.b; p.o1_hi = oa.hi; p.o1_lo = oa.lo;
     if (b) { p.g2 = b->g; p.b2 = b->b; p.o2_hi = ob->hi; p.o2_lo = ob->lo; }
     p.o32 = o32; p.ldo32 = C;
     dim3 grid((M + 3) / 4);
-    if (h->prec == STA_PREC_F16X3) hipLaunchKernelGGL(ln_kernel<true>, grid, dim3(256), 0, st, p);
+    if (h->prec != STA_PREC_F16) hipLaunchKernelGGL(ln_kernel<true>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(ln_kernel<false>, grid, dim3(256), 0, st, p);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
 static int run_attn(sta_handle* h, const QKVOut& qkv, const Planes& out, int ldo, int S, int heads,
-                    int nq, int nk, int kv_shift, hipStream_t st) {
+                    int nq, int nk, int kv_shift, hipStream_t st, bool allow_mx = true) {
     if (h->dry) return 0;
     AttnParams p; memset(&p, 0, sizeof p);
+    p.o_mx = (allow_mx && h->prec == STA_PREC_F16MX) ? 1 : 0;   // attention output feeds attn.proj / cross_attn.proj
     p.Q_hi = qkv.q.hi; p.Q_lo = qkv.q.lo; p.K_hi = qkv.k.hi; p.K_lo = qkv.k.lo; p.Vt_hi = qkv.vt.hi; p.Vt_lo = qkv.vt.lo;
     p.O_hi = out.hi; p.O_lo = out.lo; p.ldo = ldo;
     p.S = S; p.heads = heads; p.nq = nq; p.nk = nk; p.npad = qkv.npad; p.kv_shift = kv_shift;
     p.scale_log2e = 0.125f * 1.44269504088896340736f;
     dim3 grid((unsigned)(((nq + 127) / 128) * heads * S));
-    if (h->prec == STA_PREC_F16X3) {
+    if (h->prec != STA_PREC_F16) {
         static bool attr_done = false;
         if (!attr_done) { hipFuncSetAttribute((const void*)attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_smem_bytes<true>()); attr_done = true; }
         hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), attn_smem_bytes<true>(), st, p);
@@ -648,12 +661,12 @@ static int run_attn(sta_handle* h, const QKVOut& qkv, const Planes& out, int ldo
     return 0;
 }
 
-static int run_rows_to_planes(sta_handle* h, const float* x, int64_t bstride, int nb, int rows, int C, const Planes& o, hipStream_t st, int64_t obstride = 0) {
+static int run_rows_to_planes(sta_handle* h, const float* x, int64_t bstride, int nb, int rows, int C, const Planes& o, hipStream_t st, int64_t obstride = 0, bool mx = false) {
     if (h->dry) return 0;
     int64_t total4 = (int64_t)nb * rows * C / 4;
     int blocks = (int)((total4 + 255) / 256); if (blocks > 8192) blocks = 8192;
-    if (h->prec == STA_PREC_F16X3) hipLaunchKernelGGL(rows_to_planes_kernel<true>, dim3(blocks), dim3(256), 0, st, x, bstride, rows, C, total4, o.hi, o.lo, obstride, o.rp);
-    else hipLaunchKernelGGL(rows_to_planes_kernel<false>, dim3(blocks), dim3(256), 0, st, x, bstride, rows, C, total4, o.hi, o.lo, obstride, o.rp);
+    if (h->prec != STA_PREC_F16) hipLaunchKernelGGL(rows_to_planes_kernel<true>, dim3(blocks), dim3(256), 0, st, x, bstride, rows, C, total4, o.hi, o.lo, obstride, o.rp, mx ? 1 : 0);
+    else hipLaunchKernelGGL(rows_to_planes_kernel<false>, dim3(blocks), dim3(256), 0, st, x, bstride, rows, C, total4, o.hi, o.lo, obstride, o.rp, 0);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -662,7 +675,7 @@ static int run_up2(sta_handle* h, const Planes& in, int n, int Hi, int Wi, int C
     if (h->dry) return 0;
     int64_t total = (int64_t)n * Hc * Wc * (C / 8);
     int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
-    if (h->prec == STA_PREC_F16X3) hipLaunchKernelGGL(bilinear_up2_kernel<true>, dim3(blocks), dim3(256), 0, st, in.hi, in.lo, n, Hi, Wi, C, Hc, Wc, out.hi, out.lo);
+    if (h->prec != STA_PREC_F16) hipLaunchKernelGGL(bilinear_up2_kernel<true>, dim3(blocks), dim3(256), 0, st, in.hi, in.lo, n, Hi, Wi, C, Hc, Wc, out.hi, out.lo);
     else hipLaunchKernelGGL(bilinear_up2_kernel<false>, dim3(blocks), dim3(256), 0, st, in.hi, in.lo, n, Hi, Wi, C, Hc, Wc, out.hi, out.lo);
     HIPCHK(hipGetLastError());
     return 0;
@@ -694,7 +707,7 @@ static inline int rup(int x, int m) { return (x + m - 1) / m * m; }
 static int encode_impl(sta_handle* h, Bump& ws, const void* const* imgs, bool u8hwc, int nsets, int B, int H, int W,
                        float* feat, hipStream_t st) {
     const sta_config& c = h->cfg;
-    const bool split = h->prec == STA_PREC_F16X3;
+    const bool split = h->prec != STA_PREC_F16;
     const int E = c.enc_embed_dim, Hh = c.enc_num_heads, hp = H / 16, wp = W / 16, N = hp * wp;
     const int n = nsets * B, M = n * N, npad = rup(N, 64);
     Planes patches = ws.act(M, 768, split);
@@ -728,7 +741,7 @@ static int encode_impl(sta_handle* h, Bump& ws, const void* const* imgs, bool u8
         CHK(run_attn(h, qkv, ao, E, n, Hh, N, N, 0, st));
         CHK(gemm_f32(h, ao, b.proj, M, feat, E, feat, st));
         CHK(run_ln(h, feat, M, E, b.n2, lnp, nullptr, nullptr, nullptr, st));
-        CHK(gemm_f16(h, lnp, b.fc1, M, f1, ACT_GELU, st));
+        CHK(gemm_f16(h, lnp, b.fc1, M, f1, ACT_GELU, st, use_mx(h, b.fc2)));
         CHK(gemm_f32(h, f1, b.fc2, M, feat, E, feat, st));
     }
     return 0;
@@ -740,7 +753,7 @@ static int encode_impl(sta_handle* h, Bump& ws, const void* const* imgs, bool u8
 static int decode_impl(sta_handle* h, Bump& ws, const float* feat1, const float* feat2, int B, int hp, int wp,
                        float* x, float* const* want1, float* const* want2, hipStream_t st) {
     const sta_config& c = h->cfg;
-    const bool split = h->prec == STA_PREC_F16X3;
+    const bool split = h->prec != STA_PREC_F16;
     const int E = c.enc_embed_dim, D = c.dec_embed_dim, Hh = c.dec_num_heads;
     const int N = hp * wp, Np = N + 1, S = 2 * B, M = S * Np, npad = rup(Np, 64);
     Planes fp = ws.act((int64_t)S * N, E, split);
@@ -782,7 +795,7 @@ static int decode_impl(sta_handle* h, Bump& ws, const float* feat1, const float*
         CHK(run_attn(h, qkv, ao, D, S, Hh, Np, Np, B, st));
         CHK(gemm_f32(h, ao, b.cproj, M, x, D, x, st));
         CHK(run_ln(h, x, M, D, b.n3, a1, nullptr, nullptr, nullptr, st));
-        CHK(gemm_f16(h, a1, b.fc1, M, f1, ACT_GELU, st));
+        CHK(gemm_f16(h, a1, b.fc1, M, f1, ACT_GELU, st, use_mx(h, b.fc2)));
         CHK(gemm_f32(h, f1, b.fc2, M, x, D, x, st));
         if (i + 1 < c.dec_depth) {
             CHK(emit(i + 1));
@@ -831,7 +844,7 @@ static int dpt_impl(sta_handle* h, Bump& ws, const float* enc, int64_t enc_bs,
                     const float* h1, int64_t h1_bs, const float* h2, int64_t h2_bs, const float* h3, int64_t h3_bs,
                     int n, int H, int W, float* ptsA, float* confA, int nA, float* ptsB, float* confB, hipStream_t st) {
     const sta_config& c = h->cfg;
-    const bool split = h->prec == STA_PREC_F16X3;
+    const bool split = h->prec != STA_PREC_F16;
     const int E = c.enc_embed_dim, D = c.dec_embed_dim, hp = H / 16, wp = W / 16, N = hp * wp;
     const int M = n * N;
     Planes t0 = ws.act(M, E, split), t1 = ws.act(M, D, split);
@@ -1483,7 +1496,7 @@ extern "C" int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, int
     REQUIRE(h && ms_out && iters > 0, "bad argument");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
-    const bool split = h->prec == STA_PREC_F16X3;
+    const bool split = h->prec != STA_PREC_F16;
     int64_t bytes = ((int64_t)M * K + (int64_t)N * K) * 4 + (int64_t)M * N * 4 + N * 4 + (1 << 16);
     CHK(ensure_ws(h, bytes));
     h->dry = false;
@@ -1530,6 +1543,10 @@ extern "C" int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, int
         if (tile == 3) return bench_launch2<256, 128, 4, 2, 0>(split, p, st);
         if (tile == 10) return split ? launch_gemm2<true, A_DENSE, EPI_F32, 256, 128, 4, 2, 3>(p, st)
                                      : launch_gemm2<false, A_DENSE, EPI_F32, 256, 128, 4, 2, 3>(p, st);   // 3-stage ring experiment
+        if (tile == 16) { GemmParams q = p; q.mx = 1; return launch_gemm2<true, A_DENSE, EPI_F32, 192, 128, 2, 4, 2, true>(q, st); }   // the shipped f16mx kernel (random bits as operands: timing only)
+        if (tile == 17) { GemmParams q = p; q.mx = 1; q.resid = q.C32; q.ldr = q.ldc; return launch_gemm2<true, A_DENSE, EPI_F32, 192, 128, 2, 4, 2, true>(q, st); }
+        if (tile == 14) return bench_launch2<256, 256, 2, 4, 16>(split, p, st);  // instruction mix of the MX-fp8 correction scheme (not a GEMM)
+        if (tile == 15) return bench_launch2<192, 128, 2, 4, 16>(split, p, st);
         if (tile == 11) return bench_launch2<256, 256, 2, 4, 8>(split, p, st);   // staggered DMA issue
         if (tile == 12) return bench_launch2<192, 128, 2, 4, 8>(split, p, st);
         if (tile == 5) return bench_launch2<192, 256, 2, 4, 0>(split, p, st);

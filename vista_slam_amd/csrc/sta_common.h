@@ -64,5 +64,64 @@ __device__ __forceinline__ size_t blk_off(int64_t row, int col, int64_t rows) {
     return ((size_t)(col >> 5) * rows + row) * (SPLIT ? 64 : 32) + (col & 31);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Precision f16mx ("f16 main product + block-scaled fp8 corrections"): x ~= hi + lo as in f16x3, but the two correction
+// products Al*Bh + Ah*Bl are issued as ONE v_mfma_scale_f32_32x32x64_f8f6f4 (2x the f16 MFMA rate) on fp8-e4m3 copies.
+// Row block of 32 k (128 B: same size and the same blocked layout as f16x3):
+//     [ hi f16 x32 (64 B) | 32 byte pairs (64 B) ]
+//   activation pair k = ( e4m3(hi * 2^0),  e4m3(lo * 2^11) )        (|lo| <= 2^-11 |hi|)
+//   weight     pair k = ( e4m3(lo * 2^15), e4m3(hi * 2^4)  )        (|w| << 1) - the OPPOSITE order, so that byte q of
+//   an activation row meets byte q of a weight row as hi8 x lo8 / lo8 x hi8, i.e. exactly the two correction products;
+//   both carry the same combined scale 2^-(0+15) = 2^-(11+4) = 2^-15, applied by the instruction's E8M0 block scales.
+// Relative error of a GEMM ~1e-5 (f16x3: 9e-7, one-product f16: 3e-4) - measured in tests/test_gpu_kernels.py.
+#define STA_MX_A_SHI 0
+#define STA_MX_A_SLO 11
+#define STA_MX_W_SHI 4
+#define STA_MX_W_SLO 15
+static_assert(STA_MX_A_SHI + STA_MX_W_SLO == STA_MX_A_SLO + STA_MX_W_SHI, "both correction products must share one scale");
+
+__device__ __forceinline__ float clamp_e4m3(float x) { return fminf(fmaxf(x, -448.f), 448.f); }
+// (first, second) -> two OCP e4m3 bytes (RNE, saturating) in the low / high 16 bits of `old`
+__device__ __forceinline__ int cvt2_e4m3(float first, float second, int old, bool high) {
+    return high ? __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(first), clamp_e4m3(second), old, true)
+                : __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(first), clamp_e4m3(second), old, false);
+}
+struct MX4 { uint2 hi; uint2 pairs; };
+template <bool WEIGHT>
+__device__ __forceinline__ MX4 split_mx4(const float y[4]) {
+    constexpr float KHI = WEIGHT ? (float)(1 << STA_MX_W_SHI) : (float)(1 << STA_MX_A_SHI);
+    constexpr float KLO = WEIGHT ? (float)(1 << STA_MX_W_SLO) : (float)(1 << STA_MX_A_SLO);
+    union { uint2 u; f16 e[4]; } h;
+    float a[4], b[4];            // first / second byte of every pair
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = fminf(fmaxf(y[e], -STA_F16_MAX), STA_F16_MAX);
+        h.e[e] = (f16)x;
+        const float hf = (float)h.e[e], lf = x - hf;
+        a[e] = WEIGHT ? lf * KLO : hf * KHI;
+        b[e] = WEIGHT ? hf * KHI : lf * KLO;
+    }
+    MX4 r; r.hi = h.u;
+    int w0 = cvt2_e4m3(a[0], b[0], 0, false); w0 = cvt2_e4m3(a[1], b[1], w0, true);
+    int w1 = cvt2_e4m3(a[2], b[2], 0, false); w1 = cvt2_e4m3(a[3], b[3], w1, true);
+    r.pairs = make_uint2((unsigned)w0, (unsigned)w1);
+    return r;
+}
+// o = blk_off<true>(row, col, rows) with col % 4 == 0: hi at base + o, the byte pairs in the second half of the row block
+__device__ __forceinline__ void store_mx4(f16* base, size_t o, const MX4& v) {
+    *reinterpret_cast<uint2*>(base + o) = v.hi;
+    *reinterpret_cast<uint2*>(base + o + 32) = v.pairs;          // +64 B, 2 B per element: same offset arithmetic as the lo plane
+}
+template <bool WEIGHT>
+__device__ __forceinline__ void store_mx1(f16* base, size_t o, float x) {     // scalar variant (column-per-lane epilogues)
+    constexpr float KHI = WEIGHT ? (float)(1 << STA_MX_W_SHI) : (float)(1 << STA_MX_A_SHI);
+    constexpr float KLO = WEIGHT ? (float)(1 << STA_MX_W_SLO) : (float)(1 << STA_MX_A_SLO);
+    x = fminf(fmaxf(x, -STA_F16_MAX), STA_F16_MAX);
+    const f16 h = (f16)x; const float hf = (float)h, lf = x - hf;
+    const int b = WEIGHT ? cvt2_e4m3(lf * KLO, hf * KHI, 0, false) : cvt2_e4m3(hf * KHI, lf * KLO, 0, false);
+    base[o] = h;
+    reinterpret_cast<unsigned short*>(base)[o + 32] = (unsigned short)(b & 0xFFFF);
+}
+
 union H8 { uint4 u; half8 h; f16 e[8]; };
 union H4 { uint2 u; half4 h; f16 e[4]; };
