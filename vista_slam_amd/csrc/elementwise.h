@@ -226,7 +226,7 @@ __global__ void fill_pose_token_kernel(float* x, int S, int ntok, int D, const f
 // the full (2Hi,2Wi) grid.  One thread = 8 channels of one output pixel.
 template <bool SPLIT>
 __global__ void bilinear_up2_kernel(const f16* i_hi, const f16* i_lo, int n, int Hi, int Wi, int C,
-                                    int Hc, int Wc, f16* o_hi, f16* o_lo) {
+                                    int Hc, int Wc, f16* o_hi, f16* o_lo, int mx = 0 /* input and output are f16mx rows */) {
     const int c8 = C / 8;
     const int64_t total = (int64_t)n * Hc * Wc * c8;
     const float ry = Hi > 1 ? (float)(Hi - 1) / (float)(2 * Hi - 1) : 0.f;
@@ -248,17 +248,30 @@ __global__ void bilinear_up2_kernel(const f16* i_hi, const f16* i_lo, int n, int
         H8 al, bl, cl, dl;
         if (SPLIT) { al.u = ldg16(i_hi + o00 + 32); bl.u = ldg16(i_hi + o01 + 32); cl.u = ldg16(i_hi + o10 + 32); dl.u = ldg16(i_hi + o11 + 32); }
         H8 oh, ol;
+        float vout[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float v00 = (float)a.e[e], v01 = (float)b_.e[e], v10 = (float)c_.e[e], v11 = (float)d.e[e];
+            if (SPLIT && mx) {       // the second field holds (hi8, lo8) byte pairs: value = hi + lo8 * 2^-11
+                constexpr float KL = 1.0f / (float)(1 << STA_MX_A_SLO);
+                v00 += __builtin_amdgcn_cvt_f32_fp8(reinterpret_cast<const unsigned short*>(&al)[e], 1) * KL;
+                v01 += __builtin_amdgcn_cvt_f32_fp8(reinterpret_cast<const unsigned short*>(&bl)[e], 1) * KL;
+                v10 += __builtin_amdgcn_cvt_f32_fp8(reinterpret_cast<const unsigned short*>(&cl)[e], 1) * KL;
+                v11 += __builtin_amdgcn_cvt_f32_fp8(reinterpret_cast<const unsigned short*>(&dl)[e], 1) * KL;
+            } else
             if (SPLIT) { v00 += (float)al.e[e]; v01 += (float)bl.e[e]; v10 += (float)cl.e[e]; v11 += (float)dl.e[e]; }
             // same association as ATen upsample_bilinear2d: h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)
             float top = (1.f - fx) * v00 + fx * v01;
             float bot = (1.f - fx) * v10 + fx * v11;
             float v = (1.f - fy) * top + fy * bot;
+            vout[e] = v;
             if (SPLIT) split_f16(v, oh.e[e], ol.e[e]); else oh.e[e] = to_f16_sat(v);
         }
         const size_t o = blk_off<SPLIT>(((size_t)b * Hc + y) * Wc + x, c, (int64_t)n * Hc * Wc);
+        if (SPLIT && mx) {
+            store_mx4(o_hi, o, split_mx4<false>(vout)); store_mx4(o_hi, o + 4, split_mx4<false>(vout + 4));
+            continue;
+        }
         *reinterpret_cast<uint4*>(o_hi + o) = oh.u;
         if (SPLIT) *reinterpret_cast<uint4*>(o_hi + o + 32) = ol.u;
     }
@@ -272,7 +285,7 @@ __global__ void bilinear_up2_kernel(const f16* i_hi, const f16* i_lo, int n, int
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void head_final_kernel(const f16* i_hi, const f16* i_lo, int64_t pix0, int64_t irows, int64_t npix,
                                                          const float* w /*[4][128]*/, const float* bias /*[4]*/,
-                                                         float* pts, float* conf) {
+                                                         float* pts, float* conf, int mx = 0 /* input planes are f16mx rows */) {
     const int sub = threadIdx.x & 15;
     int64_t pix = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int64_t step = ((int64_t)gridDim.x * blockDim.x) >> 4;
@@ -292,7 +305,9 @@ __global__ __launch_bounds__(256) void head_final_kernel(const f16* i_hi, const 
             H8 al; if (SPLIT) al.u = ldg16(i_hi + o + 32);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float v = (float)a.e[e]; if (SPLIT) v += (float)al.e[e];
+                float v = (float)a.e[e];
+                if (SPLIT && mx) v += __builtin_amdgcn_cvt_f32_fp8(reinterpret_cast<const unsigned short*>(&al)[e], 1) * (1.0f / (float)(1 << STA_MX_A_SLO));
+                else if (SPLIT) v += (float)al.e[e];
 #pragma unroll
                 for (int o = 0; o < 4; ++o) acc[o] += v * wv[o][e];
             }

@@ -41,7 +41,8 @@ struct GemmParams {
                                                          //     holds the residual); bias is added by slice 0 only
     // ---- EPI_F16
     f16* C_hi; f16* C_lo; int ldc16; int act;            // blocked output planes with c_rp rows (ldc16 unused)
-    int c_mx;                                            // EPI_F16 output in the f16mx row format (consumer = f16mx GEMM)
+    int c_mx;                                            // EPI_F16 / EPI_CONVT output in the f16mx row format (consumer = f16mx GEMM)
+    int r_mx;                                            // residual planes R1 / R2 are f16mx rows
     int64_t c_rp;
     float* skbuf = nullptr;                              // EPI_F16 split-K: fp32 partial sums [M,N] (zeroed); splitk_finish_kernel
                                                          //     applies bias / activation / residual planes and writes the planes
@@ -191,8 +192,13 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
                 if (p.act == ACT_GELU) v = gelu_erf(v);
                 else if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
                 const size_t o = blk_off<SPLIT>(row, col, p.c_rp);
-                if (p.R1_hi) { v += (float)p.R1_hi[o]; if (SPLIT) v += (float)p.R1_hi[o + 32]; }
-                if (p.R2_hi) { v += (float)p.R2_hi[o]; if (SPLIT) v += (float)p.R2_hi[o + 32]; }
+                if (SPLIT && p.r_mx) {
+                    if (p.R1_hi) v += load_mx_act(p.R1_hi, o);
+                    if (p.R2_hi) v += load_mx_act(p.R2_hi, o);
+                } else {
+                    if (p.R1_hi) { v += (float)p.R1_hi[o]; if (SPLIT) v += (float)p.R1_hi[o + 32]; }
+                    if (p.R2_hi) { v += (float)p.R2_hi[o]; if (SPLIT) v += (float)p.R2_hi[o + 32]; }
+                }
                 if (SPLIT && p.c_mx) store_mx1<false>(p.C_hi, o, v);
                 else if (SPLIT) { f16 h, l; split_f16(v, h, l); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
                 else p.C_hi[o] = to_f16_sat(v);
@@ -206,7 +212,8 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
                 int y = rem / p.ct_w, x = rem - y * p.ct_w;
                 const size_t opix = ((size_t)img * (p.ct_h * p.ct_k) + (y * p.ct_k + dy)) * (p.ct_w * p.ct_k) + (x * p.ct_k + dx);
                 const size_t o = blk_off<SPLIT>(opix, co, p.c_rp);
-                if (SPLIT) { f16 h, l; split_f16(v, h, l); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
+                if (SPLIT && p.c_mx) store_mx1<false>(p.C_hi, o, v);
+                else if (SPLIT) { f16 h, l; split_f16(v, h, l); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
                 else p.C_hi[o] = to_f16_sat(v);
             }
         }

@@ -206,7 +206,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
             for (int ks = 0; ks < 2; ++ks) {
                 const int chunk = ks * 2 + lhi;
 #pragma unroll
-                for (int i = 0; i < MT; ++i) ah[i] = *reinterpret_cast<const half8*>(sA + lds2_off<true>(wm * WM + i * 32 + l31, chunk));
+                for (int i = 0; i < MT; ++i) {
+                    ah[i] = *reinterpret_cast<const half8*>(sA + lds2_off<true>(wm * WM + i * 32 + l31, chunk));
+                    if (AMODE == A_CONV3 && p.relu_in) {      // relu on the f16 hi fragment (packed sign masks, see the f16x3 path)
+                        union { half8 h; unsigned u[4]; } t; t.h = ah[i];
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) { const unsigned sgn = (t.u[w] >> 15) & 0x00010001u; t.u[w] &= ~((sgn << 16) - sgn); }
+                        ah[i] = t.h;
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < NT; ++j) bh[j] = *reinterpret_cast<const half8*>(sB + lds2_off<true>(wn * WN + j * 32 + l31, chunk));
 #pragma unroll
@@ -222,6 +230,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
                 const int ra = wm * WM + i * 32 + l31;
                 a8[i].q.x = *reinterpret_cast<const int4v*>(sA + lds2_off<true>(ra, 4 + 2 * lhi));
                 a8[i].q.y = *reinterpret_cast<const int4v*>(sA + lds2_off<true>(ra, 5 + 2 * lhi));
+                if (AMODE == A_CONV3 && p.relu_in) {          // a pair (hi8, lo8) is 16 bits: zero it when hi8 is negative
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) { const unsigned u = (unsigned)a8[i].v[w]; const unsigned sgn = (u >> 7) & 0x00010001u; a8[i].v[w] = (int)(u & ~((sgn << 16) - sgn)); }
+                }
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {

@@ -29,7 +29,7 @@ static int set_err(const char* fmt, ...) {
 // ------------------------------------------------------------------------------------------ types
 // fp16 planes.  Activations / weights use the K-tile-blocked layout [cols/32][rp rows][hi32|lo32]
 // (lo == hi + 32 in f16x3, lo == nullptr in f16); rp == 0 marks the row-major Q/K/V^T buffers.
-struct Planes { f16* hi = nullptr; f16* lo = nullptr; int64_t rp = 0; };
+struct Planes { f16* hi = nullptr; f16* lo = nullptr; int64_t rp = 0; bool mx = false; };   // mx: rows in the f16mx format (DPT buffers carry it explicitly)
 static inline Planes slice_rows(const Planes& p, int64_t r0) {
     Planes q = p; const int64_t es = p.lo ? 64 : 32;
     q.hi = p.hi + r0 * es; if (p.lo) q.lo = q.hi + 32;
@@ -178,13 +178,13 @@ static int reg_ln(sta_handle* h, const std::string& name, LNp& n, int C) {
 }
 // conv weight [Co,Ci,k,k] -> packed [Co][k][k][Ci]
 static int reg_conv(sta_handle* h, const std::string& name, Lin& L, int Co, int Ci, int k, bool bias) {
-    CHK(make_lin(h, L, Co, Ci * k * k, bias));
+    CHK(make_lin(h, L, Co, Ci * k * k, bias, true));
     slot_w(h, name + ".weight", {Co, Ci, k, k}, k == 1 ? SK_W_ID : SK_W_CONV, L);
     if (bias) slot_f32(h, name + ".bias", {Co}, L.bias);
     return 0;
 }
 static int reg_convt(sta_handle* h, const std::string& name, Lin& L, int C, int k) {
-    CHK(make_lin(h, L, k * k * C, C));
+    CHK(make_lin(h, L, k * k * C, C, true, true));
     slot_w(h, name + ".weight", {C, C, k, k}, SK_W_CONVT, L);
     Slot s; s.shape = {C}; s.kind = SK_B_CONVT; s.dst32 = L.bias; s.reps = k * k;
     h->slots[name + ".bias"] = s;
@@ -502,7 +502,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
         // extra tiny launches only when the K loop is long and the grid leaves most of the chip idle (swept: <= 96 / 160 /
         // 256 tiles -> DPT 1.00 / 0.85 / 0.83 ms per view).  An in-kernel fix-up (last slice finishes the tile behind a
         // device-scope fence + ticket) was 1.7x SLOWER than this: the fence writes back / invalidates the XCD's L2.
-        if (EPI == EPI_F16 && !p.c_mx && tiles <= 192 && p.K >= 1024 && p.N % 4 == 0 && (int64_t)p.M * p.N <= SKBUF_ELEMS) {
+        if (EPI == EPI_F16 && !p.c_mx && !p.r_mx && tiles <= 192 && p.K >= 1024 && p.N % 4 == 0 && (int64_t)p.M * p.N <= SKBUF_ELEMS) {
             int ks = (256 + tiles - 1) / tiles;
             const int max_ks = p.K / 256;                 // keep >= 8 K tiles per slice
             if (ks > max_ks) ks = max_ks;
@@ -529,11 +529,11 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
         if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 256, 2, 4>(p, st)));
         else CHK((launch_gemm2<false, AMODE, EPI, 192, 256, 2, 4>(p, st)));
     } else if (variant == 5) {
-        if (AMODE == A_DENSE && EPI != EPI_CONVT && p.mx) CHK((launch_gemm2<true, A_DENSE, (EPI == EPI_CONVT ? EPI_F32 : EPI), 192, 128, 2, 4, 2, true>(p, st)));
+        if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4, 2, true>(p, st)));
         else if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4>(p, st)));
         else CHK((launch_gemm2<false, AMODE, EPI, 192, 128, 2, 4>(p, st)));
     } else if (variant == 6) {
-        if (AMODE == A_DENSE && EPI != EPI_CONVT && p.mx) CHK((launch_gemm2<true, A_DENSE, (EPI == EPI_CONVT ? EPI_F32 : EPI), 128, 64, 2, 2, 3, true>(p, st)));
+        if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 2, 2, 3, true>(p, st)));
         else if (split) CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 2, 2, 3>(p, st)));
         else CHK((launch_gemm2<false, AMODE, EPI, 128, 64, 2, 2, 3>(p, st)));
         if (EPI == EPI_F16 && p.ksplit > 1) {
@@ -573,7 +573,8 @@ static GemmParams gp_dense(const Planes& A, int lda, const Lin& W, int M, bool m
 }
 
 // out fp32 = A*W^T + bias (+resid), optional row remap
-static bool use_mx(const sta_handle* h, const Lin& W) { return h->prec == STA_PREC_F16MX && W.wmx.hi != nullptr; }
+// an f16mx kernel exists for every tile family with N % 64 == 0 (the one exception on the path: act_postprocess[0], N = 96)
+static bool use_mx(const sta_handle* h, const Lin& W) { return h->prec == STA_PREC_F16MX && W.wmx.hi != nullptr && W.N % 64 == 0; }
 
 static int gemm_f32(sta_handle* h, const Planes& A, const Lin& W, int M, float* out, int ldc,
                     const float* resid, hipStream_t st, int rows_in = 0, int rows_out = 0, int row_off = 0) {
@@ -587,6 +588,7 @@ static int gemm_f16(sta_handle* h, const Planes& A, const Lin& W, int M, const P
     GemmParams p = gp_dense(A, W.K, W, M, use_mx(h, W));
     p.C_hi = out.hi; p.C_lo = out.lo; p.ldc16 = W.N; p.act = act; p.c_rp = out.rp; p.c_mx = c_mx ? 1 : 0;
     REQUIRE(h->dry || (A.rp >= M && out.rp >= M), "internal: plane rows mismatch in gemm_f16");
+    REQUIRE(h->dry || !A.mx || p.mx, "internal: f16mx input rows for a GEMM without an f16mx kernel");
     return launch_gemm<A_DENSE, EPI_F16>(h, p, st);
 }
 struct QKVOut { Planes q, k, vt; int npad; };
@@ -603,8 +605,9 @@ static int gemm_qkv(sta_handle* h, const Planes& A, const Lin& W, int M, int nq,
 }
 static int gemm_convt(sta_handle* h, const Planes& A, const Lin& W, int nimg, int hh, int ww, int k, int cout,
                       const Planes& out, hipStream_t st) {
-    GemmParams p = gp_dense(A, W.K, W, nimg * hh * ww);
-    p.C_hi = out.hi; p.C_lo = out.lo; p.ct_k = k; p.ct_cout = cout; p.ct_h = hh; p.ct_w = ww; p.c_rp = out.rp;
+    GemmParams p = gp_dense(A, W.K, W, nimg * hh * ww, use_mx(h, W));
+    REQUIRE(h->dry || A.mx == (p.mx != 0), "internal: ConvT input format mismatch");
+    p.C_hi = out.hi; p.C_lo = out.lo; p.ct_k = k; p.ct_cout = cout; p.ct_h = hh; p.ct_w = ww; p.c_rp = out.rp; p.c_mx = out.mx ? 1 : 0;
     return launch_gemm<A_DENSE, EPI_CONVT>(h, p, st);
 }
 // 3x3 conv, pad 1, NHWC planes
@@ -614,13 +617,16 @@ static int conv3(sta_handle* h, const Planes& in, int nimg, int Hi, int Wi, int 
     p.A_hi = in.hi; p.A_lo = in.lo; p.a_rp = in.rp;
     p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.cstride = stride; p.relu_in = relu_in ? 1 : 0;
     p.Ho = (Hi + 2 - 3) / stride + 1; p.Wo = (Wi + 2 - 3) / stride + 1;
-    p.B_hi = W.w.hi; p.B_lo = W.w.lo; p.bias = W.bias;
+    const bool mx = use_mx(h, W);
+    REQUIRE(h->dry || in.mx == mx, "internal: conv input format mismatch");
+    p.mx = mx ? 1 : 0;
+    p.B_hi = mx ? W.wmx.hi : W.w.hi; p.B_lo = mx ? W.wmx.lo : W.w.lo; p.bias = W.bias;
     p.M = nimg * p.Ho * p.Wo; p.N = W.N; p.K = W.K;
     REQUIRE(W.K == 9 * Cin, "conv weight K mismatch");
-    p.C_hi = out.hi; p.C_lo = out.lo; p.ldc16 = W.N; p.act = act; p.c_rp = out.rp;
+    p.C_hi = out.hi; p.C_lo = out.lo; p.ldc16 = W.N; p.act = act; p.c_rp = out.rp; p.c_mx = out.mx ? 1 : 0;
     REQUIRE(h->dry || ((int64_t)nimg * Hi * Wi == in.rp && out.rp == p.M), "internal: conv plane rows mismatch");
-    if (r1) { p.R1_hi = r1->hi; p.R1_lo = r1->lo; REQUIRE(h->dry || r1->rp == out.rp, "internal: residual rows mismatch"); }
-    if (r2) { p.R2_hi = r2->hi; p.R2_lo = r2->lo; REQUIRE(h->dry || r2->rp == out.rp, "internal: residual rows mismatch"); }
+    if (r1) { p.R1_hi = r1->hi; p.R1_lo = r1->lo; p.r_mx = r1->mx ? 1 : 0; REQUIRE(h->dry || r1->rp == out.rp, "internal: residual rows mismatch"); }
+    if (r2) { p.R2_hi = r2->hi; p.R2_lo = r2->lo; REQUIRE(h->dry || (r2->rp == out.rp && (!r1 || r1->mx == r2->mx)), "internal: residual rows / format mismatch"); p.r_mx = r2->mx ? 1 : 0; }
     return launch_gemm<A_CONV3, EPI_F16>(h, p, st);
 }
 
@@ -675,8 +681,9 @@ static int run_up2(sta_handle* h, const Planes& in, int n, int Hi, int Wi, int C
     if (h->dry) return 0;
     int64_t total = (int64_t)n * Hc * Wc * (C / 8);
     int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
-    if (h->prec != STA_PREC_F16) hipLaunchKernelGGL(bilinear_up2_kernel<true>, dim3(blocks), dim3(256), 0, st, in.hi, in.lo, n, Hi, Wi, C, Hc, Wc, out.hi, out.lo);
-    else hipLaunchKernelGGL(bilinear_up2_kernel<false>, dim3(blocks), dim3(256), 0, st, in.hi, in.lo, n, Hi, Wi, C, Hc, Wc, out.hi, out.lo);
+    REQUIRE(in.mx == out.mx, "internal: bilinear format mismatch");
+    if (h->prec != STA_PREC_F16) hipLaunchKernelGGL(bilinear_up2_kernel<true>, dim3(blocks), dim3(256), 0, st, in.hi, in.lo, n, Hi, Wi, C, Hc, Wc, out.hi, out.lo, in.mx ? 1 : 0);
+    else hipLaunchKernelGGL(bilinear_up2_kernel<false>, dim3(blocks), dim3(256), 0, st, in.hi, in.lo, n, Hi, Wi, C, Hc, Wc, out.hi, out.lo, 0);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -847,33 +854,37 @@ static int dpt_impl(sta_handle* h, Bump& ws, const float* enc, int64_t enc_bs,
     const bool split = h->prec != STA_PREC_F16;
     const int E = c.enc_embed_dim, D = c.dec_embed_dim, hp = H / 16, wp = W / 16, N = hp * wp;
     const int M = n * N;
-    Planes t0 = ws.act(M, E, split), t1 = ws.act(M, D, split);
-    Planes t2 = ws.act(M, D, split), t3 = ws.act(M, D, split);
-    CHK(run_rows_to_planes(h, enc, enc_bs, n, N, E, t0, st));
-    CHK(run_rows_to_planes(h, h1, h1_bs, n, N, D, t1, st));
-    CHK(run_rows_to_planes(h, h2, h2_bs, n, N, D, t2, st));
-    CHK(run_rows_to_planes(h, h3, h3_bs, n, N, D, t3, st));
+    // precision f16mx: every DPT buffer is in the f16mx row format, except the input of act_postprocess[0]
+    // (N = 96: no f16mx kernel for that one GEMM, it reads f16x3 rows and WRITES f16mx rows)
+    const bool dmx = h->prec == STA_PREC_F16MX;
+    auto act = [&](int64_t rows, int64_t cols, bool mx) { Planes q = ws.act(rows, cols, split); q.mx = mx; return q; };
+    Planes t0 = act(M, E, use_mx(h, h->act0_0)), t1 = act(M, D, dmx);
+    Planes t2 = act(M, D, dmx), t3 = act(M, D, dmx);
+    CHK(run_rows_to_planes(h, enc, enc_bs, n, N, E, t0, st, 0, t0.mx));
+    CHK(run_rows_to_planes(h, h1, h1_bs, n, N, D, t1, st, 0, t1.mx));
+    CHK(run_rows_to_planes(h, h2, h2_bs, n, N, D, t2, st, 0, t2.mx));
+    CHK(run_rows_to_planes(h, h3, h3_bs, n, N, D, t3, st, 0, t3.mx));
     // act_postprocess (dpt_block.py:356-410)
-    Planes a0 = ws.act(M, 96, split), l0 = ws.act((int64_t)M * 16, 96, split);
-    Planes a1 = ws.act(M, 192, split), l1 = ws.act((int64_t)M * 4, 192, split);
-    Planes l2 = ws.act(M, 384, split);
-    Planes a3 = ws.act(M, 768, split);
+    Planes a0 = act(M, 96, dmx), l0 = act((int64_t)M * 16, 96, dmx);
+    Planes a1 = act(M, 192, dmx), l1 = act((int64_t)M * 4, 192, dmx);
+    Planes l2 = act(M, 384, dmx);
+    Planes a3 = act(M, 768, dmx);
     const int h3s = (hp - 1) / 2 + 1, w3s = (wp - 1) / 2 + 1;
-    Planes l3 = ws.act((int64_t)n * h3s * w3s, 768, split);
+    Planes l3 = act((int64_t)n * h3s * w3s, 768, dmx);
     REQUIRE(!ws.overflow, "internal: dpt workspace overflow (stage 1)");
-    CHK(gemm_f16(h, t0, h->act0_0, M, a0, ACT_NONE, st));
+    CHK(gemm_f16(h, t0, h->act0_0, M, a0, ACT_NONE, st, a0.mx));
     CHK(gemm_convt(h, a0, h->act0_1, n, hp, wp, 4, 96, l0, st));
-    CHK(gemm_f16(h, t1, h->act1_0, M, a1, ACT_NONE, st));
+    CHK(gemm_f16(h, t1, h->act1_0, M, a1, ACT_NONE, st, a1.mx));
     CHK(gemm_convt(h, a1, h->act1_1, n, hp, wp, 2, 192, l1, st));
-    CHK(gemm_f16(h, t2, h->act2_0, M, l2, ACT_NONE, st));
-    CHK(gemm_f16(h, t3, h->act3_0, M, a3, ACT_NONE, st));
+    CHK(gemm_f16(h, t2, h->act2_0, M, l2, ACT_NONE, st, l2.mx));
+    CHK(gemm_f16(h, t3, h->act3_0, M, a3, ACT_NONE, st, a3.mx));
     CHK(conv3(h, a3, n, hp, wp, 768, h->act3_1, 2, false, ACT_NONE, l3, nullptr, nullptr, st));
     // layer_rn (3x3, no bias) -> 256 channels at 4x, 2x, 1x, 1/2x
     const int Hs[4] = {4 * hp, 2 * hp, hp, h3s}, Ws[4] = {4 * wp, 2 * wp, wp, w3s};
     const int Cs[4] = {96, 192, 384, 768};
     Planes lin[4] = {l0, l1, l2, l3}, r[4];
     for (int k = 0; k < 4; ++k) {
-        r[k] = ws.act((int64_t)n * Hs[k] * Ws[k], 256, split);
+        r[k] = act((int64_t)n * Hs[k] * Ws[k], 256, dmx);
         REQUIRE(!ws.overflow, "internal: dpt workspace overflow (rn)");
         CHK(conv3(h, lin[k], n, Hs[k], Ws[k], Cs[k], h->rn[k], 1, false, ACT_NONE, r[k], nullptr, nullptr, st));
     }
@@ -885,30 +896,30 @@ static int dpt_impl(sta_handle* h, Bump& ws, const float* enc, int64_t enc_bs,
         const Refine& rf = h->ref[k];
         const int hh = Hs[k], ww = Ws[k];
         const int64_t el = (int64_t)n * hh * ww;
-        Planes tmp = ws.act(el, 256, split), cur = r[k];
+        Planes tmp = act(el, 256, dmx), cur = r[k];
         if (k < 3) {
             REQUIRE(ph == hh && pw == ww, "internal: refinenet size mismatch %dx%d vs %dx%d", ph, pw, hh, ww);
-            Planes sum = ws.act(el, 256, split);
+            Planes sum = act(el, 256, dmx);
             REQUIRE(!ws.overflow, "internal: dpt workspace overflow (fusion)");
             CHK(run_rcu(h, r[k], n, hh, ww, rf.u1, tmp, sum, &path, st));   // path + RCU1(layer)
             cur = sum;
         }
-        Planes y = ws.act(el, 256, split), z = ws.act(el, 256, split);
+        Planes y = act(el, 256, dmx), z = act(el, 256, dmx);
         REQUIRE(!ws.overflow, "internal: dpt workspace overflow (rcu2)");
         CHK(run_rcu(h, cur, n, hh, ww, rf.u2, tmp, y, nullptr, st));
-        CHK(gemm_f16(h, y, rf.out, n * hh * ww, z, ACT_NONE, st));
+        CHK(gemm_f16(h, y, rf.out, n * hh * ww, z, ACT_NONE, st, z.mx));
         // upsample x2 (align_corners) ; refinenet4 output is cropped to the layers[2] size (dpt_head.py:58)
         int oh = 2 * hh, ow = 2 * ww;
         if (k == 3) { if (oh > Hs[2]) oh = Hs[2]; if (ow > Ws[2]) ow = Ws[2]; }
-        Planes up = ws.act((int64_t)n * oh * ow, 256, split);
+        Planes up = act((int64_t)n * oh * ow, 256, dmx);
         REQUIRE(!ws.overflow, "internal: dpt workspace overflow (up)");
         CHK(run_up2(h, z, n, hh, ww, 256, oh, ow, up, st));
         path = up; ph = oh; pw = ow;
     }
     // head: 3x3 256->128, up x2, 3x3 128->128 + ReLU, 1x1 128->4 + postprocess (dpt_block.py:316-324)
-    Planes h0 = ws.act((int64_t)n * ph * pw, 128, split);
-    Planes h0u = ws.act((int64_t)n * H * W, 128, split);
-    Planes h2o = ws.act((int64_t)n * H * W, 128, split);
+    Planes h0 = act((int64_t)n * ph * pw, 128, dmx);
+    Planes h0u = act((int64_t)n * H * W, 128, dmx);
+    Planes h2o = act((int64_t)n * H * W, 128, dmx);
     REQUIRE(!ws.overflow, "internal: dpt workspace overflow (head)");
     REQUIRE(2 * ph == H && 2 * pw == W, "internal: head size mismatch");
     CHK(conv3(h, path, n, ph, pw, 256, h->head0, 1, false, ACT_NONE, h0, nullptr, nullptr, st));
@@ -921,8 +932,8 @@ static int dpt_impl(sta_handle* h, Bump& ws, const float* enc, int64_t enc_bs,
         int64_t npix = (int64_t)cnt * H * W;
         const int64_t pix0 = (int64_t)i0 * H * W;
         int blocks = (int)((npix * 16 + 255) / 256); if (blocks > 16384) blocks = 16384;
-        if (split) hipLaunchKernelGGL(head_final_kernel<true>, dim3(blocks), dim3(256), 0, st, h2o.hi, h2o.lo, pix0, h2o.rp, npix, h->head4.w, h->head4.b, pp, cp);
-        else hipLaunchKernelGGL(head_final_kernel<false>, dim3(blocks), dim3(256), 0, st, h2o.hi, h2o.lo, pix0, h2o.rp, npix, h->head4.w, h->head4.b, pp, cp);
+        if (split) hipLaunchKernelGGL(head_final_kernel<true>, dim3(blocks), dim3(256), 0, st, h2o.hi, h2o.lo, pix0, h2o.rp, npix, h->head4.w, h->head4.b, pp, cp, h2o.mx ? 1 : 0);
+        else hipLaunchKernelGGL(head_final_kernel<false>, dim3(blocks), dim3(256), 0, st, h2o.hi, h2o.lo, pix0, h2o.rp, npix, h->head4.w, h->head4.b, pp, cp, 0);
         HIPCHK(hipGetLastError());
     }
     return 0;

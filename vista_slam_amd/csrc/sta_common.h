@@ -112,6 +112,11 @@ __device__ __forceinline__ void store_mx4(f16* base, size_t o, const MX4& v) {
     *reinterpret_cast<uint2*>(base + o) = v.hi;
     *reinterpret_cast<uint2*>(base + o + 32) = v.pairs;          // +64 B, 2 B per element: same offset arithmetic as the lo plane
 }
+// value of an f16mx ACTIVATION element: hi + lo8 * 2^-11 (readers outside the GEMMs: residual adds, bilinear, head)
+__device__ __forceinline__ float load_mx_act(const f16* base, size_t o) {
+    const int pair = reinterpret_cast<const unsigned short*>(base)[o + 32];
+    return (float)base[o] + __builtin_amdgcn_cvt_f32_fp8(pair, 1) * (1.0f / (float)(1 << STA_MX_A_SLO));
+}
 template <bool WEIGHT>
 __device__ __forceinline__ void store_mx1(f16* base, size_t o, float x) {     // scalar variant (column-per-lane epilogues)
     constexpr float KHI = WEIGHT ? (float)(1 << STA_MX_W_SHI) : (float)(1 << STA_MX_A_SHI);
