@@ -50,8 +50,8 @@ typedef struct sta_handle sta_handle;
 enum {
     STA_PREC_F16   = 1,  /* fp16 x fp16 -> fp32 MFMA, one product  (10-bit mantissa == TF32 class) */
     STA_PREC_F16X3 = 3,  /* 2-term fp16 split of both operands, 3 products (~21-bit, fp32 class)   */
-    STA_PREC_F16MX = 4   /* opt-in: f16x3 everywhere except the transformer linears, whose two correction
-                          * products run as one block-scaled fp8 MFMA (GEMM error ~1e-5, 1.5x less MFMA work) */
+    STA_PREC_F16MX = 4   /* opt-in: the two correction products of every linear / convolution run as ONE block-
+                          * scaled fp8 MFMA (GEMM error ~1e-5, 1.5x less MFMA work); attention stays f16x3 */
 };
 
 enum { STA_DTYPE_F32 = 0 };
