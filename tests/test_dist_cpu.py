@@ -73,3 +73,46 @@ def test_single_process_gather_is_identity():
     main, supp = fake_outputs([0, 1, 2])
     p = P.pack_compact(main, supp)
     assert P.gather_compact(p, 3) is p
+
+
+# ---------------------------------------------------------------------------------------------------------
+# SLAM-side partitioning: the candidate edges of one keyframe scattered over the ranks, compact results all-gathered.
+class _Edge:
+    def __init__(self, e, accepted):
+        g = torch.Generator().manual_seed(100 + e)
+        self.accepted, self.rel_pose_conf = accepted, 0.1 * e + 0.05
+        self.pose = torch.rand(4, 4, generator=g) + e
+        self.intri = torch.rand(3, 3, generator=g) + e if accepted else None
+        self.depths = torch.rand(2, H, W_, generator=g) + e if accepted else None
+        self.confs = torch.rand(2, H, W_, generator=g) + 1 if accepted else None
+
+
+def _edge_worker(rank, world, port, num_edges, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        accepted = [e % 3 != 1 for e in range(num_edges)]           # some loop candidates rejected
+        mine = P.edge_shard(num_edges, world, rank)
+        local = P.pack_edges([_Edge(e, accepted[e]) for e in mine], H, W_, device="cpu")
+        allr = P.gather_edges(local, num_edges, H, W_)
+        ok = len(allr) == num_edges
+        for e, d in enumerate(allr):
+            ref = _Edge(e, accepted[e])
+            ok &= d["accepted"] == ref.accepted and abs(d["rel_pose_conf"] - ref.rel_pose_conf) < 1e-6
+            ok &= torch.equal(d["pose"], ref.pose)
+            if ref.accepted:
+                ok &= torch.equal(d["intri"], ref.intri) and torch.equal(d["depths"], ref.depths) and torch.equal(d["confs"], ref.confs)
+            else:
+                ok &= d["intri"] is None and d["depths"] is None and d["confs"] is None
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_edges", [5, 6, 1])    # TUM-style keyframe (3 neighbours + 2 loops), even split, fewer edges than ranks
+def test_two_rank_keyframe_edge_scatter(num_edges):
+    world = 2
+    assert sorted(P.edge_shard(num_edges, world, 0) + P.edge_shard(num_edges, world, 1)) == list(range(num_edges))
+    ret = mp.Manager().dict()
+    mp.spawn(_edge_worker, args=(world, _free_port(), num_edges, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}

@@ -70,3 +70,65 @@ def gather_compact(local: torch.Tensor, num_pairs: int, out: torch.Tensor | None
     tmp = torch.empty(world * mx, width, device=local.device, dtype=local.dtype)
     dist.all_gather_into_tensor(tmp, pad)
     return torch.cat([tmp[r * mx: r * mx + counts[r]] for r in range(world)], dim=0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# SLAM-side partitioning: the <= neighbor_edge_num + loop_edge_num candidate edges of ONE keyframe are
+# scattered over the ranks; every rank holds the replicated encoder features (<= 400 x 0.8 MB @224x224), runs the
+# keyframe scheduler (`slam_scheduler.regress_views`) on its own edges, and one all-gather returns every edge's compact
+# result (what `connect_view_i_j` consumes: pose, confidence, accepted flag, shared intrinsics, depths, conf maps).
+
+def edge_shard(num_edges: int, world: int, rank: int) -> List[int]:
+    """Edge indices owned by `rank`: round-robin, so the adjacent (always accepted, DPT-heavy) edge and the cheap
+    rejected loop candidates spread evenly instead of piling on one rank."""
+    return list(range(rank, num_edges, world))
+
+
+def edge_elems(H: int, W: int) -> int:
+    """accepted flag, pose_conf, pose 16, K 9, depths 2HW, confs 2HW"""
+    return 2 + 16 + 9 + 4 * H * W
+
+
+def pack_edges(results, H: int, W: int, device=None) -> torch.Tensor:
+    """`results`: list of slam_scheduler.EdgeResult (or objects with the same fields) of THIS rank's edges."""
+    rows = []
+    for r in results:
+        dev = r.pose.device if device is None else device
+        head = torch.tensor([1.0 if r.accepted else 0.0, float(r.rel_pose_conf)], device=dev)
+        if r.accepted:
+            body = [r.pose.reshape(16), r.intri.reshape(9), r.depths.reshape(-1), r.confs.reshape(-1)]
+        else:
+            body = [r.pose.reshape(16), torch.zeros(9 + 4 * H * W, device=dev)]
+        rows.append(torch.cat([head] + [b.to(dev, torch.float32) for b in body]))
+    if not rows:
+        return torch.empty(0, edge_elems(H, W), device=device)
+    return torch.stack(rows).contiguous()
+
+
+def gather_edges(local: torch.Tensor, num_edges: int, H: int, W: int) -> List[dict]:
+    """All ranks -> the results of ALL edges in the original edge order (list of dicts; depths / confs / intri are None
+    for rejected edges, exactly like regress_two_views' early return, slam.py:170)."""
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    width = edge_elems(H, W)
+    per = (num_edges + world - 1) // world
+    if world > 1:
+        pad = torch.zeros(per, width, device=local.device, dtype=torch.float32)
+        pad[:local.shape[0]] = local
+        allr = torch.empty(world * per, width, device=local.device, dtype=torch.float32)
+        dist.all_gather_into_tensor(allr, pad)
+    else:
+        allr = local
+    out: List[dict] = [None] * num_edges
+    for r in range(world):
+        for slot, e in enumerate(edge_shard(num_edges, world, r)):
+            row = allr[r * per + slot] if world > 1 else allr[slot]
+            acc = bool(row[0] > 0.5)
+            d = {"accepted": acc, "rel_pose_conf": float(row[1]), "pose": row[2:18].reshape(4, 4),
+                 "intri": None, "depths": None, "confs": None}
+            if acc:
+                d["intri"] = row[18:27].reshape(3, 3)
+                d["depths"] = row[27:27 + 2 * H * W].reshape(2, H, W)
+                d["confs"] = row[27 + 2 * H * W:].reshape(2, H, W)
+            out[e] = d
+    return out
