@@ -56,6 +56,7 @@ struct Slot {
 };
 
 static const int64_t SKBUF_ELEMS = (int64_t)4 << 20;   // 16 MiB: M*N of the largest split-K plane-epilogue GEMM
+static const int SKBUF_SLOTS = 5;                      // caller's stream + the 4 internal slice streams: concurrent slices must not share it
 
 struct sta_handle {
     sta_config cfg;
@@ -77,7 +78,7 @@ struct sta_handle {
     float* stage = nullptr; int64_t stage_elems = 0;
     char* ws = nullptr; int64_t ws_cap = 0;
     f16* zero_page = nullptr;
-    float* skbuf = nullptr;   // fp32 partial sums of split-K GEMMs with the plane epilogue (SKBUF_ELEMS floats)
+    float* skbuf = nullptr;   // fp32 partial sums of split-K GEMMs with the plane epilogue (SKBUF_SLOTS x SKBUF_ELEMS floats)
     int gemm_variant = 0;   // 0 auto, 1 force 128x128 kernel, 2 force 256-row kernel (tests/bench only)
     // rope table
     float* rope_tab = nullptr; int rope_P = 0;
@@ -317,7 +318,7 @@ extern "C" int sta_create(const sta_config* cfg, int device, sta_handle** out) {
     int64_t big = (int64_t)768 * 768 * 9;
     if (big > h->stage_elems) h->stage_elems = big;
     if (hipMalloc((void**)&h->stage, (size_t)h->stage_elems * 4) != hipSuccess) { sta_destroy(h); return set_err("staging alloc failed"); }
-    if (hipMalloc((void**)&h->skbuf, (size_t)SKBUF_ELEMS * 4) != hipSuccess) { sta_destroy(h); return set_err("split-K buffer alloc failed"); }
+    if (hipMalloc((void**)&h->skbuf, (size_t)SKBUF_SLOTS * SKBUF_ELEMS * 4) != hipSuccess) { sta_destroy(h); return set_err("split-K buffer alloc failed"); }
     if (hipMalloc((void**)&h->zero_page, 256) != hipSuccess || hipMemset(h->zero_page, 0, 256) != hipSuccess) { sta_destroy(h); return set_err("zero page alloc failed"); }
     *out = h;
     return 0;
@@ -507,8 +508,10 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
             const int max_ks = p.K / 256;                 // keep >= 8 K tiles per slice
             if (ks > max_ks) ks = max_ks;
             if (ks > 1) {
-                p.ksplit = ks; p.skbuf = h->skbuf;
-                HIPCHK(hipMemsetAsync(h->skbuf, 0, (size_t)p.M * p.N * 4, st));
+                int slot = 0;                             // one scratch slot per stream the forward may be running on
+                for (int q = 0; q < 4; ++q) if (h->aux[q] && st == h->aux[q]) slot = q + 1;
+                p.ksplit = ks; p.skbuf = h->skbuf + (size_t)slot * SKBUF_ELEMS;
+                HIPCHK(hipMemsetAsync(p.skbuf, 0, (size_t)p.M * p.N * 4, st));
             }
         }
     }
