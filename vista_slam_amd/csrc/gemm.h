@@ -22,7 +22,8 @@
 #include "sta_common.h"
 
 enum { A_DENSE = 0, A_CONV3 = 1 };
-enum { EPI_F32 = 0, EPI_F16 = 1, EPI_QKV = 2, EPI_CONVT = 3 };
+enum { EPI_F32 = 0, EPI_F16 = 1, EPI_QKV = 2, EPI_CONVT = 3,
+       EPI_GELU = 4 };   // mlp.fc1: fp16-plane epilogue with the activation fixed at compile time and no residual planes
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
 
 struct GemmParams {
@@ -184,6 +185,14 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
                     if (p.resid) v += p.resid[(size_t)orow * p.ldr + col];
                     p.C32[(size_t)orow * p.ldc + col] = v;
                 }
+            }
+        } else if (EPI == EPI_GELU) {       // the one hot plane epilogue (fc1): no per-element flag branches
+            if (ok) {
+                v = gelu_erf(v);
+                const size_t o = blk_off<SPLIT>(row, col, p.c_rp);
+                if (SPLIT && p.c_mx) store_mx1<false>(p.C_hi, o, v);
+                else if (SPLIT) { f16 h, l; split_f16(v, h, l); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
+                else p.C_hi[o] = to_f16_sat(v);
             }
         } else if (EPI == EPI_F16) {
             if (ok && p.ksplit > 1) {

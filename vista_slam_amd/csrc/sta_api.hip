@@ -592,6 +592,8 @@ static int gemm_f16(sta_handle* h, const Planes& A, const Lin& W, int M, const P
     p.C_hi = out.hi; p.C_lo = out.lo; p.ldc16 = W.N; p.act = act; p.c_rp = out.rp; p.c_mx = c_mx ? 1 : 0;
     REQUIRE(h->dry || (A.rp >= M && out.rp >= M), "internal: plane rows mismatch in gemm_f16");
     REQUIRE(h->dry || !A.mx || p.mx, "internal: f16mx input rows for a GEMM without an f16mx kernel");
+    if (act == ACT_GELU && M > 640) return launch_gemm<A_DENSE, EPI_GELU>(h, p, st);   // mlp.fc1 at throughput scale: compile-time activation, no residual
+                                                                                      // planes (small M keeps the generic epilogue and its split-K path)
     return launch_gemm<A_DENSE, EPI_F16>(h, p, st);
 }
 struct QKVOut { Planes q, k, vt; int npad; };
