@@ -23,7 +23,9 @@
 
 enum { A_DENSE = 0, A_CONV3 = 1 };
 enum { EPI_F32 = 0, EPI_F16 = 1, EPI_QKV = 2, EPI_CONVT = 3,
-       EPI_GELU = 4 };   // mlp.fc1: fp16-plane epilogue with the activation fixed at compile time and no residual planes
+       EPI_GELU = 4,     // mlp.fc1: fp16-plane epilogue with the activation fixed at compile time and no residual planes
+       EPI_F32R = 5 };   // attn.proj / mlp.fc2 at throughput scale: fp32 output added IN PLACE to the residual stream,
+                         // no row remap, no split-K - the common case of EPI_F32 without its per-element flag branches
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
 
 struct GemmParams {
@@ -175,7 +177,12 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
         const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
         const bool ok = col_ok && row < p.M;
         float v = acc[r] + bv;
-        if (EPI == EPI_F32) {
+        if (EPI == EPI_F32R) {
+            if (ok) {
+                float* c = p.C32 + (size_t)row * p.ldc + col;
+                *c = v + *c;
+            }
+        } else if (EPI == EPI_F32) {
             if (ok) {
                 int orow = row;
                 if (p.rows_in > 0) orow = (row / p.rows_in) * p.rows_out + p.row_off + row % p.rows_in;

@@ -445,7 +445,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
     if (AMODE == A_CONV3) REQUIRE(p.Cin % GEMM_BK == 0, "conv Cin=%d must be a multiple of %d", p.Cin, GEMM_BK);
     if (h->dry) return 0;
     const bool split = h->prec != STA_PREC_F16;
-    const bool timed = h->ktime && AMODE == A_DENSE && EPI == EPI_F32;
+    const bool timed = h->ktime && AMODE == A_DENSE && (EPI == EPI_F32 || EPI == EPI_F32R);
     if (timed) {
         if ((int)h->kev.size() < 2 * (h->kn + 1)) {
             hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
@@ -584,6 +584,9 @@ static int gemm_f32(sta_handle* h, const Planes& A, const Lin& W, int M, float* 
     GemmParams p = gp_dense(A, W.K, W, M, use_mx(h, W));
     p.C32 = out; p.ldc = ldc; p.resid = resid; p.ldr = ldc;
     p.rows_in = rows_in; p.rows_out = rows_out; p.row_off = row_off;
+    // throughput-scale in-place residual GEMMs (attn.proj, mlp.fc2, cross_attn.proj): specialised epilogue
+    if (resid == out && rows_in == 0 && M > 640 && (int64_t)((M + 191) / 192) * ((W.N + 127) / 128) >= 128)
+        return launch_gemm<A_DENSE, EPI_F32R>(h, p, st);
     return launch_gemm<A_DENSE, EPI_F32>(h, p, st);
 }
 // c_mx: the output planes feed an f16mx GEMM (mlp.fc1 -> GELU -> mlp.fc2)
