@@ -172,6 +172,26 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
     const int lhi = lane >> 5;
     const bool col_ok = col < p.N;
     const float bv = (p.bias != nullptr && col_ok && first_slice) ? p.bias[col] : 0.f;
+    if ((EPI == EPI_F32R || EPI == EPI_GELU) && row0 + 32 <= p.M && __all(col_ok)) {
+        // interior tile of a hot epilogue (every tile when M, N are tile multiples, as at bench scale): no per-element
+        // bounds predicate -> no exec-mask save / branch per element
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            float v = acc[r] + bv;
+            if (EPI == EPI_F32R) {
+                float* c = p.C32 + (size_t)row * p.ldc + col;
+                *c = v + *c;
+            } else {
+                v = gelu_erf(v);
+                const size_t o = blk_off<SPLIT>(row, col, p.c_rp);
+                if (SPLIT && p.c_mx) store_mx1<false>(p.C_hi, o, v);
+                else if (SPLIT) { f16 h, l; split_f16(v, h, l); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
+                else p.C_hi[o] = to_f16_sat(v);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
