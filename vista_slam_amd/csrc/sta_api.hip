@@ -1112,283 +1112,7 @@ extern "C" int sta_forward_pair_u8hwc(sta_handle* h, const uint8_t* img_a, const
     return forward_pair_any(h, img_a, img_b, true, B, H, W, pts, conf, pose, pose_conf, stream);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// f3: input step.  Host side = the integer geometry of _crop_resize_if_necessary_image_only
-// (base_view_graph_dataset.py:171-225) and Pillow's coefficient tables (Resample.c precompute_coeffs +
-// normalize_coeffs_8bpc), in double like the original; device side = elementwise.h pre_*_kernel.
-static double pre_lanczos(double x) {
-    auto sinc = [](double v) { if (v == 0.0) return 1.0; v = v * M_PI; return sin(v) / v; };
-    if (-3.0 <= x && x < 3.0) return sinc(x) * sinc(x / 3.0);
-    return 0.0;
-}
-// coefficients for output samples [o0, o0+cnt) of an in_size -> out_size resample; returns ksize
-static int pre_coeffs(int in_size, int out_size, int o0, int cnt, std::vector<int>& bounds, std::vector<int>& kk) {
-    double scale, filterscale;
-    filterscale = scale = (double)((float)in_size - 0.0f) / out_size;
-    if (filterscale < 1.0) filterscale = 1.0;
-    const double support = 3.0 * filterscale;
-    const int ksize = (int)ceil(support) * 2 + 1;
-    bounds.assign((size_t)cnt * 2, 0);
-    kk.assign((size_t)cnt * ksize, 0);
-    std::vector<double> w(ksize);
-    const double ss = 1.0 / filterscale;
-    for (int q = 0; q < cnt; ++q) {
-        const int xx = o0 + q;
-        const double center = 0.0 + (xx + 0.5) * scale;
-        double ww = 0.0;
-        int xmin = (int)(center - support + 0.5); if (xmin < 0) xmin = 0;
-        int xmax = (int)(center + support + 0.5); if (xmax > in_size) xmax = in_size;
-        xmax -= xmin;
-        for (int x = 0; x < xmax; ++x) { w[x] = pre_lanczos((x + xmin - center + 0.5) * ss); ww += w[x]; }
-        for (int x = 0; x < xmax; ++x) {
-            double v = w[x];
-            if (ww != 0.0) v /= ww;
-            kk[(size_t)q * ksize + x] = v < 0 ? (int)(-0.5 + v * (1 << 22)) : (int)(0.5 + v * (1 << 22));
-        }
-        bounds[2 * q] = xmin; bounds[2 * q + 1] = xmax;
-    }
-    return ksize;
-}
-
-extern "C" int sta_preprocess_frame(sta_handle* h, const uint8_t* src, int Hs, int Ws, int out_H, int out_W, int w_edge, int h_edge,
-                                    uint8_t* u8_out, float* rgb_out, float* gray_out, void* stream) {
-    REQUIRE(h && src, "null argument");
-    REQUIRE(u8_out || rgb_out || gray_out, "no output requested");
-    REQUIRE(Hs > 0 && Ws > 0 && out_H > 0 && out_W > 0 && w_edge >= 0 && h_edge >= 0, "bad size");
-    REQUIRE(out_W >= out_H, "resolution must be landscape or square (W >= H), got %dx%d", out_W, out_H);
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t st = (hipStream_t)stream;
-    const int key[6] = {Hs, Ws, out_H, out_W, w_edge, h_edge};
-    if (memcmp(key, h->pre_key, sizeof(key)) != 0) {
-        const int cx = (int)(Ws / 2.0), cy = (int)(Hs / 2.0);
-        const int mx = cx < Ws - cx ? cx : Ws - cx, my = cy < Hs - cy ? cy : Hs - cy;
-        REQUIRE(mx > Ws / 5.0 && my > Hs / 5.0, "Bad principal point");
-        int l = cx - mx, t = cy - my, r = cx + mx, b = cy + my;
-        if (l < w_edge) l = w_edge; if (t < h_edge) t = h_edge;
-        if (r > Ws - w_edge) r = Ws - w_edge; if (b > Hs - h_edge) b = Hs - h_edge;
-        const int cw = r - l, ch = b - t;
-        REQUIRE(cw > 0 && ch > 0, "edge margins leave no image");
-        REQUIRE(!(ch > 1.1 * cw), "portrait frames are not supported (landscape / square only)");
-        REQUIRE(!(0.9 < (double)ch / cw && (double)ch / cw < 1.1 && out_W != out_H),
-                "square frame with a non-square resolution: the reference picks the orientation at random");
-        const double sx = (double)out_W / cw, sy = (double)out_H / ch;
-        const double scale_final = (sx > sy ? sx : sy) + 1e-8;                       // cropping.py:67
-        const int rw = (int)floor(cw * scale_final), rh = (int)floor(ch * scale_final);
-        const int l2 = (int)nearbyint(rw / 2.0 - out_W / 2.0), t2 = (int)nearbyint(rh / 2.0 - out_H / 2.0);   // np.round: half to even
-        REQUIRE(l2 >= 0 && t2 >= 0 && l2 + out_W <= rw && t2 + out_H <= rh, "internal: final crop outside the rescaled image");
-        std::vector<int> bh, kh, bv, kv;
-        const int ksh = pre_coeffs(cw, rw, l2, out_W, bh, kh);
-        const int ksv = pre_coeffs(ch, rh, t2, out_H, bv, kv);
-        const int y_first = bv[0], y_last = bv[2 * (out_H - 1)] + bv[2 * (out_H - 1) + 1];
-        for (int y = 0; y < out_H; ++y) bv[2 * y] -= y_first;
-        const int64_t total = (int64_t)bh.size() + kh.size() + bv.size() + kv.size();
-        HIPCHK(hipStreamSynchronize(st));                       // earlier frames may still read the old tables
-        if (total > h->pre_cap) {
-            if (h->pre_tab) HIPCHK(hipFree(h->pre_tab));
-            h->pre_tab = nullptr; h->pre_cap = 0;
-            HIPCHK(hipMalloc((void**)&h->pre_tab, (size_t)total * 4));
-            h->pre_cap = total;
-        }
-        std::vector<int> all; all.reserve(total);
-        all.insert(all.end(), bh.begin(), bh.end()); all.insert(all.end(), kh.begin(), kh.end());
-        all.insert(all.end(), bv.begin(), bv.end()); all.insert(all.end(), kv.begin(), kv.end());
-        HIPCHK(hipMemcpy(h->pre_tab, all.data(), (size_t)total * 4, hipMemcpyHostToDevice));
-        const int meta[12] = {l, t, ksh, ksv, y_first, y_last - y_first, (int)bh.size(), (int)kh.size(), (int)bv.size(), (int)kv.size(), 0, 0};
-        memcpy(h->pre_meta, meta, sizeof(meta));
-        memcpy(h->pre_key, key, sizeof(key));
-    }
-    const int* m = h->pre_meta;
-    return plan_and_run(h, [&](Bump& ws) -> int {
-        uint8_t* tmp = (uint8_t*)ws.take((int64_t)m[5] * out_W * 4);
-        if (h->dry) return 0;
-        REQUIRE(!ws.overflow, "internal: workspace overflow");
-        PreParams p;
-        p.src = src; p.Ws = Ws; p.l = m[0]; p.t = m[1]; p.ow = out_W; p.oh = out_H;
-        p.bh = h->pre_tab; p.kh = p.bh + m[6]; p.ksh = m[2];
-        p.bv = p.kh + m[7]; p.kv = p.bv + m[8]; p.ksv = m[3];
-        p.y_first = m[4]; p.y_rows = m[5]; p.tmp = tmp;
-        p.out_u8 = u8_out; p.out_rgb = rgb_out; p.out_gray = gray_out;
-        const int gx = (out_W + 255) / 256;
-        hipLaunchKernelGGL(pre_horizontal_kernel, dim3(gx, p.y_rows), dim3(256), 0, st, p);
-        hipLaunchKernelGGL(pre_vertical_kernel, dim3(gx, out_H), dim3(256), 0, st, p);
-        HIPCHK(hipGetLastError());
-        return 0;
-    });
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// f4: output step (slam.py:338-421).
-extern "C" int sta_world_pointcloud(sta_handle* h, const float* depths, const float* scales, const float* K, const float* poses,
-                                    const float* confs, const float* imgs, int N, int H, int W, float conf_thres,
-                                    float* pts_out, float* col_out, uint8_t* ply_records_out, int64_t* count_host, void* stream) {
-    REQUIRE(h && depths && scales && K && poses && confs && count_host, "null argument");
-    REQUIRE(N > 0 && H > 0 && W > 0, "bad size");
-    REQUIRE(pts_out || col_out || ply_records_out, "no output requested");
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t st = (hipStream_t)stream;
-    const int64_t total = (int64_t)N * H * W;
-    REQUIRE((total + 255) / 256 < (int64_t)1 << 30, "point cloud too large");
-    const int nblk = (int)((total + 255) / 256);
-    *count_host = 0;
-    return plan_and_run(h, [&](Bump& ws) -> int {
-        int* counts = (int*)ws.take((int64_t)nblk * 4);
-        int64_t* offs = (int64_t*)ws.take((int64_t)(nblk + 1) * 8);
-        if (h->dry) return 0;
-        REQUIRE(!ws.overflow, "internal: workspace overflow");
-        CloudParams p;
-        p.depth = depths; p.scale = scales; p.K = K; p.pose = poses; p.conf = confs; p.img = imgs;
-        p.N = N; p.H = H; p.W = W; p.thres = conf_thres; p.counts = counts; p.offs = offs; p.nblk = nblk;
-        p.pts = pts_out; p.col = col_out; p.rec = ply_records_out;
-        hipLaunchKernelGGL(cloud_count_kernel, dim3(nblk), dim3(256), 0, st, p);
-        hipLaunchKernelGGL(cloud_scan_kernel, dim3(1), dim3(1024), 0, st, p);
-        hipLaunchKernelGGL(cloud_emit_kernel, dim3(nblk), dim3(256), 0, st, p);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(count_host, offs + nblk, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        return 0;
-    });
-}
-
-extern "C" int sta_mat_to_se3(sta_handle* h, const float* poses, int B, float* se3_out, void* stream) {
-    REQUIRE(h && poses && se3_out && B > 0, "bad argument");
-    HIPCHK(hipSetDevice(h->device));
-    hipLaunchKernelGGL(mat_to_se3_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, poses, B, se3_out);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-extern "C" int sta_estimate_intrinsics(sta_handle* h, const float* pts, const float* conf, int B, int H, int W, int shared,
-                                       float* K_out, float* depth_out, float* conf_mean_out, void* stream) {
-    REQUIRE(h && pts && conf && K_out && B > 0 && H > 0 && W > 0, "bad argument");
-    REQUIRE(shared >= 0 && (shared < 2 || B % shared == 0), "shared group size %d does not divide B=%d", shared, B);
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t st = (hipStream_t)stream;
-    const int64_t hw = (int64_t)H * W;
-    int nblk = (int)((hw + 256 * 8 - 1) / (256 * 8)); if (nblk > 256) nblk = 256; if (nblk < 1) nblk = 1;
-    return plan_and_run(h, [&](Bump& ws) -> int {
-        double* partial = (double*)ws.take((int64_t)B * nblk * 5 * 8);
-        if (h->dry) return 0;
-        REQUIRE(!ws.overflow, "internal: workspace overflow");
-        hipLaunchKernelGGL(intrinsics_partial_kernel, dim3(nblk, B), dim3(256), 0, st, pts, conf, B, H, W, depth_out, partial, nblk);
-        hipLaunchKernelGGL(intrinsics_final_kernel, dim3(1), dim3(64), 0, st, partial, B, nblk, H, W, shared, K_out, conf_mean_out);
-        HIPCHK(hipGetLastError());
-        return 0;
-    });
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// f2: keyframe scheduler.  OnlineSLAM.step (slam.py:263-277) calls regress_two_views (slam.py:153-189) once per
-// candidate edge (i, j): B=1 decode -> pose head (ij only) -> early return when the pose confidence is below
-// rel_pose_thres and the views are not adjacent -> DPT on both views -> shared intrinsics + depths.
-// Here all k candidate edges of keyframe i are decoded in ONE batched launch sequence, the pose head runs first,
-// one k-float D2H read decides acceptance, and the DPT + post-STA reductions run batched over the accepted edges
-// only (so the DPT-skip saving of the reference is kept).
-static int launch_gather(const GatherChunks& g, int n, int64_t max16, hipStream_t st) {
-    int gx = (int)((max16 + 256 * 4 - 1) / (256 * 4)); if (gx < 1) gx = 1; if (gx > 256) gx = 256;
-    hipLaunchKernelGGL(gather_chunks_kernel, dim3(gx, n), dim3(256), 0, st, g);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-extern "C" int sta_regress_views(sta_handle* h, const float* feat_i, const float* const* feat_j, int k,
-                                 const uint8_t* adjacent, float rel_pose_thres, int H, int W,
-                                 float* pose, float* pose_conf_host, int* slot_host, int* n_accepted,
-                                 float* pts, float* conf, float* K, float* depth, void* stream) {
-    CHK(check_ready(h, k, H, W));
-    REQUIRE(k <= 16, "at most 16 candidate edges per keyframe (got %d)", k);
-    REQUIRE(feat_i && feat_j && adjacent && pose && pose_conf_host && slot_host && n_accepted && pts && conf && K && depth,
-            "null argument");
-    for (int e = 0; e < k; ++e) REQUIRE(feat_j[e] && ((uintptr_t)feat_j[e] & 15) == 0, "feat_j[%d] null or not 16-byte aligned", e);
-    REQUIRE(((uintptr_t)feat_i & 15) == 0, "feat_i not 16-byte aligned");
-    hipStream_t st = (hipStream_t)stream;
-    const sta_config& c = h->cfg;
-    const int hp = H / 16, wp = W / 16, N = hp * wp, Np = N + 1, E = c.enc_embed_dim, D = c.dec_embed_dim, S = 2 * k;
-    CHK(ensure_rope(h, hp > wp ? hp : wp));
-    const int dd = c.dec_depth;
-    const int hidx[3] = {dd * 2 / 4, dd * 3 / 4, dd};
-    const int64_t fe = (int64_t)N * E, xe = (int64_t)Np * D;
-    *n_accepted = 0;
-    return plan_and_run(h, [&](Bump& ws) -> int {
-        float* F = (float*)ws.take(S * fe * 4);              // [2k,N,E]: k copies of view i, then the k views j
-        float* x = (float*)ws.take(S * xe * 4);
-        float* hk[3] = {(float*)ws.take(S * xe * 4), (float*)ws.take(S * xe * 4), (float*)ws.take(S * xe * 4)};
-        float* cdev = (float*)ws.take(k * 4);
-        float* cf = (float*)ws.take(S * fe * 4);             // compacted DPT inputs of the accepted edges
-        float* ch[3] = {(float*)ws.take(S * xe * 4), (float*)ws.take(S * xe * 4), (float*)ws.take(S * xe * 4)};
-        const int64_t mark = ws.off;
-        if (!h->dry) {
-            GatherChunks g;
-            for (int e = 0; e < k; ++e) {
-                g.src[e] = (const uint4*)feat_i; g.dst[e] = (uint4*)(F + e * fe); g.n16[e] = fe / 4;
-                g.src[k + e] = (const uint4*)feat_j[e]; g.dst[k + e] = (uint4*)(F + (k + e) * fe); g.n16[k + e] = fe / 4;
-            }
-            CHK(launch_gather(g, 2 * k, fe / 4, st));
-        }
-        std::vector<float*> w1(dd + 1, nullptr), w2(dd + 1, nullptr);
-        for (int q = 0; q < 3; ++q) { w1[hidx[q]] = hk[q]; w2[hidx[q]] = hk[q] + (size_t)k * xe; }
-        CHK(decode_impl(h, ws, F, F + (size_t)k * fe, k, hp, wp, x, w1.data(), w2.data(), st));
-        ws.rewind(mark);
-        CHK(pose_impl(h, ws, hk[2], k, xe, pose, cdev, st));       // pose_ij only (slam.py:165)
-        int na = k;
-        int slots[16];
-        if (!h->dry) {
-            HIPCHK(hipMemcpyAsync(pose_conf_host, cdev, (size_t)k * 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));                      // the reference syncs here too (slam.py:169)
-            na = 0;
-            for (int e = 0; e < k; ++e) {
-                const bool rej = pose_conf_host[e] < rel_pose_thres && !adjacent[e];   // slam.py:169
-                slots[e] = rej ? -1 : na++;
-                slot_host[e] = slots[e];
-            }
-            *n_accepted = na;
-            if (na == 0) return 0;
-            GatherChunks g;
-            int m = 0;
-            for (int e = 0; e < k; ++e) {
-                if (slots[e] < 0) continue;
-                const int s0 = 2 * slots[e];                       // image order per edge: [ij, ji] (slam.py:182)
-                for (int side = 0; side < 2; ++side) {
-                    g.src[m] = (const uint4*)(F + (size_t)(side * k + e) * fe); g.dst[m] = (uint4*)(cf + (size_t)(s0 + side) * fe); g.n16[m] = fe / 4; ++m;
-                }
-            }
-            CHK(launch_gather(g, m, fe / 4, st));
-            REQUIRE(xe % 4 == 0, "internal: hook slice not 16-byte sized");
-            for (int q = 0; q < 3; ++q) {
-                m = 0;
-                for (int e = 0; e < k; ++e) {
-                    if (slots[e] < 0) continue;
-                    const int s0 = 2 * slots[e];
-                    for (int side = 0; side < 2; ++side) {
-                        g.src[m] = (const uint4*)(hk[q] + (size_t)(side * k + e) * xe); g.dst[m] = (uint4*)(ch[q] + (size_t)(s0 + side) * xe); g.n16[m] = xe / 4; ++m;
-                    }
-                }
-                CHK(launch_gather(g, m, xe / 4, st));
-            }
-        }
-        ws.rewind(mark);
-        const int n = 2 * na;
-        CHK(dpt_impl(h, ws, cf, fe, ch[0] + D, xe, ch[1] + D, xe, ch[2] + D, xe, n, H, W, pts, conf, n, nullptr, nullptr, st));
-        ws.rewind(mark);
-        const int64_t hw = (int64_t)H * W;
-        int nblk = (int)((hw + 256 * 8 - 1) / (256 * 8)); if (nblk > 256) nblk = 256; if (nblk < 1) nblk = 1;
-        double* partial = (double*)ws.take((int64_t)n * nblk * 5 * 8);
-        if (h->dry) return 0;
-        REQUIRE(!ws.overflow, "internal: workspace overflow");
-        hipLaunchKernelGGL(intrinsics_partial_kernel, dim3(nblk, n), dim3(256), 0, st, pts, conf, n, H, W, depth, partial, nblk);
-        hipLaunchKernelGGL(intrinsics_final_kernel, dim3(1), dim3(64), 0, st, partial, n, nblk, H, W, 2, K, (float*)nullptr);
-        HIPCHK(hipGetLastError());
-        return 0;
-    });
-}
-
-extern "C" int sta_estimate_scale(sta_handle* h, const float* Di, const float* Dj, const float* ci, const float* cj, int64_t n,
-                                  float* s_out, void* stream) {
-    REQUIRE(h && Di && Dj && ci && cj && s_out && n > 0, "bad argument");
-    HIPCHK(hipSetDevice(h->device));
-    hipLaunchKernelGGL(scale_estimate_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, Di, Dj, ci, cj, n, s_out);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
+#include "sta_rows.inc"     // input step, keyframe scheduler, post-STA reductions, output step
 
 extern "C" int sta_kernel_timing(sta_handle* h, int enable) {
     REQUIRE(h, "null handle");
@@ -1456,151 +1180,6 @@ extern "C" int sta_rope2d_inplace(float* tokens_dev, int64_t stride_b, int64_t s
     return 0;
 }
 
-// ------------------------------------------------------------------------------------------ FLOPs + GEMM bench
-extern "C" double sta_flops_per_pair(const sta_handle* h, int H, int W) {
-    if (!h) return 0;
-    const sta_config& c = h->cfg;
-    const double E = c.enc_embed_dim, D = c.dec_embed_dim, R = c.mlp_ratio;
-    const double hp = H / 16, wp = W / 16, N = hp * wp, Np = N + 1;
-    // per block: qkv 6NE^2 + proj 2NE^2 + mlp 4R NE^2  (R=4 -> 24 N E^2)
-    double f_enc = 2 * N * 768 * E + c.enc_depth * ((8 + 4 * R) * N * E * E + 4 * N * N * E);
-    double f_dec = 4 * N * E * D + 2.0 * c.dec_depth * ((16 + 4 * R) * Np * D * D + 8 * Np * Np * D);
-    // DPT: reference op placement (out_conv after the upsample), per view
-    auto conv = [](double hh, double ww, double ci, double co, double k) { return 2.0 * hh * ww * ci * co * k * k; };
-    double h3 = floor((hp - 1) / 2) + 1, w3 = floor((wp - 1) / 2) + 1;
-    double f = 0;
-    f += conv(hp, wp, E, 96, 1) + 2.0 * hp * wp * 96 * 96 * 16;
-    f += conv(hp, wp, D, 192, 1) + 2.0 * hp * wp * 192 * 192 * 4;
-    f += conv(hp, wp, D, 384, 1);
-    f += conv(hp, wp, D, 768, 1) + conv(h3, w3, 768, 768, 3);
-    f += conv(4 * hp, 4 * wp, 96, 256, 3) + conv(2 * hp, 2 * wp, 192, 256, 3) + conv(hp, wp, 384, 256, 3) + conv(h3, w3, 768, 256, 3);
-    f += 2 * conv(h3, w3, 256, 256, 3) + conv(hp, wp, 256, 256, 1);
-    f += 4 * conv(hp, wp, 256, 256, 3) + conv(2 * hp, 2 * wp, 256, 256, 1);
-    f += 4 * conv(2 * hp, 2 * wp, 256, 256, 3) + conv(4 * hp, 4 * wp, 256, 256, 1);
-    f += 4 * conv(4 * hp, 4 * wp, 256, 256, 3) + conv(8 * hp, 8 * wp, 256, 256, 1);
-    f += conv(8 * hp, 8 * wp, 256, 128, 3) + conv(16 * hp, 16 * wp, 128, 128, 3) + conv(16 * hp, 16 * wp, 128, 4, 1);
-    double f_pose = 2.0 * (D * 512 + 2 * 512 * 512 + 512 * 13);
-    return 2 * f_enc + f_dec + 2 * f + 2 * f_pose;
-}
-
-__global__ void fill_rand_f16_kernel(f16* p, int64_t n, uint32_t seed, float scale) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t step = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += step) {
-        uint32_t x = (uint32_t)i * 0x9E3779B1u + seed;
-        x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-        p[i] = (f16)(((float)(x >> 8) * (2.0f / 16777216.0f) - 1.0f) * scale);
-    }
-}
-
-template <int BM, int BN, int WMS, int WNS, int ABL>
-static int bench_launch2(bool split, const GemmParams& p, hipStream_t st) {
-    if (split) {
-        constexpr int smem = gemm2_smem_bytes<true, BM, BN>();
-        HIPCHK(hipFuncSetAttribute((const void*)gemm2_kernel<true, A_DENSE, EPI_F32, BM, BN, WMS, WNS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        hipLaunchKernelGGL((gemm2_kernel<true, A_DENSE, EPI_F32, BM, BN, WMS, WNS, ABL>), dim3((unsigned)(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN))), dim3(WMS * WNS * 64), smem, st, p);
-    } else {
-        constexpr int smem = gemm2_smem_bytes<false, BM, BN>();
-        HIPCHK(hipFuncSetAttribute((const void*)gemm2_kernel<false, A_DENSE, EPI_F32, BM, BN, WMS, WNS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        hipLaunchKernelGGL((gemm2_kernel<false, A_DENSE, EPI_F32, BM, BN, WMS, WNS, ABL>), dim3((unsigned)(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN))), dim3(WMS * WNS * 64), smem, st, p);
-    }
-    return 0;
-}
-
-// tile: 0 = automatic product selection, 1 = 128x128, 2 = 256x256, 3 = 256x128; abl: gemm2 ablation (tile 2/3 only)
-static float g_bench_ghz = 0.f;
-extern "C" float sta_bench_gemm_last_ghz() { return g_bench_ghz; }
-
-extern "C" int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, int tile, int abl, float* ms_out, void* stream) {
-    REQUIRE(h && ms_out && iters > 0, "bad argument");
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t st = (hipStream_t)stream;
-    const bool split = h->prec != STA_PREC_F16;
-    int64_t bytes = ((int64_t)M * K + (int64_t)N * K) * 4 + (int64_t)M * N * 4 + N * 4 + (1 << 16);
-    CHK(ensure_ws(h, bytes));
-    h->dry = false;
-    Bump ws{h->ws, h->ws_cap};
-    Planes A = ws.act(M, K, true);
-    Lin Wt; Wt.N = N; Wt.K = K; Wt.w = ws.act(N, K, true);
-    Wt.bias = (float*)ws.take((int64_t)N * 4);
-    float* C = (float*)ws.take((int64_t)M * N * 4);
-    unsigned long long* clk = (unsigned long long*)ws.take(16);
-    REQUIRE(!ws.overflow, "internal: bench workspace overflow");
-    // random operands (both hi and lo halves of every row block get full-range random bits: the data
-    // dependence of MFMA power is what matters for a throughput number)
-    hipLaunchKernelGGL(fill_rand_f16_kernel, dim3(2048), dim3(256), 0, st, A.hi, (int64_t)M * K * 2, 1u, 1.0f);
-    hipLaunchKernelGGL(fill_rand_f16_kernel, dim3(2048), dim3(256), 0, st, Wt.w.hi, (int64_t)N * K * 2, 3u, 0.03f);
-    HIPCHK(hipMemsetAsync(Wt.bias, 0, (size_t)N * 4, st));
-    if (!split) { A.lo = nullptr; }   // f16 mode reads the same buffer as [K/32][M][32]
-    GemmParams p = gp_dense(A, K, Wt, M);
-    p.C32 = C; p.ldc = N; p.ldr = N; p.zero_page = h->zero_page;
-    const int keep = h->gemm_variant;
-    auto once = [&]() -> int {
-        if (tile >= 2 && abl > 0) {
-            if (tile == 2) {
-                switch (abl) {
-                    case 1: return bench_launch2<256, 256, 2, 4, 1>(split, p, st);
-                    case 2: return bench_launch2<256, 256, 2, 4, 2>(split, p, st);
-                    case 3: return bench_launch2<256, 256, 2, 4, 3>(split, p, st);
-                    case 4: return bench_launch2<256, 256, 2, 4, 4>(split, p, st);
-                    case 5: return bench_launch2<256, 256, 2, 4, 5>(split, p, st);
-                    case 6: return bench_launch2<256, 256, 2, 4, 6>(split, p, st);
-                    default: return bench_launch2<256, 256, 2, 4, 7>(split, p, st);
-                }
-            }
-            switch (abl) {
-                case 1: return bench_launch2<192, 128, 2, 4, 1>(split, p, st);
-                case 2: return bench_launch2<192, 128, 2, 4, 2>(split, p, st);
-                case 3: return bench_launch2<192, 128, 2, 4, 3>(split, p, st);
-                case 4: return bench_launch2<192, 128, 2, 4, 4>(split, p, st);
-                case 5: return bench_launch2<192, 128, 2, 4, 5>(split, p, st);
-                case 6: return bench_launch2<192, 128, 2, 4, 6>(split, p, st);
-                default: return bench_launch2<192, 128, 2, 4, 7>(split, p, st);
-            }
-        }
-        if (tile == 2) return bench_launch2<256, 256, 2, 4, 0>(split, p, st);
-        if (tile == 3) return bench_launch2<256, 128, 4, 2, 0>(split, p, st);
-        if (tile == 10) return split ? launch_gemm2<true, A_DENSE, EPI_F32, 256, 128, 4, 2, 3>(p, st)
-                                     : launch_gemm2<false, A_DENSE, EPI_F32, 256, 128, 4, 2, 3>(p, st);   // 3-stage ring experiment
-        if (tile == 16) { GemmParams q = p; q.mx = 1; return launch_gemm2<true, A_DENSE, EPI_F32, 192, 128, 2, 4, 2, true>(q, st); }   // the shipped f16mx kernel (random bits as operands: timing only)
-        if (tile == 17) { GemmParams q = p; q.mx = 1; q.resid = q.C32; q.ldr = q.ldc; return launch_gemm2<true, A_DENSE, EPI_F32, 192, 128, 2, 4, 2, true>(q, st); }
-        if (tile == 14) return bench_launch2<256, 256, 2, 4, 16>(split, p, st);  // instruction mix of the MX-fp8 correction scheme (not a GEMM)
-        if (tile == 15) return bench_launch2<192, 128, 2, 4, 16>(split, p, st);
-        if (tile == 11) return bench_launch2<256, 256, 2, 4, 8>(split, p, st);   // staggered DMA issue
-        if (tile == 12) return bench_launch2<192, 128, 2, 4, 8>(split, p, st);
-        if (tile == 5) return bench_launch2<192, 256, 2, 4, 0>(split, p, st);
-        if (tile == 6) return bench_launch2<192, 128, 2, 4, 0>(split, p, st);
-        if (tile == 13) { GemmParams q = p; q.resid = q.C32; q.ldr = q.ldc; return bench_launch2<192, 128, 2, 4, 0>(split, q, st); }   // in-place residual like attn.proj / mlp.fc2
-        if (tile == 7) return bench_launch2<192, 128, 2, 2, 0>(split, p, st);
-        if (tile == 8) return bench_launch2<128, 192, 2, 2, 0>(split, p, st);
-        if (tile == 9) return bench_launch2<128, 128, 2, 2, 0>(split, p, st);
-        h->gemm_variant = tile == 1 ? 1 : 0;
-        int r = launch_gemm<A_DENSE, EPI_F32>(h, p, st);
-        h->gemm_variant = keep;
-        return r;
-    };
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    for (int i = 0; i < 2; ++i) CHK(once());
-    HIPCHK(hipEventRecord(e0, st));
-    for (int i = 0; i < iters; ++i) CHK(once());
-    HIPCHK(hipEventRecord(e1, st));
-    HIPCHK(hipEventSynchronize(e1));
-    HIPCHK(hipGetLastError());
-    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-    *ms_out = ms / iters;
-    // effective shader clock during this kernel (DVFS: the chip clocks to its power budget): a few extra launches
-    // with the in-kernel probe on (s_memtime vs the constant 100 MHz s_memrealtime), sampled on every 64th block
-    HIPCHK(hipMemsetAsync(clk, 0, 16, st));
-    p.clk_dbg = clk;
-    for (int i = 0; i < 3; ++i) CHK(once());
-    p.clk_dbg = nullptr;
-    unsigned long long hc[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(hc, clk, 16, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    g_bench_ghz = hc[1] ? (float)((double)hc[0] / ((double)hc[1] / 100e6) * 1e-9) : 0.f;
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    return 0;
-}
+#include "sta_bench.inc"    // FLOP model + GEMM micro-benchmark entry points
 
 #include "sta_debug.inc"
