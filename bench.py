@@ -175,7 +175,7 @@ def main():
     if not args.no_kernel_timing:
         # the fp32-epilogue GEMM class (attn.proj / mlp.fc2 / embeds) runs on several tile families;
         # report the kernel SYMBOL with the largest total time so the rocprofv3 row is comparable.
-        sp = "true" if args.precision == "f16x3" else "false"
+        sp = "false" if args.precision == "f16" else "true"     # SPLIT template flag of the kernel symbol
         # (epilogue 5 = EPI_F32R, the in-place-residual specialisation that attn.proj / mlp.fc2 run at this scale)
         names = {1: f"gemm_kernel<{sp}, 0, 0>", 2: f"gemm2_kernel<{sp}, 0, 5, 256, 256, 2, 4, 0>",
                  3: f"gemm2_kernel<{sp}, 0, 5, 256, 128, 4, 2, 0>", 4: f"gemm2_kernel<{sp}, 0, 5, 192, 256, 2, 4, 0>",
@@ -193,8 +193,8 @@ def main():
                     "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": pmc_traffic(names[fam][:-3]),
                     "algorithmic_bytes_per_launch": int(by / n), "gflop_per_launch": round(fl / n / 1e9, 2),
                     "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
-                    "mfma_products_per_flop": 3 if args.precision == "f16x3" else 1,
-                    "issued_frac": round(ach * (3 if args.precision == "f16x3" else 1) / PEAK_F16_MFMA_TFLOPS, 4)}
+                    "mfma_products_per_flop": {"f16x3": 3, "f16mx": 2, "f16": 1}[args.precision],
+                    "issued_frac": round(ach * {"f16x3": 3, "f16mx": 2, "f16": 1}[args.precision] / PEAK_F16_MFMA_TFLOPS, 4)}
             if fam == 5 and ghz.value > 0:
                 # DVFS: the chip clocks to its power budget; peak available at the clock the kernel actually ran at
                 roof["effective_clock_ghz"] = round(ghz.value, 3)
