@@ -11,9 +11,15 @@ Pairs are independent units: ranks process disjoint pairs (weak scaling); the on
 RCCL all-gather per step of the compact per-pair outputs a SLAM consumer reads (pose 4x4, pose
 confidence, depth = pts[...,2] and the confidence map; slam.py:165-185).
 
-Prints ONE JSON line on rank 0 with the throughput, the roofline of the dominant kernel (live HIP
-event timing of every launch of gemm_kernel<.., dense, fp32-epilogue> inside the timed region) and
-a CPU baseline (the oracle restatement timed on the host cores on a bounded sample).
+`python bench.py --gpus N` with N > 1 from a bare shell (no WORLD_SIZE in the environment) starts its own N ranks
+by re-executing itself under torch.distributed.run on 127.0.0.1.
+
+Prints ONE JSON line on rank 0 with the throughput (`value` = K steps / wall time between two
+barrier + synchronize brackets, max over ranks; `median_ms_per_step` = median of the K per-step stream-event
+durations of rank 0), the roofline of the dominant kernel (live HIP event timing of every launch of the in-place
+residual GEMM class inside the timed region - those per-launch event records are part of the timed region) and a CPU
+baseline (a torch-CPU re-expression of the forward and the C + OpenMP oracle, timed on the host cores on a bounded
+sample).
 """
 import argparse
 import json
@@ -29,19 +35,22 @@ PEAK_F16_MFMA_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak, MI355X_MICROARCH
 
 
 def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_traffic.json <- tools/pmc_summary.py; FETCH_SIZE doubled per the gfx950
-    correction).  bench.py cannot collect PMCs itself; null when no summary is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        for k, v in d.items():
-            if k.startswith(kernel_prefix):
-                return int(v["avg_hbm_bytes_per_launch"])
-    except Exception:   # noqa: BLE001
-        pass
-    return None
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
+    (profiles/rNN_pmc_traffic.json <- tools/pmc_summary.py; FETCH_SIZE doubled per the gfx950
+    correction).  bench.py cannot collect PMCs itself (they need their own rocprofv3 --pmc passes), so this is a
+    STATIC figure from the profiled run of the same command, not a measurement of this run: the source file is
+    reported beside it.  (None, None) when no summary is committed."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            for k, v in d.items():
+                if k.startswith(kernel_prefix):
+                    return int(v["avg_hbm_bytes_per_launch"]), os.path.relpath(path, ROOT) + " (static: separate rocprofv3 --pmc passes)"
+        except Exception:   # noqa: BLE001
+            pass
+    return None, None
 
 
 def slam_probe(model, dev, iters=20):
@@ -78,30 +87,92 @@ def slam_probe(model, dev, iters=20):
             "note": "frontend-only estimate for a TUM-style keyframe (1 encode + 5 accepted pairs); the reference's CPU stages (ORB/DBoW3, PGO) are not included"}
 
 
-def cpu_baseline(H=384, W_=512):
-    """Oracle (port of the reference algorithm, fp32, C + OpenMP) on the host cores: ONE pair of the metric's own
-    workload (512x384, 1857.5 GFLOP) - a bounded sample (~20-30 s on the GPU box's cores) of the per-pair work the
-    GPU line is quoted on."""
-    import numpy as np  # noqa: F401
-    from oracle import sta_oracle as O
+def host_cores():
+    """Cores this process may actually use: min(cpu_count, affinity mask, cgroup CPU quota).  The GPU boxes report 256
+    logical CPUs but run the container under a 16-CPU cgroup quota (cpu.max = 1600000 100000): 256 threads on that
+    quota made the round-1 baseline 5x slower than 16 threads, and torch's CPU kernels stall outright."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                tok = f.read().split()
+            if path.endswith("cpu.max"):
+                if tok[0] != "max":
+                    n = min(n, max(1, int(int(tok[0]) / int(tok[1]))))
+            else:
+                q = int(tok[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                        n = min(n, max(1, int(q / int(f2.read().split()[0]))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def cpu_baseline_subprocess(H, W_, timeout_s=300):
+    """Run cpu_baseline() in its own process under a hard timeout: a CPU-side stall must never cost the bench line."""
+    import subprocess
+    cores = host_cores()
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores), MKL_NUM_THREADS=str(cores), HIP_VISIBLE_DEVICES="")
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", str(H), str(W_)],
+                           env=env, capture_output=True, text=True, timeout=timeout_s)
+        for line in reversed(r.stdout.splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"error": f"no result (rc {r.returncode}): {r.stderr[-300:]}"}
+    except subprocess.TimeoutExpired:
+        return {"error": f"CPU baseline exceeded {timeout_s} s on {cores} cores and was stopped"}
+
+
+def cpu_baseline(H=384, W_=512, with_c_port=True):
+    """CPU baseline on the host cores, ONE pair of the metric's own workload (512x384, 1857.5 GFLOP) per timed pass:
+    (1) `value`: oracle/torch_cpu.py, a torch-CPU (MKL / oneDNN) re-expression of the reference forward with
+    torch.set_num_threads(all cores) - the kernels the reference's own CPU path would run on, best of 2 passes after one
+    warm-up; (2) `c_port`: the C + OpenMP oracle (oracle/sta_oracle.py), the checker of the parity tests, one pass.
+    Both are ports (the reference's Python does not travel to the GPU box); bounded to ~10-40 s of CPU work in total."""
+    import torch
+    from oracle import torch_cpu as T
     from vista_slam_amd import weights as Wt
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    cores = host_cores()
     sd = Wt.state_dict(Wt.FULL, seed=43)
     imgs = Wt.synth_images(2, H, W_, seed=43, tag=0)
-    t0 = time.perf_counter()
-    O.forward_pair(Wt.FULL, sd, imgs[:1], imgs[1:])
-    dt = time.perf_counter() - t0
     gf = 1857.47 if (H, W_) == (384, 512) else 435.81
-    return {"value": round(1.0 / dt, 5), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"1 pair @{W_}x{H} ({gf:.1f} GFLOP, {dt:.1f} s), oracle/sta_oracle (C + OpenMP restatement of the reference forward)",
-            "gflops": round(gf / dt, 1)}
+    torch.set_num_threads(cores)
+    T.forward_pair(Wt.FULL, sd, imgs[:1], imgs[1:])                      # warm-up (thread pool, oneDNN primitive cache)
+    best = 1e30
+    for _ in range(2):
+        t0 = time.perf_counter()
+        T.forward_pair(Wt.FULL, sd, imgs[:1], imgs[1:])
+        best = min(best, time.perf_counter() - t0)
+    res = {"value": round(1.0 / best, 5), "unit": "pairs/s", "cores": cores, "kind": "port", "impl": "torch-cpu",
+           "sample": f"1 pair @{W_}x{H} ({gf:.1f} GFLOP) x 3 passes, best of the last 2 = {best:.2f} s; oracle/torch_cpu.py "
+                     f"(torch {torch.__version__} CPU kernels, torch.set_num_threads({cores}) = usable cores: "
+                     f"{os.cpu_count()} logical CPUs under the container's cgroup CPU quota)",
+           "gflops": round(gf / best, 1)}
+    if with_c_port:
+        from oracle import sta_oracle as O
+        os.environ["OMP_NUM_THREADS"] = str(cores)
+        t0 = time.perf_counter()
+        O.forward_pair(Wt.FULL, sd, imgs[:1], imgs[1:])
+        dt = time.perf_counter() - t0
+        res["c_port"] = {"value": round(1.0 / dt, 5), "unit": "pairs/s", "cores": cores, "gflops": round(gf / dt, 1),
+                         "sample": f"1 pair @{W_}x{H}, {dt:.1f} s, oracle/sta_oracle.py (C + OpenMP restatement; the parity checker)"}
+    return res
 
 
 def main():
+    if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-only":       # child of cpu_baseline_subprocess
+        print(json.dumps(cpu_baseline(int(sys.argv[2]), int(sys.argv[3]))), flush=True)
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16", "f16mx"])
     ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="image pairs per GPU per step")
@@ -114,6 +185,18 @@ def main():
     ap.add_argument("--slices", type=int, default=1, help="batch slices run concurrently on internal streams (1 or 2)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, RCCL) and relay the JSON line
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
+
     import torch
     import torch.distributed as dist
     from vista_slam_amd import weights as Wt
@@ -125,7 +208,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.device_count() > local, f"rank {rank}: local GPU {local} not visible ({torch.cuda.device_count()} devices)"
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
 
@@ -144,10 +228,17 @@ def main():
     if world > 1:
         gathered = torch.empty(world * B, P.compact_elems_per_pair(H, W_), device=dev)
 
-    def step():
+    gather_ev = []
+
+    def step(timed=False):
         main_o, supp_o = model.forward_pair(img_a, img_b)
         if world > 1:   # compact per-pair outputs -> every rank (slam.py consumes pose, conf, depth, conf map)
+            if timed:
+                e0 = torch.cuda.Event(enable_timing=True); e0.record()
             P.gather_compact(P.pack_compact(main_o, supp_o), world * B, out=gathered)
+            if timed:
+                e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                gather_ev.append((e0, e1))
         return main_o, supp_o
 
     for _ in range(args.warmup):
@@ -158,17 +249,27 @@ def main():
     if not args.no_kernel_timing:
         model.kernel_timing(True)
     torch.cuda.synchronize()
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    step_ev[0].record()
+    for i in range(args.steps):
+        out = step(timed=True)
+        step_ev[i + 1].record()             # stream-ordered marker, no host sync inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    my_dt = dt
+    step_ms = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
+    per_rank = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [round(B * args.steps / float(x.item()), 3) for x in allt]
+        dt = max(float(x.item()) for x in allt)
+    gather_ms = sorted(a.elapsed_time(b) for a, b in gather_ev)
     assert bool(torch.isfinite(out[0]["pts3d_pred"]).all()), "non-finite output"
 
     roof = None
@@ -188,9 +289,11 @@ def main():
         model.kernel_timing(False)
         if n > 0 and ms > 0:
             ach = fl / (ms * 1e-3) / 1e12
+            traffic, traffic_src = pmc_traffic(names[fam][:-3])
             roof = {"bound": "mfma", "kernel": names[fam] + " (attn.proj / mlp.fc2 fp32-epilogue GEMMs)",
                     "achieved": round(ach, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": pmc_traffic(names[fam][:-3]),
+                    "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "timing": "HIP events recorded by the library around every launch of this kernel on its launch stream, inside the timed region (their cost is part of `value`)",
                     "algorithmic_bytes_per_launch": int(by / n), "gflop_per_launch": round(fl / n / 1e9, 2),
                     "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
                     "mfma_products_per_flop": {"f16x3": 3, "f16mx": 2, "f16": 1}[args.precision],
@@ -205,7 +308,9 @@ def main():
         flops_pair = model.flops_per_pair(H, W_)
         res = {"metric": "STA image-pairs/sec @512x384", "value": round(pairs / dt, 3), "unit": "pairs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(dt / args.steps * 1e3, 3), "median_ms_per_step": round(median_ms, 3),
+               "value_at_median_step": round(B * world / (median_ms * 1e-3), 3),
+               "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": {"f16x3": "f16x3-split MFMA, fp32 accumulate", "f16": "f16 MFMA, fp32 accumulate", "f16mx": "f16 MFMA + block-scaled fp8 correction MFMA (linears, convolutions), f16x3 attention, fp32 accumulate"}[args.precision],
                "data": "synthetic (uint8-uniform RGB pairs, procedural weights of the full 438M-parameter architecture)",
                "config": {"workload": f"512x384 batch={B} pairs/GPU STA two-view forward (BASELINE configs[1])",
@@ -215,6 +320,10 @@ def main():
                "whole_path_tflops": round(pairs * flops_pair / dt / 1e12, 1),
                "workspace_gb": round(model.workspace_bytes() / 1e9, 2),
                "roofline": roof}
+        if world > 1:
+            res["per_rank_pairs_per_s"] = per_rank
+            res["all_gather_ms_median"] = round(gather_ms[len(gather_ms) // 2], 4) if gather_ms else None
+            res["all_gather_bytes_per_rank"] = int(B * P.compact_elems_per_pair(H, W_) * 4)
         if world == 1 and args.precision == "f16x3" and not args.no_alt_precision:
             # the opt-in precision on the same inputs, same K steps (informative: `value` above is the default f16x3)
             model.set_precision("f16mx")
@@ -228,15 +337,13 @@ def main():
             dt2 = time.perf_counter() - t1
             model.set_precision("f16x3")
             res["opt_in_f16mx"] = {"value": round(B * args.steps / dt2, 3), "unit": "pairs/s", "ms_per_step": round(dt2 / args.steps * 1e3, 3),
-                                   "note": "precision f16mx: linears and convolutions as f16 main product + one block-scaled fp8 correction MFMA; "
-                                           "parity vs the reference goldens <= 3.2e-5 (f16x3: <= 7e-6; bar 1e-3), see DESIGN.md section 2"}
+                                   "note": "NOT a parity-qualified mode (no credit claimed): f16 main product + one block-scaled fp8 correction MFMA; "
+                                           "holds the reference-architecture goldens at <= 9e-5 but exceeds the 1e-3 bar on two sharpened "
+                                           "tiny-config stress sets (1.1e-3 / 5.6e-3), see DESIGN.md section 2"}
         if world == 1 and not args.no_slam_probe:
             res["slam_224_b1"] = slam_probe(model, dev)
         if world == 1 and not args.no_cpu_baseline:
-            try:
-                res["cpu_baseline"] = cpu_baseline(224, 224) if args.cpu_baseline_224 else cpu_baseline()
-            except Exception as e:   # noqa: BLE001  (the baseline is a report, never the product)
-                res["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+            res["cpu_baseline"] = cpu_baseline_subprocess(224, 224) if args.cpu_baseline_224 else cpu_baseline_subprocess(H, W_)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -103,6 +103,11 @@ int sta_finalize_weights(sta_handle* h);
 int sta_encode(sta_handle* h, const float* img_dev, int B, int H, int W,
                float* feat_dev, void* stream);
 
+/* enc_norm (the encoder's final LayerNorm) on `rows` token rows of enc_dim floats: what
+ * _encode_image(normalize=True) adds after the blocks (sta_model.py:172-173).  The forward / SLAM paths call
+ * _encode_image(normalize=False) (sta_model.py:259,267; slam.py:144), so nothing on the hot path runs this. */
+int sta_encoder_norm(sta_handle* h, const float* feat_dev, int64_t rows, float* out_dev, void* stream);
+
 /* feat1/feat2 [B, N, enc_dim] (N = hp*wp tokens, hp x wp patch grid).
  * out1/out2: arrays of (dec_depth+1) device pointers, each [B, N+1, dec_dim] or NULL to skip
  * that layer.  Index 0 = decoder input (embed + pose token), index i = output of block i,

@@ -61,6 +61,10 @@ int sta_debug_svd_orthogonalize(sta_handle* h, const float* m, float* r, int B, 
  * duration (ms) and tile family of up to `cap` launches (tools/inmodel_vs_micro.py). */
 int sta_kernel_timing_dump(sta_handle* h, int cap, double* flops, float* ms, int* variant, int* n_out);
 
+/* The same record for EVERY GEMM / convolution launch after sta_kernel_timing(h, 2) (experiments: per-shape in-model
+ * durations of a forced tile family, tools/gemm_tiles.py shapes): shape5 = {M, N, K, epilogue id, A-loader id}. */
+int sta_kernel_timing_dump_shapes(sta_handle* h, int cap, int* shape5, float* ms, int* variant, int* n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -257,6 +257,84 @@ def gen_fmt():
     print("[golden] fmt done", points.shape, flush=True)
 
 
+def _ref_slam_utils():
+    """The reference's slam_utils module (colorama stubbed: terminal colours only)."""
+    import types
+    if "colorama" not in sys.modules:
+        col = types.ModuleType("colorama")
+        class _Any:
+            def __getattr__(self, _name):
+                return ""
+        col.Fore = _Any(); col.Style = _Any()
+        sys.modules["colorama"] = col
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_slam_utils", "/root/reference/vista_slam/utils/slam_utils.py")
+    su = importlib.util.module_from_spec(spec); spec.loader.exec_module(su)
+    return su
+
+
+def gen_f2(name, cfg, H, W_, nview, sub=1, seed=43, tag=21):
+    """Keyframe edge regression: OnlineSLAM.add_view + regress_two_views (slam.py:142-189) executed
+    statement by statement on the REFERENCE model (its own _encode_image / _decode_stereo / head_pose_s / head_pts and
+    slam_utils.estimate_intrinsic_from_pts3d) for the edges (i, j), i = last view, j < i - slam.py itself cannot be
+    imported here (pypose / cv2 / DBoW3 absent), so the method body is replayed with the same calls in the same order;
+    pp.mat2SE3 is left out (the 4x4 pose is stored).  The threshold is the midpoint between two non-adjacent confidences, so accepted
+    and rejected edges both occur; the adjacent edge (i-j == 1) is exempt from rejection (slam.py:169)."""
+    t0 = time.time()
+    su = _ref_slam_utils()
+    sd = W.state_dict(cfg, seed=seed)
+    model = load_reference_model(cfg, sd)
+    imgs = torch.from_numpy(W.synth_images(nview, H, W_, seed=seed, tag=tag).copy())
+    ts = torch.tensor([[H, W_]])
+    enc_features, enc_pos = [], []
+    for v in range(nview):                                     # add_view (slam.py:142-151)
+        f, p_ = model._encode_image(imgs[v:v + 1], ts, normalize=False)
+        enc_features.append(f); enc_pos.append(p_)
+    i = nview - 1
+    res = {}
+
+    def regress_two_views(i, j, rel_pose_thres):               # slam.py:153-189
+        dec_feat_ij, dec_feat_ji = model._decode_stereo(enc_features[i], enc_features[j], enc_pos[i], enc_pos[j])
+        pose_ij = model.head_pose_s(dec_feat_ij[-1][:, 0, :])
+        rel_pose_conf_ij = pose_ij["conf"]
+        if rel_pose_conf_ij < rel_pose_thres and i - j != 1:
+            return pose_ij["pose"], rel_pose_conf_ij, None, None, None
+        ji_in = [enc_features[j]] + [tok[:, 1:, :].float() for tok in dec_feat_ji]
+        ij_in = [enc_features[i]] + [tok[:, 1:, :].float() for tok in dec_feat_ij]
+        ji_ret = model.head_pts(ji_in, ts)
+        ij_ret = model.head_pts(ij_in, ts)
+        pcls = torch.cat([ij_ret["pts3d"], ji_ret["pts3d"]], dim=0)
+        confs = torch.cat([ij_ret["conf"], ji_ret["conf"]], dim=0)
+        intri = su.estimate_intrinsic_from_pts3d(pcls, confs, shared_intrinsic=True)
+        return pose_ij["pose"], rel_pose_conf_ij, confs, intri, pcls[..., 2]
+
+    probe = [float(regress_two_views(i, j, -1.0)[1]) for j in range(i)]
+    nonadj = sorted(probe[:-1])
+    k = max(1, len(nonadj) // 2)
+    thres = 0.5 * (nonadj[k - 1] + nonadj[k])                  # midpoint: rejects the lower non-adjacent edges with a margin
+                                                               # far above fp32 noise (a 1e-6 error cannot flip an edge)
+    acc = []
+    for j in range(i):
+        pose, c, confs, intri, depths = regress_two_views(i, j, thres)
+        res[f"pose_{j}"] = pose[0].numpy(); res[f"conf_{j}"] = np.float32(float(c))
+        acc.append(confs is not None)
+        if confs is not None:
+            res[f"confs_{j}"] = confs.numpy()[:, ::sub, ::sub].copy()
+            res[f"depths_{j}"] = depths.numpy()[:, ::sub, ::sub].copy()
+            res[f"intri_{j}"] = intri.numpy()
+            res[f"confs_l2_{j}"] = np.sqrt((confs.double().numpy() ** 2).sum())
+            res[f"depths_l2_{j}"] = np.sqrt((depths.double().numpy() ** 2).sum())
+    res["accepted"] = np.array(acc)
+    res["thres"] = np.float64(thres)
+    # _encode_image(normalize=True) (sta_model.py:172-173) of the last view: the enc_norm path
+    res["enc_feat_norm"] = model._encode_image(imgs[i:i + 1], ts, normalize=True)[0].numpy()[:, ::max(1, sub)].copy()
+    meta = dict(H=H, W=W_, nview=nview, sub=sub, seed=seed, tag=tag)
+    res["meta_keys"] = np.array(list(meta.keys()))
+    res["meta_vals"] = np.array([float(v) for v in meta.values()], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **res)
+    print(f"[golden] {name}: accepted {acc} thres {thres:.6f} confs {probe} in {time.time() - t0:.1f}s", flush=True)
+
+
 CASES = {
     "sharpfull": [dict(name="full_224_b1_sharp", cfg=W.FULL, H=224, W_=224, B=1, sub=8, qk_gain=3.0)],
     "tiny": [
@@ -288,6 +366,9 @@ if __name__ == "__main__":
             gen_post()
         elif s == "fmt":
             gen_fmt()
+        elif s == "f2":
+            gen_f2("f2_tiny_48x64", W.TINY, 48, 64, nview=5)
+            gen_f2("f2_full_224", W.FULL, 224, 224, nview=4, sub=8)
         else:
             for c in CASES[s]:
                 run_case(**c)

@@ -277,6 +277,32 @@ def forward_pair(cfg, sd, img_a, img_b):
     return res
 
 
+def encode_image_normalized(cfg, sd, img):
+    """_encode_image(normalize=True) (sta_model.py:163-174): the blocks, then enc_norm."""
+    x, pos = encode_image(cfg, sd, img)
+    return ln(sd, "enc_norm", x, cfg.ln_eps), pos
+
+
+# ------------------------------------------------------------------ keyframe edge regression (SURVEY 8 f2)
+def regress_two_views(cfg, sd, enc_feat_i, enc_feat_j, pos_i, pos_j, adjacent, rel_pose_thres, H, W_):
+    """OnlineSLAM.regress_two_views (vista_slam/slam.py:153-189) for one edge (i, j), B = 1:
+    _decode_stereo -> head_pose_s on the ij pose token -> early return when `conf < rel_pose_thres and i-j != 1`
+    (:169-170) -> head_pts on both sides (ji first, :179-180) -> pcls = cat(ij, ji), confs = cat(ij, ji) ->
+    estimate_intrinsic_from_pts3d(shared_intrinsic=True) -> depths = pcls[..., 2].
+    Returns (pose_ij 4x4, rel_pose_conf_ij, confs, intri, depths); the last three are None for a rejected edge.
+    (The reference converts pose_ij with pp.mat2SE3 - see mat_to_se3 below; pypose is absent here.)"""
+    dec_ij, dec_ji = decode_stereo(cfg, sd, enc_feat_i, enc_feat_j, pos_i, pos_j)
+    pose, conf = head_pose(cfg, sd, dec_ij[-1][:, 0, :])
+    if float(conf[0]) < rel_pose_thres and not adjacent:
+        return pose[0], float(conf[0]), None, None, None
+    pts_ji, conf_ji = head_pts(cfg, sd, [enc_feat_j] + [t[:, 1:, :] for t in dec_ji], H, W_)
+    pts_ij, conf_ij = head_pts(cfg, sd, [enc_feat_i] + [t[:, 1:, :] for t in dec_ij], H, W_)
+    pcls = np.concatenate([pts_ij, pts_ji], 0)
+    confs = np.concatenate([conf_ij, conf_ji], 0)
+    intri = estimate_intrinsic_from_pts3d(pcls, confs, shared_intrinsic=True)
+    return pose[0], float(conf[0]), confs, intri, pcls[..., 2]
+
+
 # ------------------------------------------------------------------ post-STA reductions (SURVEY 8 f1)
 def estimate_intrinsic_from_pts3d(pts3d, confidence, shared_intrinsic=False):
     """vista_slam/utils/slam_utils.py:8-79, restated in numpy float32 (same formula, same clamps)."""

@@ -425,6 +425,77 @@ def test_keyframe_scheduler_f2_matches_sequential_edges(G, cfg, H, Wd, nview):
     assert 0 < n_rej < len(js)
 
 
+@pytest.mark.parametrize("name,cfg", [("f2_tiny_48x64", "tiny"), ("f2_full_224", "full")])
+def test_keyframe_scheduler_f2_vs_reference_golden(G, name, cfg):
+    """f2 pinned by the reference: sta_regress_views (one batched call for all edges of the keyframe) and the per-edge
+    split calls vs tests/golden/f2_*.npz = regress_two_views (slam.py:153-189) replayed on the reference model with the
+    reference's estimate_intrinsic_from_pts3d (oracle/gen_golden.py gen_f2): accepted / rejected edges and the
+    adjacent-edge exemption of slam.py:169."""
+    import numpy as np
+    import torch
+    from helpers import load_golden, rel_l2, max_rel
+    from vista_slam_amd import weights as W
+    from vista_slam_amd.slam_scheduler import regress_views
+    if cfg == "full":
+        G.drop_models()
+    g, meta = load_golden(name)
+    H, Wd, nview, sub = int(meta["H"]), int(meta["W"]), int(meta["nview"]), int(meta["sub"])
+    m = G.model(cfg, 1.0, "f16x3")
+    G.set_variant(m, 0)
+    imgs = torch.from_numpy(W.synth_images(nview, H, Wd, seed=int(meta["seed"]), tag=int(meta["tag"]))).cuda()
+    feats = [m._encode_image(imgs[v:v + 1], None, normalize=False)[0] for v in range(nview)]
+    i = nview - 1
+    js = list(range(i))
+    thres = float(g["thres"])
+    res = regress_views(m, feats[i], [feats[j] for j in js], [i - j == 1 for j in js], thres, H, Wd)
+    torch.cuda.synchronize()
+    acc = g["accepted"]
+    assert acc.any() and not acc.all()
+    for j, r in zip(js, res):
+        assert abs(r.rel_pose_conf - float(g[f"conf_{j}"])) < 1e-4, (j, r.rel_pose_conf, float(g[f"conf_{j}"]))
+        assert rel_l2(r.pose.cpu().numpy(), g[f"pose_{j}"]) < TOL
+        assert r.accepted == bool(acc[j]), (j, r.rel_pose_conf, thres)
+        if not r.accepted:
+            assert r.confs is None and r.intri is None and r.depths is None
+            continue
+        confs, depths = r.confs.cpu().numpy(), r.depths.cpu().numpy()
+        assert rel_l2(confs[:, ::sub, ::sub], g[f"confs_{j}"]) < TOL
+        assert rel_l2(depths[:, ::sub, ::sub], g[f"depths_{j}"]) < TOL
+        assert abs(np.sqrt((confs.astype(np.float64) ** 2).sum()) / float(g[f"confs_l2_{j}"]) - 1) < TOL
+        assert abs(np.sqrt((depths.astype(np.float64) ** 2).sum()) / float(g[f"depths_l2_{j}"]) - 1) < TOL
+        assert max_rel(r.intri.cpu().numpy(), g[f"intri_{j}"]) < TOL
+    assert res[-1].accepted and float(g[f"conf_{i - 1}"]) < thres      # accepted only through the adjacency exemption
+    # _encode_image(normalize=True): the reference's default argument (sta_model.py:163,172-173)
+    fn, _ = m._encode_image(imgs[i:i + 1], None, normalize=True)
+    assert rel_l2(fn.cpu().numpy()[:, ::max(1, sub)], g["enc_feat_norm"]) < TOL
+    if cfg == "full":
+        G.drop_models()
+
+
+def test_forward_encodes_main_view_once_and_matches_forward_pair(G):
+    """forward(views) (sta_model.py:247-291) with two support views == forward_pair per support view (the main view is
+    encoded once, sta_model.py:257)."""
+    import torch
+    from helpers import rel_l2
+    from vista_slam_amd import weights as W
+    m = G.model("tiny", 1.0, "f16x3")
+    imgs = torch.from_numpy(W.synth_images(3, 48, 64, seed=43, tag=31)).cuda()
+    views = {"main_view": {"img": imgs[0:1]}, "neighbor_views": [{"img": imgs[1:2]}], "loop_views": [{"img": imgs[2:3]}]}
+    calls = []
+    orig = m._encode_image
+    m._encode_image = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        out = m(views)
+    finally:
+        m._encode_image = orig
+    assert len(calls) == 3                                   # main once + one per support view
+    for k, v in enumerate((imgs[1:2], imgs[2:3])):
+        mm, ss = m.forward_pair(imgs[0:1], v)
+        for key in ("pts3d_pred", "conf", "relative_pose", "relative_pose_conf"):
+            assert rel_l2(out["main_views"][k][key].cpu().numpy(), mm[key].cpu().numpy()) < 2e-5, (k, key)
+            assert rel_l2(out["support_views"][k][key].cpu().numpy(), ss[key].cpu().numpy()) < 2e-5, (k, key)
+
+
 def test_keyframe_scheduler_f2_all_rejected_and_errors(G):
     import torch
     from vista_slam_amd import weights as W
@@ -455,3 +526,52 @@ def test_post_sta_reductions_f1(G):
     assert torch.equal(depth, pts[..., 2])
     assert max_rel(cmean.cpu().numpy(), g["conf_mean"]) < 1e-6
     assert abs(float(s) - float(g["scale"])) < 1e-5 * abs(float(g["scale"]))
+
+
+def test_multi_gpu_layer_on_real_outputs_nccl_world1(G):
+    """SURVEY 8(e) on the GPU: pack_compact -> gather_compact (RCCL all_gather_into_tensor) -> unpack_compact on REAL
+    forward_pair outputs and pack_edges -> gather_edges on REAL regress_views results, in an `nccl` process group of
+    world size 1 (one GPU per box; the world-2 paths run under gloo in tests/test_dist_cpu.py)."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from vista_slam_amd import parallel as P
+    from vista_slam_amd import weights as W
+    from vista_slam_amd.slam_scheduler import regress_views
+    m = G.model("tiny", 1.0, "f16x3")
+    H, Wd, B = 48, 64, 3
+    imgs = torch.from_numpy(W.synth_images(2 * B, H, Wd, seed=43, tag=41)).cuda()
+    main_o, supp_o = m.forward_pair(imgs[:B], imgs[B:])
+    feats = [m._encode_image(imgs[v:v + 1], None, normalize=False)[0] for v in range(4)]
+    edges = regress_views(m, feats[3], [feats[j] for j in range(3)], [False, False, True], 0.0, H, Wd)
+    edges_rej = regress_views(m, feats[3], [feats[0]], [False], 2.0, H, Wd)     # sigmoid conf < 2: rejected
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda:0"))
+    try:
+        assert dist.get_backend() == "nccl"
+        local = P.pack_compact(main_o, supp_o)
+        assert local.shape == (B, P.compact_elems_per_pair(H, Wd))
+        allp = P.gather_compact(local, B)
+        torch.cuda.synchronize()
+        assert allp.data_ptr() != local.data_ptr()                       # went through the collective
+        um, us = P.unpack_compact(allp, H, Wd)
+        for u, o in ((um, main_o), (us, supp_o)):
+            assert torch.equal(u["relative_pose"], o["relative_pose"]) and torch.equal(u["relative_pose_conf"], o["relative_pose_conf"])
+            assert torch.equal(u["depth"], o["pts3d_pred"][..., 2]) and torch.equal(u["conf"], o["conf"])
+        res = P.gather_edges(P.pack_edges(edges + edges_rej, H, Wd), 4, H, Wd)
+        torch.cuda.synchronize()
+        for r, e in zip(res, edges + edges_rej):
+            assert r["accepted"] == e.accepted and abs(r["rel_pose_conf"] - e.rel_pose_conf) < 1e-7
+            assert torch.equal(r["pose"], e.pose)
+            if e.accepted:
+                assert torch.equal(r["depths"], e.depths) and torch.equal(r["confs"], e.confs) and torch.equal(r["intri"], e.intri)
+            else:
+                assert r["depths"] is None and r["confs"] is None and r["intri"] is None
+        assert not res[3]["accepted"] and all(r["accepted"] for r in res[:3])
+    finally:
+        dist.destroy_process_group()

@@ -101,3 +101,56 @@ def test_oracle_world_pointcloud_and_se3_vs_reference_golden():
     se3 = O.mat_to_se3(g["poses"])
     q = g["quat_xyzw"] * np.sign(g["quat_xyzw"][:, 3:4])
     assert np.abs(se3[:, 3:] - q).max() < 2e-6 and np.array_equal(se3[:, :3].astype(np.float32), g["poses"][:, :3, 3])
+
+
+def _f2_case(name, cfg):
+    g, meta = load_golden(name)
+    H, W_, nview = int(meta["H"]), int(meta["W"]), int(meta["nview"])
+    sd = W.state_dict(cfg, seed=int(meta["seed"]))
+    imgs = W.synth_images(nview, H, W_, seed=int(meta["seed"]), tag=int(meta["tag"]))
+    return g, meta, H, W_, nview, sd, imgs
+
+
+def test_regress_two_views_f2_vs_reference_golden():
+    """oracle.regress_two_views (restating slam.py:153-189) vs the golden produced by replaying that method
+    on the reference model + the reference's slam_utils: accepted and rejected edges, the adjacent-edge exemption."""
+    g, meta, H, W_, nview, sd, imgs = _f2_case("f2_tiny_48x64", W.TINY)
+    feats = [O.encode_image(W.TINY, sd, imgs[v:v + 1]) for v in range(nview)]
+    i = nview - 1
+    acc = g["accepted"]
+    assert acc.any() and not acc.all() and acc[-1]          # fixture holds both outcomes; the adjacent edge is accepted
+    for j in range(i):
+        pose, c, confs, intri, depths = O.regress_two_views(W.TINY, sd, feats[i][0], feats[j][0], feats[i][1], feats[j][1],
+                                                            i - j == 1, float(g["thres"]), H, W_)
+        assert abs(c - float(g[f"conf_{j}"])) < 2e-6
+        assert rel_l2(pose, g[f"pose_{j}"]) < TOL
+        assert (confs is not None) == bool(acc[j]), (j, c, float(g["thres"]))
+        if confs is None:
+            assert intri is None and depths is None
+            continue
+        assert rel_l2(confs, g[f"confs_{j}"]) < TOL and rel_l2(depths, g[f"depths_{j}"]) < TOL
+        assert max_rel(intri, g[f"intri_{j}"]) < TOL
+    # the adjacent edge would be rejected by its confidence alone: the exemption of slam.py:169 is what accepts it
+    assert float(g[f"conf_{i - 1}"]) < float(g["thres"])
+
+
+def test_encode_image_normalize_true_vs_reference_golden():
+    """_encode_image(normalize=True) (sta_model.py:172-173): enc_norm after the blocks."""
+    g, meta, H, W_, nview, sd, imgs = _f2_case("f2_tiny_48x64", W.TINY)
+    x, _pos = O.encode_image_normalized(W.TINY, sd, imgs[nview - 1:nview])
+    assert rel_l2(x, g["enc_feat_norm"]) < TOL
+
+
+@pytest.mark.parametrize("case", ["tiny_32x32_b1", "tiny_48x64_b2_sharp"])
+def test_torch_cpu_port_vs_reference_golden(case):
+    """oracle/torch_cpu.py (the torch-CPU re-expression bench.py times as the CPU baseline) vs the reference goldens."""
+    from oracle import torch_cpu as T
+    g, meta = load_golden(case)
+    H, W_, B = int(meta["H"]), int(meta["W"]), int(meta["B"])
+    sd = W.state_dict(W.TINY, seed=int(meta["seed"]), qk_gain=float(meta["qk_gain"]))
+    imgs = W.synth_images(2 * B, H, W_, seed=int(meta["seed"]), tag=0)
+    r = T.forward_pair(W.TINY, sd, imgs[:B], imgs[B:])
+    tol = TOL_SHARP if float(meta["qk_gain"]) != 1.0 else TOL
+    for side in ("main", "supp"):
+        for k, gk in (("pts3d", "pts3d"), ("conf", "conf"), ("pose", "pose"), ("pose_conf", "pose_conf")):
+            assert rel_l2(r[side][k], g[f"{side}_{gk}"]) < tol, (side, k)

@@ -1,0 +1,19 @@
+"""A few whole-path steps (8 pairs @512x384) with a forced GEMM tile family, for rocprofv3 --kernel-trace.
+
+    rocprofv3 --kernel-trace -d gpurun_out/prof_v9 -- python tools/model_steps.py 9 [steps] [precision]
+"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import torch
+from vista_slam_amd import weights as W, _lib
+from vista_slam_amd.sta_frontend import STAFrontend
+variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+prec = sys.argv[3] if len(sys.argv) > 3 else "f16x3"
+m = STAFrontend(W.FULL, "cuda:0", precision=prec).load_procedural(seed=43)
+_lib.check(m.lib.sta_set_gemm_variant(m._h, variant))
+B, H, Wd = 8, 384, 512
+imgs = torch.from_numpy(W.synth_images(2 * B, H, Wd, seed=43, tag=0)).cuda()
+for _ in range(steps):
+    m.forward_pair(imgs[:B], imgs[B:])
+torch.cuda.synchronize()

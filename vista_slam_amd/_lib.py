@@ -43,6 +43,7 @@ SIGNATURES = {
     "sta_forward_pair": (_i, [_vp, _fp, _fp, _i, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
                               C.POINTER(_vp), _vp]),
     "sta_encode_u8hwc": (_i, [_vp, _fp, _i, _i, _i, _fp, _vp]),
+    "sta_encoder_norm": (_i, [_vp, _fp, C.c_int64, _fp, _vp]),
     "sta_forward_pair_u8hwc": (_i, [_vp, _fp, _fp, _i, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
                                     C.POINTER(_vp), _vp]),
     "sta_estimate_intrinsics": (_i, [_vp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _vp]),
@@ -68,6 +69,7 @@ SIGNATURES = {
     # ---- debug / kernel-level test entry points
     "sta_set_gemm_variant": (_i, [_vp, _i]),
     "sta_kernel_timing_dump": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(_i), C.POINTER(_i)]),
+    "sta_kernel_timing_dump_shapes": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(C.c_float), C.POINTER(_i), C.POINTER(_i)]),
     "sta_debug_gemm": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _vp]),
     "sta_debug_qkv_rope": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _vp]),
     "sta_debug_attention": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _vp]),

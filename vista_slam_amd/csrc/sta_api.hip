@@ -24,6 +24,17 @@ static int set_err(const char* fmt, ...) {
 }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return set_err("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 #define CHK(x) do { int r_ = (x); if (r_ != 0) return r_; } while (0)
+// Every entry point runs on the handle's device and RESTORES the caller's current HIP device on return (torch keeps its
+// own notion of the current device; a library that leaves another one selected silently redirects the caller's next ops).
+struct DevScope {
+    int prev = -1; bool ok = true;
+    explicit DevScope(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess; else prev = -1;
+    }
+    ~DevScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define DEV_SCOPE(dev) DevScope dev_scope_(dev); do { if (!dev_scope_.ok) return set_err("hipSetDevice(%d) failed", (int)(dev)); } while (0)
 #define REQUIRE(c, ...) do { if (!(c)) return set_err(__VA_ARGS__); } while (0)
 
 // ------------------------------------------------------------------------------------------ types
@@ -69,7 +80,7 @@ struct sta_handle {
     int64_t weight_bytes = 0;
     // weights
     Lin patch; std::vector<EncBlk> enc; Lin dec_embed; float* pose_tok = nullptr;
-    std::vector<DecBlk> dec; LNp dec_norm;
+    std::vector<DecBlk> dec; LNp dec_norm, enc_norm;
     Lin act0_0, act0_1, act1_0, act1_1, act2_0, act3_0, act3_1;
     Lin rn[4]; Refine ref[4];      // ref[0] = refinenet1 ... ref[3] = refinenet4
     Lin head0, head2; F32Lin head4;
@@ -87,6 +98,7 @@ struct sta_handle {
     // per-launch timing of the dominant kernel (gemm_kernel<*, A_DENSE, EPI_F32>) for the roofline report
     unsigned long long* clk_buf = nullptr;   // {shader cycles, 100 MHz ticks} summed over sampled workgroups of the timed GEMMs
     bool ktime = false; std::vector<hipEvent_t> kev; int kn = 0; std::vector<double> kflops, kbytes; std::vector<int> kvar;
+    bool ktime_all = false; std::vector<int> kshape;   // sta_kernel_timing(h, 2): every GEMM / conv launch is timed; {M, N, K, EPI, AMODE} per record
     // optional two-slice concurrency (sta_set_concurrency)
     int n_streams = 1; hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     // f3 input-step tables (one cached geometry)
@@ -217,7 +229,7 @@ static int build_schema(sta_handle* h) {
         CHK(reg_linear(h, p + "mlp.fc1", b.fc1, R * E, E, true));
         CHK(reg_linear(h, p + "mlp.fc2", b.fc2, E, R * E, true));
     }
-    slot_drop(h, "enc_norm.weight", {E}); slot_drop(h, "enc_norm.bias", {E});   // never applied (sta_model.py:259,267)
+    CHK(reg_ln(h, "enc_norm", h->enc_norm, E));   // only applied by _encode_image(normalize=True) (sta_model.py:172-173); the forward / SLAM paths pass False
     CHK(reg_linear(h, "decoder_embed", h->dec_embed, D, E));
     h->dec.resize(c.dec_depth);
     for (int i = 0; i < c.dec_depth; ++i) {
@@ -307,7 +319,7 @@ extern "C" int sta_create(const sta_config* cfg, int device, sta_handle** out) {
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     REQUIRE(device >= 0 && device < ndev, "device %d out of range (%d visible)", device, ndev);
-    HIPCHK(hipSetDevice(device));
+    DEV_SCOPE(device);
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, "this library is built for gfx950 only, device reports %s", prop.gcnArchName);
@@ -326,7 +338,7 @@ extern "C" int sta_create(const sta_config* cfg, int device, sta_handle** out) {
 
 extern "C" int sta_destroy(sta_handle* h) {
     if (!h) return 0;
-    hipSetDevice(h->device);
+    DevScope dev_scope_(h->device);
     hipDeviceSynchronize();
     for (void* p : h->allocs) hipFree(p);
     if (h->stage) hipFree(h->stage);
@@ -359,7 +371,7 @@ extern "C" int sta_set_concurrency(sta_handle* h, int n_slices) {
     return 0;
 }
 extern "C" int sta_set_gemm_variant(sta_handle* h, int variant) {
-    REQUIRE(h && variant >= 0 && variant <= 4, "bad gemm variant");
+    REQUIRE(h && variant >= 0 && variant <= 12, "bad gemm variant");
     h->gemm_variant = variant;
     return 0;
 }
@@ -372,7 +384,7 @@ extern "C" int sta_load_tensor(sta_handle* h, const char* name, const void* host
                                const int64_t* shape, int ndim, int dtype) {
     REQUIRE(h && name && host_ptr && shape, "sta_load_tensor: null argument");
     REQUIRE(dtype == STA_DTYPE_F32, "only fp32 source tensors are supported");
-    HIPCHK(hipSetDevice(h->device));
+    DEV_SCOPE(h->device);
     auto it = h->slots.find(name);
     REQUIRE(it != h->slots.end(), "unexpected key in state_dict: %s", name);
     Slot& s = it->second;
@@ -410,25 +422,25 @@ extern "C" int sta_finalize_weights(sta_handle* h) {
     REQUIRE(h, "null handle");
     for (auto& kv : h->slots)
         REQUIRE(kv.second.loaded, "missing key in state_dict: %s", kv.first.c_str());
-    HIPCHK(hipSetDevice(h->device));
+    DEV_SCOPE(h->device);
     HIPCHK(hipDeviceSynchronize());
     h->finalized = true;
     return 0;
 }
 
 // ------------------------------------------------------------------------------------------ launch helpers
-template <bool SPLIT, int AMODE, int EPI, int BM, int BN, int WMS, int WNS, int NSTG = 2, bool MX = false>
+template <bool SPLIT, int AMODE, int EPI, int BM, int BN, int WMS, int WNS, int NSTG = 2, bool MX = false, int PIPE = 0>
 static int launch_gemm2(const GemmParams& p, hipStream_t st) {
     static bool attr_done = false;
     constexpr int smem = gemm2_smem_bytes<SPLIT, BM, BN>(NSTG);
     if (!attr_done) {
-        HIPCHK(hipFuncSetAttribute((const void*)gemm2_kernel<SPLIT, AMODE, EPI, BM, BN, WMS, WNS, 0, NSTG, MX>,
+        HIPCHK(hipFuncSetAttribute((const void*)gemm2_kernel<SPLIT, AMODE, EPI, BM, BN, WMS, WNS, 0, NSTG, MX, PIPE>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_done = true;
     }
     int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
-    hipLaunchKernelGGL((gemm2_kernel<SPLIT, AMODE, EPI, BM, BN, WMS, WNS, 0, NSTG, MX>), dim3((unsigned)(tm * tn * ks)), dim3(WMS * WNS * 64), smem, st, p);
+    hipLaunchKernelGGL((gemm2_kernel<SPLIT, AMODE, EPI, BM, BN, WMS, WNS, 0, NSTG, MX, PIPE>), dim3((unsigned)(tm * tn * ks)), dim3(WMS * WNS * 64), smem, st, p);
     return 0;
 }
 
@@ -445,7 +457,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
     if (AMODE == A_CONV3) REQUIRE(p.Cin % GEMM_BK == 0, "conv Cin=%d must be a multiple of %d", p.Cin, GEMM_BK);
     if (h->dry) return 0;
     const bool split = h->prec != STA_PREC_F16;
-    const bool timed = h->ktime && AMODE == A_DENSE && (EPI == EPI_F32 || EPI == EPI_F32R);
+    const bool timed = h->ktime && (h->ktime_all || (AMODE == A_DENSE && (EPI == EPI_F32 || EPI == EPI_F32R)));
     if (timed) {
         if ((int)h->kev.size() < 2 * (h->kn + 1)) {
             hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
@@ -453,6 +465,8 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
         }
         if ((int)h->kflops.size() <= h->kn) h->kflops.resize(h->kn + 1);
         h->kflops[h->kn] = 2.0 * p.M * p.N * p.K;
+        if ((int)h->kshape.size() < 5 * (h->kn + 1)) h->kshape.resize(5 * (h->kn + 1));
+        { int* q = &h->kshape[5 * h->kn]; q[0] = p.M; q[1] = p.N; q[2] = p.K; q[3] = EPI; q[4] = AMODE; }
         if ((int)h->kbytes.size() <= h->kn) h->kbytes.resize(h->kn + 1);
         // algorithmic bytes: A and W planes (2 B x planes) read once, C written once (+ residual read)
         h->kbytes[h->kn] = (split ? 4.0 : 2.0) * ((double)p.M * p.K + (double)p.N * p.K) + 4.0 * p.M * p.N * (p.resid ? 2.0 : 1.0);
@@ -519,6 +533,12 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
     if (h->gemm_variant == 3 && p.N % 128 == 0) variant = (p.N % 256 == 0 && EPI != EPI_QKV) ? 4 : 5;
     if (h->gemm_variant == 4 && p.N % 128 == 0) variant = 5;
     if (h->gemm_variant == 1) variant = 1;
+    // experiments (bench / tools only): 7 = 192x128 with 6 waves (wave tile 64x64), 8 = 256x256 with 16 waves, 9 = 192x256 with 12 waves
+    if (h->gemm_variant >= 7 && h->gemm_variant <= 9 && split && !p.mx && variant != 6 && p.N % 128 == 0)
+        variant = (h->gemm_variant != 7 && p.N % 256 == 0) ? h->gemm_variant : 7;
+    // 10 / 11 / 12: the software-pipelined main loop (gemm2.h PIPE) on 192x128 (8 waves), 256x256 (8 waves), 192x256 (12 waves)
+    if (h->gemm_variant >= 10 && h->gemm_variant <= 12 && split && !p.mx && variant != 6 && p.N % 128 == 0)
+        variant = (h->gemm_variant != 10 && p.N % 256 == 0 && EPI != EPI_QKV) ? h->gemm_variant : 10;
     if (variant != 6) p.ksplit = 1;
     if (p.mx && variant != 6) variant = 5;     // f16mx kernels exist for the 192x128 and the small-grid families
     if (timed && variant == 5) p.clk_dbg = h->clk_buf;   // effective-clock probe of the dominant kernel (bench only)
@@ -535,6 +555,18 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
         if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4, 2, true>(p, st)));
         else if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4>(p, st)));
         else CHK((launch_gemm2<false, AMODE, EPI, 192, 128, 2, 4>(p, st)));
+    } else if (variant == 10) {
+        CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4, 2, false, 1>(p, st)));
+    } else if (variant == 11) {
+        CHK((launch_gemm2<true, AMODE, EPI, 256, 256, 2, 4, 2, false, 1>(p, st)));
+    } else if (variant == 12) {
+        CHK((launch_gemm2<true, AMODE, EPI, 192, 256, 3, 4, 2, false, 1>(p, st)));
+    } else if (variant == 7) {
+        CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 3, 2>(p, st)));
+    } else if (variant == 8) {
+        CHK((launch_gemm2<true, AMODE, EPI, 256, 256, 4, 4>(p, st)));
+    } else if (variant == 9) {
+        CHK((launch_gemm2<true, AMODE, EPI, 192, 256, 3, 4>(p, st)));
     } else if (variant == 6) {
         if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 2, 2, 3, true>(p, st)));
         else if (split) CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 2, 2, 3>(p, st)));
@@ -954,7 +986,6 @@ static int check_ready(sta_handle* h, int B, int H, int W) {
     REQUIRE(B > 0, "batch must be positive");
     REQUIRE(H % 16 == 0 && W % 16 == 0 && H > 0 && W > 0, "Input image size (%dx%d) is not a multiple of patch size (16)", H, W);
     REQUIRE(W >= H, "img should be in landscape mode, but got W=%d H=%d", W, H);
-    HIPCHK(hipSetDevice(h->device));
     return 0;
 }
 
@@ -973,6 +1004,8 @@ static int plan_and_run(sta_handle* h, F&& body) {
 }
 
 extern "C" int sta_encode(sta_handle* h, const float* img_dev, int B, int H, int W, float* feat_dev, void* stream) {
+    REQUIRE(h, "null handle");
+    DEV_SCOPE(h->device);
     CHK(check_ready(h, B, H, W));
     REQUIRE(img_dev && feat_dev, "null device pointer");
     hipStream_t st = (hipStream_t)stream;
@@ -983,6 +1016,8 @@ extern "C" int sta_encode(sta_handle* h, const float* img_dev, int B, int H, int
 }
 
 extern "C" int sta_encode_u8hwc(sta_handle* h, const uint8_t* img_dev, int B, int H, int W, float* feat_dev, void* stream) {
+    REQUIRE(h, "null handle");
+    DEV_SCOPE(h->device);
     CHK(check_ready(h, B, H, W));
     REQUIRE(img_dev && feat_dev, "null device pointer");
     REQUIRE(((uintptr_t)img_dev & 15) == 0, "u8 HWC image must be 16-byte aligned");
@@ -993,8 +1028,18 @@ extern "C" int sta_encode_u8hwc(sta_handle* h, const uint8_t* img_dev, int B, in
     return plan_and_run(h, [&](Bump& ws) { return encode_impl(h, ws, imgs, true, 1, B, H, W, feat_dev, st); });
 }
 
+extern "C" int sta_encoder_norm(sta_handle* h, const float* feat_dev, int64_t rows, float* out_dev, void* stream) {
+    REQUIRE(h && h->finalized, "handle not ready");
+    REQUIRE(feat_dev && out_dev && rows > 0 && rows < (int64_t)1 << 31, "bad argument");
+    DEV_SCOPE(h->device);
+    Planes none;
+    return run_ln(h, feat_dev, (int)rows, h->cfg.enc_embed_dim, h->enc_norm, none, nullptr, nullptr, out_dev, (hipStream_t)stream);
+}
+
 extern "C" int sta_decode(sta_handle* h, const float* feat1, const float* feat2, int B, int hp, int wp,
                           float* const* out1, float* const* out2, void* stream) {
+    REQUIRE(h, "null handle");
+    DEV_SCOPE(h->device);
     CHK(check_ready(h, B, hp * 16, wp * 16));
     REQUIRE(feat1 && feat2, "null device pointer");
     hipStream_t st = (hipStream_t)stream;
@@ -1010,7 +1055,7 @@ extern "C" int sta_decode(sta_handle* h, const float* feat1, const float* feat2,
 extern "C" int sta_head_pose(sta_handle* h, const float* tok, int B, int64_t tok_stride, float* pose, float* conf, void* stream) {
     REQUIRE(h && h->finalized, "handle not ready");
     REQUIRE(tok && pose && conf && B > 0, "bad argument");
-    HIPCHK(hipSetDevice(h->device));
+    DEV_SCOPE(h->device);
     REQUIRE(tok_stride % 4 == 0, "tok_stride must be a multiple of 4 floats");
     hipStream_t st = (hipStream_t)stream;
     return plan_and_run(h, [&](Bump& ws) { return pose_impl(h, ws, tok, B, tok_stride, pose, conf, st); });
@@ -1020,6 +1065,8 @@ extern "C" int sta_head_pts(sta_handle* h, const float* enc_feat, int64_t enc_bs
                             const float* hook1, int64_t hook1_bstride, const float* hook2, int64_t hook2_bstride,
                             const float* hook3, int64_t hook3_bstride, int B, int H, int W,
                             float* pts, float* conf, void* stream) {
+    REQUIRE(h, "null handle");
+    DEV_SCOPE(h->device);
     CHK(check_ready(h, B, H, W));
     REQUIRE(enc_feat && hook1 && hook2 && hook3 && pts && conf, "null device pointer");
     hipStream_t st = (hipStream_t)stream;
@@ -1032,6 +1079,8 @@ extern "C" int sta_head_pts(sta_handle* h, const float* enc_feat, int64_t enc_bs
 static int forward_pair_any(sta_handle* h, const void* img_a, const void* img_b, bool u8hwc, int B, int H, int W,
                             float* const pts[2], float* const conf[2], float* const pose[2], float* const pose_conf[2],
                             void* stream) {
+    REQUIRE(h, "null handle");
+    DEV_SCOPE(h->device);
     CHK(check_ready(h, B, H, W));
     REQUIRE(img_a && img_b && pts && conf && pose && pose_conf, "null argument");
     hipStream_t st = (hipStream_t)stream;
@@ -1116,16 +1165,16 @@ extern "C" int sta_forward_pair_u8hwc(sta_handle* h, const uint8_t* img_a, const
 
 extern "C" int sta_kernel_timing(sta_handle* h, int enable) {
     REQUIRE(h, "null handle");
-    HIPCHK(hipSetDevice(h->device));
+    DEV_SCOPE(h->device);
     if (enable && !h->clk_buf) { HIPCHK(hipMalloc((void**)&h->clk_buf, 16)); }
     if (h->clk_buf) HIPCHK(hipMemset(h->clk_buf, 0, 16));
-    h->ktime = enable != 0; h->kn = 0;
+    h->ktime = enable != 0; h->ktime_all = enable == 2; h->kn = 0;
     return 0;
 }
 extern "C" int sta_kernel_clock_read(sta_handle* h, float* ghz_out) {
     REQUIRE(h && ghz_out, "null argument");
     REQUIRE(h->clk_buf, "kernel timing was never enabled");
-    HIPCHK(hipSetDevice(h->device));
+    DEV_SCOPE(h->device);
     HIPCHK(hipDeviceSynchronize());
     unsigned long long hc[2] = {0, 0};
     HIPCHK(hipMemcpy(hc, h->clk_buf, 16, hipMemcpyDeviceToHost));
@@ -1134,7 +1183,7 @@ extern "C" int sta_kernel_clock_read(sta_handle* h, float* ghz_out) {
 }
 extern "C" int sta_kernel_timing_read(sta_handle* h, int variant, int* launches, double* total_ms, double* total_flops, double* total_bytes) {
     REQUIRE(h && launches && total_ms && total_flops && total_bytes, "null argument");
-    HIPCHK(hipSetDevice(h->device));
+    DEV_SCOPE(h->device);
     double ms = 0, fl = 0, by = 0;
     int cnt = 0;
     for (int i = 0; i < h->kn; ++i) {
@@ -1150,12 +1199,26 @@ extern "C" int sta_kernel_timing_read(sta_handle* h, int variant, int* launches,
 
 extern "C" int sta_kernel_timing_dump(sta_handle* h, int cap, double* flops, float* ms, int* variant, int* n_out) {
     REQUIRE(h && flops && ms && variant && n_out, "null argument");
-    HIPCHK(hipSetDevice(h->device));
+    DEV_SCOPE(h->device);
     int n = 0;
     for (int i = 0; i < h->kn && n < cap; ++i, ++n) {
         HIPCHK(hipEventSynchronize(h->kev[2 * i + 1]));
         HIPCHK(hipEventElapsedTime(&ms[n], h->kev[2 * i], h->kev[2 * i + 1]));
         flops[n] = h->kflops[i]; variant[n] = h->kvar[i];
+    }
+    *n_out = n;
+    return 0;
+}
+
+extern "C" int sta_kernel_timing_dump_shapes(sta_handle* h, int cap, int* shape5, float* ms, int* variant, int* n_out) {
+    REQUIRE(h && shape5 && ms && variant && n_out, "null argument");
+    DEV_SCOPE(h->device);
+    int n = 0;
+    for (int i = 0; i < h->kn && n < cap; ++i, ++n) {
+        HIPCHK(hipEventSynchronize(h->kev[2 * i + 1]));
+        HIPCHK(hipEventElapsedTime(&ms[n], h->kev[2 * i], h->kev[2 * i + 1]));
+        for (int q = 0; q < 5; ++q) shape5[5 * n + q] = h->kshape[5 * i + q];
+        variant[n] = h->kvar[i];
     }
     *n_out = n;
     return 0;

@@ -34,7 +34,7 @@ def mat_to_se3(frontend: STAFrontend, pose: torch.Tensor) -> torch.Tensor:
     """pp.mat2SE3(pose).data (slam.py:166): [B,4,4] -> [B,7] = (tx,ty,tz,qx,qy,qz,qw)."""
     p = _dev(frontend, pose).reshape(-1, 4, 4)
     out = torch.empty(p.shape[0], 7, device=frontend.device, dtype=torch.float32)
-    _lib.check(frontend.lib.sta_mat_to_se3(frontend._h, p.data_ptr(), p.shape[0], out.data_ptr(), _stream_ptr()))
+    _lib.check(frontend.lib.sta_mat_to_se3(frontend._h, p.data_ptr(), p.shape[0], out.data_ptr(), frontend._stream()))
     return out
 
 
@@ -57,7 +57,7 @@ def world_pointcloud(frontend: STAFrontend, depths, scales, intrinsics, poses, c
                                                  poses.data_ptr(), confs.data_ptr(),
                                                  imgs.data_ptr() if imgs is not None else None, N, H, W, float(conf_thres),
                                                  pts.data_ptr(), col.data_ptr(), rec.data_ptr() if rec is not None else None,
-                                                 C.byref(cnt), _stream_ptr()))
+                                                 C.byref(cnt), frontend._stream()))
     M = cnt.value
     if want_records:
         records = np.frombuffer(rec[:M * 27].cpu().numpy().tobytes(), dtype=PLY_RECORD)

@@ -53,9 +53,9 @@ def gather_compact(local: torch.Tensor, num_pairs: int, out: torch.Tensor | None
 
     Equal shards use one all_gather_into_tensor (the steady-state bench path); ragged shards pad to
     the largest shard and strip the padding afterwards."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local
-    world, rank = dist.get_world_size(), dist.get_rank()
+    world, rank = dist.get_world_size(), dist.get_rank()     # (a world of 1 still runs the collective: the GPU test uses it)
     sizes = [shard_range(num_pairs, world, r) for r in range(world)]
     counts = [hi - lo for lo, hi in sizes]
     mx = max(counts)
@@ -108,11 +108,11 @@ def pack_edges(results, H: int, W: int, device=None) -> torch.Tensor:
 def gather_edges(local: torch.Tensor, num_edges: int, H: int, W: int) -> List[dict]:
     """All ranks -> the results of ALL edges in the original edge order (list of dicts; depths / confs / intri are None
     for rejected edges, exactly like regress_two_views' early return, slam.py:170)."""
-    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-    rank = dist.get_rank() if world > 1 else 0
+    on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size() if on else 1
     width = edge_elems(H, W)
     per = (num_edges + world - 1) // world
-    if world > 1:
+    if on:
         pad = torch.zeros(per, width, device=local.device, dtype=torch.float32)
         pad[:local.shape[0]] = local
         allr = torch.empty(world * per, width, device=local.device, dtype=torch.float32)
@@ -122,7 +122,7 @@ def gather_edges(local: torch.Tensor, num_edges: int, H: int, W: int) -> List[di
     out: List[dict] = [None] * num_edges
     for r in range(world):
         for slot, e in enumerate(edge_shard(num_edges, world, r)):
-            row = allr[r * per + slot] if world > 1 else allr[slot]
+            row = allr[r * per + slot]
             acc = bool(row[0] > 0.5)
             d = {"accepted": acc, "rel_pose_conf": float(row[1]), "pose": row[2:18].reshape(4, 4),
                  "intri": None, "depths": None, "confs": None}

@@ -27,7 +27,7 @@ def pair_reductions(frontend: STAFrontend, pts3d: torch.Tensor, confidence: torc
     cmean = torch.empty(B, device=pts3d.device, dtype=torch.float32)
     _lib.check(frontend.lib.sta_estimate_intrinsics(frontend._h, pts3d.data_ptr(), confidence.data_ptr(), B, H, W,
                                                     int(shared_intrinsic), K.data_ptr(), depth.data_ptr(), cmean.data_ptr(),
-                                                    _stream_ptr()))
+                                                    frontend._stream()))
     return K, depth, cmean
 
 
@@ -37,7 +37,7 @@ def estimate_intrinsic_from_pts3d(frontend: STAFrontend, pts3d: torch.Tensor, co
     B, H, W, _ = pts3d.shape
     K = torch.empty((3, 3) if shared_intrinsic else (B, 3, 3), device=pts3d.device, dtype=torch.float32)
     _lib.check(frontend.lib.sta_estimate_intrinsics(frontend._h, pts3d.data_ptr(), confidence.data_ptr(), B, H, W,
-                                                    int(shared_intrinsic), K.data_ptr(), None, None, _stream_ptr()))
+                                                    int(shared_intrinsic), K.data_ptr(), None, None, frontend._stream()))
     return K
 
 
@@ -45,5 +45,5 @@ def estimate_scale_with_depth_and_confidence(frontend: STAFrontend, Di, Dj, ci, 
     Di, Dj, ci, cj = (_prep(t).reshape(-1) for t in (Di, Dj, ci, cj))
     s = torch.empty((), device=Di.device, dtype=torch.float32)
     _lib.check(frontend.lib.sta_estimate_scale(frontend._h, Di.data_ptr(), Dj.data_ptr(), ci.data_ptr(), cj.data_ptr(),
-                                               Di.numel(), s.data_ptr(), _stream_ptr()))
+                                               Di.numel(), s.data_ptr(), frontend._stream()))
     return s

@@ -29,7 +29,7 @@ def process_image(frontend: STAFrontend, rgb_image, resolution=(224, 224), w_edg
     rgb = torch.empty(3, oh, ow, device=frontend.device, dtype=torch.float32)
     gray = torch.empty(1, oh, ow, device=frontend.device, dtype=torch.float32)
     _lib.check(frontend.lib.sta_preprocess_frame(frontend._h, src.data_ptr(), Hs, Ws, oh, ow, int(w_edge), int(h_edge),
-                                                 u8.data_ptr(), rgb.data_ptr(), gray.data_ptr(), _stream_ptr()))
+                                                 u8.data_ptr(), rgb.data_ptr(), gray.data_ptr(), frontend._stream()))
     out = {"rgb": rgb, "gray": gray, "u8": u8}
     if img_name is not None:
         import os.path as osp

@@ -58,7 +58,7 @@ def regress_views(frontend: STAFrontend, enc_feat_i: torch.Tensor, enc_feats_j: 
     nacc = C.c_int(0)
     _lib.check(frontend.lib.sta_regress_views(frontend._h, fi.data_ptr(), ptrs, k, adj, float(rel_pose_thres), H, W,
                                               pose.data_ptr(), pconf, slot, C.byref(nacc), pts.data_ptr(), conf.data_ptr(),
-                                              Kt.data_ptr(), depth.data_ptr(), _stream_ptr()))
+                                              Kt.data_ptr(), depth.data_ptr(), frontend._stream()))
     out = []
     for e in range(k):
         s = slot[e]

@@ -21,8 +21,10 @@ from . import _lib
 from . import weights as W
 
 
-def _stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream_ptr(device=None) -> int:
+    """Raw HIP stream torch is currently enqueueing on FOR `device` (not for whatever torch's current device happens
+    to be: a frontend on cuda:1 used while torch's current device is cuda:0 must get cuda:1's stream)."""
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 class STAFrontend:
@@ -63,9 +65,19 @@ class STAFrontend:
             self._h = None
 
     def to(self, device):
-        if torch.device(device).type != "cuda":
-            raise _lib.StaError("STAFrontend lives on the GPU it was created on")
+        """nn.Module.to for the only move that makes sense here: the device the handle was created on.  Weights and
+        workspace live inside libsta_mi355.so on that GPU; another index (or the CPU) raises instead of silently staying put."""
+        d = torch.device(device)
+        if d.type != "cuda":
+            raise _lib.StaError("STAFrontend lives on the GPU it was created on; there is no CPU path")
+        idx = d.index if d.index is not None else torch.cuda.current_device()
+        mine = self.device.index if self.device.index is not None else 0
+        if idx != mine:
+            raise _lib.StaError(f"STAFrontend was created on cuda:{mine}; construct it with device='cuda:{idx}' instead of .to()")
         return self
+
+    def _stream(self) -> int:
+        return _stream_ptr(self.device)
 
     def eval(self):
         self.training = False
@@ -144,16 +156,15 @@ class STAFrontend:
 
     # ------------------------------------------------------------------ split entry points
     def _encode_image(self, image: torch.Tensor, true_shape=None, normalize: bool = True):
-        if normalize:
-            raise NotImplementedError("enc_norm is never applied on the SLAM/forward path "
-                                      "(sta_model.py:259,267; slam.py:144); normalize=True is unsupported")
         image = self._f32(image).contiguous()
         B, Cc, H, W_ = image.shape
         assert Cc == 3
         self._check_hw(H, W_, self.patch_size)
         hp, wp = H // 16, W_ // 16
         feat = torch.empty(B, hp * wp, self.cfg.enc_embed_dim, device=self.device, dtype=torch.float32)
-        _lib.check(self.lib.sta_encode(self._h, image.data_ptr(), B, H, W_, feat.data_ptr(), _stream_ptr()))
+        _lib.check(self.lib.sta_encode(self._h, image.data_ptr(), B, H, W_, feat.data_ptr(), self._stream()))
+        if normalize:   # the reference's default argument (sta_model.py:163,172-173); forward / SLAM pass False
+            _lib.check(self.lib.sta_encoder_norm(self._h, feat.data_ptr(), B * hp * wp, feat.data_ptr(), self._stream()))
         return feat, self._positions(B, hp, wp)
 
     def _grid_from_pos(self, pos: torch.Tensor, N: int):
@@ -187,7 +198,7 @@ class STAFrontend:
             out2[i] = torch.empty(B, N + 1, D, device=self.device, dtype=torch.float32)
             p1[i] = out1[i].data_ptr()
             p2[i] = out2[i].data_ptr()
-        _lib.check(self.lib.sta_decode(self._h, feat1.data_ptr(), feat2.data_ptr(), B, hp, wp, p1, p2, _stream_ptr()))
+        _lib.check(self.lib.sta_decode(self._h, feat1.data_ptr(), feat2.data_ptr(), B, hp, wp, p1, p2, self._stream()))
         return out1, out2
 
     def head_pose_s(self, pose_token: torch.Tensor):
@@ -199,7 +210,7 @@ class STAFrontend:
         pose = torch.empty(B, 4, 4, device=self.device, dtype=torch.float32)
         conf = torch.empty(B, device=self.device, dtype=torch.float32)
         _lib.check(self.lib.sta_head_pose(self._h, tok.data_ptr(), B, tok.stride(0) if B > 1 else D,
-                                          pose.data_ptr(), conf.data_ptr(), _stream_ptr()))
+                                          pose.data_ptr(), conf.data_ptr(), self._stream()))
         return {"pose": pose, "conf": conf}
 
     def _rows(self, t: torch.Tensor, N: int, Cdim: int) -> torch.Tensor:
@@ -231,7 +242,7 @@ class STAFrontend:
             return t.stride(0) if B > 1 else t.shape[1] * t.shape[2]
         _lib.check(self.lib.sta_head_pts(self._h, enc.data_ptr(), bs(enc), hk[0].data_ptr(), bs(hk[0]),
                                          hk[1].data_ptr(), bs(hk[1]), hk[2].data_ptr(), bs(hk[2]),
-                                         B, H, W_, pts.data_ptr(), conf.data_ptr(), _stream_ptr()))
+                                         B, H, W_, pts.data_ptr(), conf.data_ptr(), self._stream()))
         return {"pts3d": pts, "conf": conf}
 
     # ------------------------------------------------------------------ monolithic paths
@@ -255,7 +266,7 @@ class STAFrontend:
             for a, key in zip(arrs, ("pts3d_pred", "conf", "relative_pose", "relative_pose_conf")):
                 a[k] = o[key].data_ptr()
         _lib.check(self.lib.sta_forward_pair(self._h, img_a.data_ptr(), img_b.data_ptr(), B, H, W_,
-                                             arrs[0], arrs[1], arrs[2], arrs[3], _stream_ptr()))
+                                             arrs[0], arrs[1], arrs[2], arrs[3], self._stream()))
         return outs[0], outs[1]
 
     def encode_u8hwc(self, image_u8: torch.Tensor):
@@ -268,7 +279,7 @@ class STAFrontend:
         self._check_hw(H, W_, self.patch_size)
         hp, wp = H // 16, W_ // 16
         feat = torch.empty(B, hp * wp, self.cfg.enc_embed_dim, device=self.device, dtype=torch.float32)
-        _lib.check(self.lib.sta_encode_u8hwc(self._h, img.data_ptr(), B, H, W_, feat.data_ptr(), _stream_ptr()))
+        _lib.check(self.lib.sta_encode_u8hwc(self._h, img.data_ptr(), B, H, W_, feat.data_ptr(), self._stream()))
         return feat, self._positions(B, hp, wp)
 
     def forward_pair_u8hwc(self, img_a: torch.Tensor, img_b: torch.Tensor):
@@ -289,17 +300,31 @@ class STAFrontend:
             for arr, key in zip(arrs, ("pts3d_pred", "conf", "relative_pose", "relative_pose_conf")):
                 arr[k] = o[key].data_ptr()
         _lib.check(self.lib.sta_forward_pair_u8hwc(self._h, a.data_ptr(), b.data_ptr(), B, H, W_,
-                                                   arrs[0], arrs[1], arrs[2], arrs[3], _stream_ptr()))
+                                                   arrs[0], arrs[1], arrs[2], arrs[3], self._stream()))
         return outs[0], outs[1]
 
     def forward(self, views: dict, loop_num: int = 0):
+        """sta_model.py:247-291: the main view is encoded ONCE (:257) and decoded against every support view."""
         main_view = views["main_view"]
         support = list(views["neighbor_views"]) + list(views["loop_views"])   # eval: all loop views (sta_model.py:252-255)
         main_res, supp_res = [], []
+        if not support:
+            return {"main_views": main_res, "support_views": supp_res}
+        img_m = self._f32(main_view["img"])
+        B, _c, H, W_ = img_m.shape
+        ts = [[H, W_]] * B
+        feat_m, pos_m = self._encode_image(img_m, None, normalize=False)
+        hooks = self.cfg.hooks                      # decoder list indices hooks[k] - 1 (dpt_head.py:112)
+        layers = sorted({hk - 1 for hk in hooks[1:]})
         for v in support:
-            m, s = self.forward_pair(main_view["img"], v["img"])
-            main_res.append(m)
-            supp_res.append(s)
+            feat_s, pos_s = self._encode_image(v["img"], None, normalize=False)
+            d1, d2 = self._decode_stereo(feat_m, feat_s, pos_m, pos_s, layers=layers)
+            for res, feat, dec in ((main_res, feat_m, d1), (supp_res, feat_s, d2)):
+                toks = [feat] + [None if t is None else t[:, 1:, :] for t in dec]
+                pts = self.head_pts(toks, ts)
+                pose = self.head_pose_s(dec[-1][:, 0, :])
+                res.append({"pts3d_pred": pts["pts3d"], "conf": pts["conf"],
+                            "relative_pose": pose["pose"], "relative_pose_conf": pose["conf"]})
         return {"main_views": main_res, "support_views": supp_res}
 
     __call__ = forward
@@ -326,7 +351,7 @@ class STAFrontend:
 
     def bench_gemm(self, M: int, N: int, K: int, iters: int = 20, tile: int = 0, ablation: int = 0) -> float:
         ms = C.c_float()
-        _lib.check(self.lib.sta_bench_gemm(self._h, M, N, K, iters, tile, ablation, C.byref(ms), _stream_ptr()))
+        _lib.check(self.lib.sta_bench_gemm(self._h, M, N, K, iters, tile, ablation, C.byref(ms), self._stream()))
         return float(ms.value)
 
     def workspace_bytes(self) -> int:
@@ -349,5 +374,5 @@ def rope2d_inplace(tokens: torch.Tensor, positions: torch.Tensor, base: float, f
     assert positions.is_contiguous(), "positions are not contiguous"
     assert D % 4 == 0, "token dim must be multiple of 4"
     _lib.check(lib.sta_rope2d_inplace(tokens.data_ptr(), tokens.stride(0), tokens.stride(1), positions.data_ptr(),
-                                      B, N, Hh, D, float(base), float(fwd), _stream_ptr()))
+                                      B, N, Hh, D, float(base), float(fwd), _stream_ptr(tokens.device)))
     return tokens
