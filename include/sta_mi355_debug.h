@@ -18,6 +18,11 @@ extern "C" {
  * small shapes. */
 int sta_set_gemm_variant(sta_handle* h, int variant);
 
+/* Precision-policy experiments: choose which layer classes run in the f16mx arithmetic (f16 main product + one block-scaled
+ * fp8 correction MFMA).  Bits: 1 = qkv / projq / projk|projv, 2 = attn.proj / cross_attn.proj, 4 = mlp.fc1, 8 = mlp.fc2,
+ * 16 = DPT head convolutions.  sta_set_precision resets it (f16x3: 0, f16x3h: 16, f16mx: 31). */
+int sta_set_mx_mask(sta_handle* h, int mask);
+
 /* nn.Linear (+GELU/ReLU, +residual): out[M,N] = act(A[M,K] W[N,K]^T + bias) (+resid).
  * act: 0 none, 1 erf-GELU, 2 ReLU.  via_f16 != 0 uses the fp16-plane epilogue (sta_blocks.py:73-79). */
 int sta_debug_gemm(sta_handle* h, const float* A, const float* W, const float* bias, int M, int N, int K,
@@ -62,8 +67,14 @@ int sta_debug_svd_orthogonalize(sta_handle* h, const float* m, float* r, int B, 
 int sta_kernel_timing_dump(sta_handle* h, int cap, double* flops, float* ms, int* variant, int* n_out);
 
 /* The same record for EVERY GEMM / convolution launch after sta_kernel_timing(h, 2) (experiments: per-shape in-model
- * durations of a forced tile family, tools/gemm_tiles.py shapes): shape5 = {M, N, K, epilogue id, A-loader id}. */
-int sta_kernel_timing_dump_shapes(sta_handle* h, int cap, int* shape5, float* ms, int* variant, int* n_out);
+ * durations per tile family, tools/gemm_tiles.py shapes; the roofline block of bench.py): shape6 = {M, N, K, epilogue id,
+ * A-loader id (0 dense, 1 conv3x3), 1 if the launch ran in the f16mx arithmetic}; variant = tile family (1 = 128x128
+ * register-staged, 2 = 256x256 / 16 waves, 3 = 192x256 / 12 waves, 5 = 192x128 / 8 waves, 6 = 128x64 small-grid ring). */
+int sta_kernel_timing_dump_shapes(sta_handle* h, int cap, int* shape6, float* ms, int* variant, int* n_out);
+
+/* Restrict the per-launch timing to ONE kernel symbol {epilogue id, A-loader id, tile family, f16mx flag}; then
+ * sta_kernel_timing(h, 3) times only its launches (bench.py: the dominant kernel inside the timed region). */
+int sta_kernel_timing_filter(sta_handle* h, int epilogue, int a_mode, int family, int mx);
 
 #ifdef __cplusplus
 }

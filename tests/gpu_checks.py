@@ -24,13 +24,13 @@ def st():
     return torch.cuda.current_stream().cuda_stream
 
 
-def model(cfg_name="tiny", qk_gain=1.0, precision="f16x3"):
-    """Cached frontends (weights are procedural, so (cfg, gain) identifies them)."""
-    key = (cfg_name, qk_gain)
+def model(cfg_name="tiny", qk_gain=1.0, precision="f16x3", seed=43):
+    """Cached frontends (weights are procedural, so (cfg, gain, seed) identifies them)."""
+    key = (cfg_name, qk_gain, seed)
     if key not in _models:
         cfg = W.TINY if cfg_name == "tiny" else W.FULL
         m = STAFrontend(cfg, DEV, precision=precision)
-        m.load_procedural(seed=43, qk_gain=qk_gain)
+        m.load_procedural(seed=seed, qk_gain=qk_gain)
         _models[key] = m
     m = _models[key]
     m.set_precision(precision)
@@ -244,7 +244,7 @@ def run_golden_case(name, precision, taps=True, variant=0):
     """HIP forward on the procedural inputs of a golden case; returns {key: rel-L2 error}."""
     g, meta = load_golden(name)
     cfg_name = "tiny" if int(meta["cfg_enc_embed_dim"]) == W.TINY.enc_embed_dim else "full"
-    m = model(cfg_name, float(meta["qk_gain"]), precision)
+    m = model(cfg_name, float(meta["qk_gain"]), precision, int(meta["seed"]))
     set_variant(m, variant)
     cfg = m.cfg
     H, W_, B, sub = int(meta["H"]), int(meta["W"]), int(meta["B"]), int(meta["sub"])

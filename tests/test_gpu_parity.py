@@ -19,18 +19,34 @@ def G():
     gpu_checks.drop_models()
 
 
+DEFAULT = "f16x3h"      # the shipped precision policy: f16x3 transformer + pose head, f16mx arithmetic in the DPT head
+STRESS = [f"tiny_48x80_sharp_s{sd}{sm}" for sd in (44, 45, 46, 47) for sm in ("_smooth", "")]
+
+
+@pytest.mark.parametrize("prec", [DEFAULT, "f16x3"])
 @pytest.mark.parametrize("case", ["tiny_32x32_b1", "tiny_48x64_b2", "tiny_48x64_b2_sharp", "tiny_48x80_smooth_sharp"])
-def test_tiny_goldens_default_precision(G, case):
-    r = G.run_golden_case(case, "f16x3")
+def test_tiny_goldens_default_precision(G, case, prec):
+    r = G.run_golden_case(case, prec)
+    bad = {k: v for k, v in r.items() if v > TOL}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("case", STRESS)
+def test_stress_goldens_default_precision(G, case):
+    """Eight more draws (weight / image seeds 44-47, smooth and noisy frames) of the sharpened tiny configuration: these
+    sets amplify every rounding error ~100x (the fp32 oracle itself is at 1e-4 on them), so one of them is a noisy judge of
+    a precision policy.  The default policy must hold all of them at the 1e-3 bar (measured: <= 3.7e-4, same as pure f16x3)."""
+    r = G.run_golden_case(case, DEFAULT)
     bad = {k: v for k, v in r.items() if v > TOL}
     assert not bad, bad
 
 
 @pytest.mark.parametrize("case", ["tiny_48x64_b2", "tiny_48x80_smooth_sharp"])
 def test_tiny_goldens_large_tile_kernel(G, case):
-    """Same goldens with the 256-row direct-to-LDS GEMM family forced (the bench-scale kernels)."""
+    """Same goldens with the large-tile GEMM families forced (2 = 256x256 / 16 waves, 3 = 192x256 / 12 waves: the
+    bench-scale kernels of mlp.fc1 / mlp.fc2 and the refinement convolutions, f16x3 and f16mx forms)."""
     for variant in (2, 3):
-        r = G.run_golden_case(case, "f16x3", variant=variant)
+        r = G.run_golden_case(case, DEFAULT, variant=variant)
         bad = {k: v for k, v in r.items() if v > TOL}
         assert not bad, (variant, bad)
 
@@ -45,7 +61,7 @@ def test_tiny_goldens_f16(G, case):
 @pytest.mark.parametrize("case", ["full_224_b1", "full_384x512_b1"])
 def test_full_goldens_default_precision(G, case):
     """Full-size model (438 M parameters) at the SLAM resolution and at the benchmark resolution."""
-    r = G.run_golden_case(case, "f16x3")
+    r = G.run_golden_case(case, DEFAULT)
     bad = {k: v for k, v in r.items() if v > TOL}
     assert not bad, bad
 
@@ -53,7 +69,7 @@ def test_full_goldens_default_precision(G, case):
 def test_full_sharp_attention_golden(G):
     """Peaky-attention weight set: a wrong RoPE/softmax cannot hide under the tolerance."""
     G.drop_models()
-    r = G.run_golden_case("full_224_b1_sharp", "f16x3")
+    r = G.run_golden_case("full_224_b1_sharp", DEFAULT)
     bad = {k: v for k, v in r.items() if v > TOL}
     assert not bad, bad
 
@@ -63,9 +79,12 @@ def test_full_sharp_attention_golden(G):
                                       # the two sharpened tiny-config stress sets amplify every rounding error ~100x (f16x3: 2e-4 there):
                                       # beyond what this opt-in mode promises, bounded here so a regression still shows
                                       ("tiny_48x64_b2_sharp", 5e-3), ("tiny_48x80_smooth_sharp", 2e-2)])
-def test_goldens_f16mx_opt_in_precision(G, case, tol):
-    """Opt-in precision f16mx (transformer linears: f16 main product + one block-scaled fp8 correction MFMA): the
-    reference-architecture goldens hold 1e-4 (bar 1e-3), i.e. ~10x the f16x3 error and ~30x below one-product f16."""
+def test_goldens_f16mx_experimental_precision(G, case, tol):
+    """Experimental precision f16mx (EVERY linear / convolution: f16 main product + one block-scaled fp8 correction MFMA).
+    NOT parity-qualified: it holds the reference-architecture goldens at <= 1e-4 but EXCEEDS the 1e-3 bar on the sharpened
+    tiny-config stress sets (1.2e-3 / 6e-3 on the two below, up to 2e-3 on the other eight).  The loosened bounds only keep a
+    regression of the mode visible; the shipped policy (f16x3h) uses this arithmetic in the DPT head alone and is held to
+    1e-3 on every golden by the tests above."""
     if case.startswith("full"):
         G.drop_models()
     r = G.run_golden_case(case, "f16mx")
@@ -88,7 +107,7 @@ def test_random_shapes_and_batches_vs_oracle(G):
         H, Wd = 16 * hp, 16 * wp
         imgs = (W.smooth_images if it % 2 else W.synth_images)(2 * B, H, Wd, seed=43, tag=30 + it)
         want = O.forward_pair(W.TINY, sd, imgs[:B], imgs[B:])
-        for prec, tol in (("f16x3", 2e-5), ("f16mx", 2e-4)):
+        for prec, tol in (("f16x3", 2e-5), (DEFAULT, 5e-5), ("f16mx", 2e-4)):
             m = G.model("tiny", 1.0, prec)
             G.set_variant(m, 0)
             main, supp = m.forward_pair(torch.from_numpy(imgs[:B]).cuda(), torch.from_numpy(imgs[B:]).cuda())

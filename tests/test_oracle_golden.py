@@ -55,7 +55,8 @@ def test_postprocess(ops):
     assert np.all(pts[0, 0, 0] == 0)            # zero-norm pixel: clip(1e-8) path
 
 
-@pytest.mark.parametrize("case", ["tiny_32x32_b1", "tiny_48x64_b2", "tiny_48x64_b2_sharp", "tiny_48x80_smooth_sharp"])
+@pytest.mark.parametrize("case", ["tiny_32x32_b1", "tiny_48x64_b2", "tiny_48x64_b2_sharp", "tiny_48x80_smooth_sharp",
+                                  "tiny_48x80_sharp_s44_smooth", "tiny_48x80_sharp_s45", "tiny_48x80_sharp_s46_smooth", "tiny_48x80_sharp_s47"])
 def test_forward_vs_reference_golden(case):
     g, meta = load_golden(case)
     H, W_, B = int(meta["H"]), int(meta["W"]), int(meta["B"])

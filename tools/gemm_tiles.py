@@ -84,11 +84,11 @@ def shapes(variants, steps=3):
             m.forward_pair(imgs[:B], imgs[B:])
         torch.cuda.synchronize()
         cap = 8192
-        sh = (C.c_int * (5 * cap))(); ms = (C.c_float * cap)(); var = (C.c_int * cap)(); n = C.c_int()
+        sh = (C.c_int * (6 * cap))(); ms = (C.c_float * cap)(); var = (C.c_int * cap)(); n = C.c_int()
         _lib.check(m.lib.sta_kernel_timing_dump_shapes(m._h, cap, sh, ms, var, C.byref(n)))
         m.kernel_timing(False)
         for i in range(n.value):
-            key = tuple(sh[5 * i + q] for q in range(5))
+            key = tuple(sh[6 * i + q] for q in range(5))
             table.setdefault(key, collections.defaultdict(list))[v].append((ms[i] * 1e3, var[i]))
     epi = {0: "f32", 1: "f16", 2: "qkv", 3: "convT", 4: "gelu", 5: "f32r"}
     print(f"{'M':>8s} {'N':>5s} {'K':>5s} {'epi':>5s} {'A':>4s} {'n/step':>6s} {'GF':>8s} | " + " | ".join(f"v{v}: us (TF) [family]" for v in variants))

@@ -12,7 +12,8 @@ LIB_PATH = os.path.join(PKG, "libsta_mi355.so")
 STA_PREC_F16 = 1
 STA_PREC_F16X3 = 3
 STA_PREC_F16MX = 4
-PRECISIONS = {"f16": STA_PREC_F16, "f16x3": STA_PREC_F16X3, "f16mx": STA_PREC_F16MX}
+STA_PREC_F16X3H = 5
+PRECISIONS = {"f16": STA_PREC_F16, "f16x3": STA_PREC_F16X3, "f16mx": STA_PREC_F16MX, "f16x3h": STA_PREC_F16X3H}
 
 
 class StaConfig(C.Structure):
@@ -69,6 +70,8 @@ SIGNATURES = {
     # ---- debug / kernel-level test entry points
     "sta_set_gemm_variant": (_i, [_vp, _i]),
     "sta_kernel_timing_dump": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(_i), C.POINTER(_i)]),
+    "sta_set_mx_mask": (_i, [_vp, _i]),
+    "sta_kernel_timing_filter": (_i, [_vp, _i, _i, _i, _i]),
     "sta_kernel_timing_dump_shapes": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(C.c_float), C.POINTER(_i), C.POINTER(_i)]),
     "sta_debug_gemm": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _vp]),
     "sta_debug_qkv_rope": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _vp]),

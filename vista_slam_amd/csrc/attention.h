@@ -232,25 +232,32 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
             }
     };
     using std::integral_constant;
-    auto step = [&](auto stage_c, int it, int ntiles_) {
+    // Full tiles run in a loop whose body has ONE version of the tile code per stage; the partly valid last tile (decoder:
+    // 769 = 12 x 64 + 1 keys) is peeled.  (With the tail test inside the loop hipcc merged the two bodies' O accumulators
+    // through 16 v_mov_b64 per tile.)
+    auto step = [&](auto stage_c, auto tail_c, int it, int ntiles_) {
         constexpr int STG = decltype(stage_c)::value;
         const int kv0 = it * ATT_KV;
         if (it + 1 < ntiles_) issue_tile(STG ^ 1, kv0 + ATT_KV);      // stage STG^1 was released by the last barrier
-        if (wave_active) {
-            if (kv0 + ATT_KV > p.nk) tile_body(stage_c, integral_constant<bool, true>{}, kv0);
-            else tile_body(stage_c, integral_constant<bool, false>{}, kv0);
-        }
+        if (wave_active) tile_body(stage_c, tail_c, kv0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
 
-    const int ntiles = (p.nk + ATT_KV - 1) / ATT_KV;
+    const int ntiles = (p.nk + ATT_KV - 1) / ATT_KV, nfull = p.nk / ATT_KV;
+    using F = integral_constant<bool, false>; using T = integral_constant<bool, true>;
     issue_tile(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int it = 0; it < ntiles; it += 2) {
-        step(integral_constant<int, 0>{}, it, ntiles);
-        if (it + 1 < ntiles) step(integral_constant<int, 1>{}, it + 1, ntiles);
+    int it = 0;
+    for (; it + 1 < nfull; it += 2) {
+        step(integral_constant<int, 0>{}, F{}, it, ntiles);
+        step(integral_constant<int, 1>{}, F{}, it + 1, ntiles);
+    }
+    if (it < nfull) { step(integral_constant<int, 0>{}, F{}, it, ntiles); ++it; }
+    if (it < ntiles) {                                                  // the tail tile, in whichever stage it landed
+        if (it & 1) step(integral_constant<int, 1>{}, T{}, it, ntiles);
+        else step(integral_constant<int, 0>{}, T{}, it, ntiles);
     }
 
     // ---- normalise and store: lane owns query q, d = dt*32 + (r&3) + 8*(r>>2) + 4*lhi

@@ -750,7 +750,7 @@ __global__ void mat_to_se3_kernel(const float* pose, int B, float* out) {
 // epilogue_tile<EPI_F16> and writes the blocked output planes.  One thread = 4 consecutive columns of one row.
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* skbuf, const float* bias, int M, int N, int act,
-                                                            const f16* R1, const f16* R2, f16* C, int64_t c_rp) {
+                                                            const f16* R1, const f16* R2, f16* C, int64_t c_rp, int r_mx, int c_mx) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int n4 = N >> 2;
     if (i >= (int64_t)M * n4) return;
@@ -764,10 +764,17 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* skbuf, 
         float x = v[e] + (bias ? bias[col + e] : 0.f);
         if (act == 1) x = gelu_erf(x);
         else if (act == 2) x = fmaxf(x, 0.f);
-        if (R1) { x += (float)R1[o + e]; if (SPLIT) x += (float)R1[o + 32 + e]; }
-        if (R2) { x += (float)R2[o + e]; if (SPLIT) x += (float)R2[o + 32 + e]; }
+        if (SPLIT && r_mx) {          // residual planes in the f16mx row format
+            if (R1) x += load_mx_act(R1, o + e);
+            if (R2) x += load_mx_act(R2, o + e);
+        } else {
+            if (R1) { x += (float)R1[o + e]; if (SPLIT) x += (float)R1[o + 32 + e]; }
+            if (R2) { x += (float)R2[o + e]; if (SPLIT) x += (float)R2[o + 32 + e]; }
+        }
+        v[e] = x;
         if (SPLIT) split_f16(x, oh.e[e], ol.e[e]); else oh.e[e] = to_f16_sat(x);
     }
+    if (SPLIT && c_mx) { store_mx4(C, o, split_mx4<false>(v)); return; }
     *reinterpret_cast<uint2*>(C + o) = oh.u;
     if (SPLIT) *reinterpret_cast<uint2*>(C + o + 32) = ol.u;
 }

@@ -20,7 +20,6 @@
 //    resident on one XCD share A / W panels in that XCD's L2.
 #pragma once
 #include "gemm.h"
-#include <type_traits>
 
 typedef short short8 __attribute__((ext_vector_type(8)));
 
@@ -38,81 +37,14 @@ __device__ __forceinline__ int lds2_off(int row, int chunk) {
     return SPLIT ? row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4) : row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
 }
 
-// ---- helpers of the software-pipelined loop (PIPE).  Fragment reads are inline asm: hipcc would wait lgkmcnt(0) for the
-// just-issued register set before the MFMAs of the older one (its waitcnt pass does not count across the loop's back
-// edge); completion is counted by hand instead - LDS operations return in order, so "lgkmcnt(NF)" with NF younger reads
-// in flight means the older set has landed.  The wait statement names the registers it releases ("+v"), which is what
-// keeps the MFMAs behind it (cdna_hip_programming.md 5.7, form ii).
-template <int OFF>
-__device__ __forceinline__ void dsr128(half8& dst, unsigned addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
-}
-template <int MT, int NT>
-__device__ __forceinline__ void pipe_read_frags(half8 (&fa)[MT][2], half8 (&fb)[NT][2], const unsigned (&adA)[2], const unsigned (&adB)[2], unsigned so) {
-    const unsigned a0 = adA[0] + so, a1 = adA[1] + so, b0 = adB[0] + so, b1 = adB[1] + so;
-    if constexpr (NT >= 1) { dsr128<0>(fb[0][0], b0); dsr128<0>(fb[0][1], b1); }
-    if constexpr (NT >= 2) { dsr128<4096>(fb[1][0], b0); dsr128<4096>(fb[1][1], b1); }
-    if constexpr (NT >= 3) { dsr128<8192>(fb[2][0], b0); dsr128<8192>(fb[2][1], b1); }
-    if constexpr (NT >= 4) { dsr128<12288>(fb[3][0], b0); dsr128<12288>(fb[3][1], b1); }
-    if constexpr (MT >= 1) { dsr128<0>(fa[0][0], a0); dsr128<0>(fa[0][1], a1); }
-    if constexpr (MT >= 2) { dsr128<4096>(fa[1][0], a0); dsr128<4096>(fa[1][1], a1); }
-    if constexpr (MT >= 3) { dsr128<8192>(fa[2][0], a0); dsr128<8192>(fa[2][1], a1); }
-    if constexpr (MT >= 4) { dsr128<12288>(fa[3][0], a0); dsr128<12288>(fa[3][1], a1); }
-    static_assert(MT <= 4 && NT <= 4, "wave tile");
-}
-// release a register set: at most PENDING younger LDS reads may still be in flight
-template <int MT, int NT, int PENDING>
-__device__ __forceinline__ void pipe_wait_set(half8 (&fa)[MT][2], half8 (&fb)[NT][2]) {
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PENDING));
-#pragma unroll
-    for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(fb[j][0]), "+v"(fb[j][1]));
-#pragma unroll
-    for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(fa[i][0]), "+v"(fa[i][1]));
-}
-template <int MT, int NT>
-__device__ __forceinline__ void pipe_mfma_set(floatx16 (&acc)[MT][NT], half8 (&fa)[MT][2], half8 (&fb)[NT][2], bool relu) {
-    if (relu) {       // RCU input ReLU on the fragments: relu(hi + lo), the sign of hi decides (packed-half integer form)
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            union { half8 h; unsigned u[4]; } ah, al;
-            ah.h = fa[i][0]; al.h = fa[i][1];
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const unsigned sgn = (ah.u[w] >> 15) & 0x00010001u;
-                const unsigned m = (sgn << 16) - sgn;
-                ah.u[w] &= ~m; al.u[w] &= ~m;
-            }
-            fa[i][0] = ah.h; fa[i][1] = al.h;
-        }
-    }
-    // product-major: consecutive MFMAs hit different accumulators
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
-}
-
 // ABL (bench-only ablation bit mask, 0 in the product): 1 = no DMA inside the K loop, 2 = no LDS fragment
 // reads (MFMA on stale registers), 4 = no MFMA (fragments kept alive); barriers always stay.
 // NSTG: LDS stages.  2 = issue tile k+1, compute k, drain, barrier.  >2 = ring: the DMA runs NSTG-1 K tiles
 // ahead and stays in flight across the barrier (counted vmcnt + raw s_barrier in one asm statement) -
 // no gain on the big throughput shapes (DMA-throughput bound) but it is what makes the small-M /
 // split-K family (SLAM-scale GEMMs, a handful of K tiles per block) latency-tolerant.
-// PIPE = 1: software-pipelined f16x3 main loop (2 LDS stages).  The fragments of K step s+1 are read from LDS into a
-// second register set while the MFMAs of step s run, so a wave meets ONE wait per K tile (the stage hand-over: DMA landed
-// + barrier) instead of one lgkmcnt(0) per fragment group; the DMA of tile k+2 is issued right after the hand-over,
-// interleaved with the MFMAs of the second K step.  (The un-pipelined loop, as hipcc schedules it, issues each group of
-// ds_reads just before the 2-3 MFMAs that use them: ~5 exposed LDS round trips per K tile and wave.)
-template <bool SPLIT, int AMODE, int EPI, int BM, int BN, int WAVES_M, int WAVES_N, int ABL = 0, int NSTG = 2, bool MX = false, int PIPE = 0>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (PIPE && BM * BN <= 192 * 128) ? 512 / (WAVES_M * WAVES_N * 16) : 1) void gemm2_kernel(const GemmParams p) {
+template <bool SPLIT, int AMODE, int EPI, int BM, int BN, int WAVES_M, int WAVES_N, int ABL = 0, int NSTG = 2, bool MX = false>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MT = WM / 32, NT = WN / 32;
@@ -235,59 +167,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (PIPE && BM * BN <= 192 * 12
     constexpr int GPW = SA + SB;                   // DMA instructions per wave per K tile
     static_assert(!RING || (NSA % NW == 0 && NSB % NW == 0), "ring needs the same DMA count in every wave");
     static_assert(NSTG >= 2 && NSTG <= 5, "2..5 stages");
-    if (PIPE) {
-        static_assert(!PIPE || (SPLIT && !MX && ABL == 0 && NSTG == 2), "PIPE: f16x3, two stages");
-        constexpr int NF = 2 * (MT + NT);                // ds_read_b128 per register set
-        half8 fa[2][MT][2], fb[2][NT][2];               // [register set][tile][hi, lo]
-        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-        // byte address of (row, chunk = 2*ks + lhi + 4*lo): the XOR swizzle only touches address bits 4..6, so the four
-        // (ks, lo) variants of a lane are base ^ {0, 32, 64, 96}; +32 rows = +4096 B (same swizzle), stage / tile = immediates
-        unsigned adA[2][2], adB[2][2];                  // [ks][lo], stage 0
-        {
-            const int ra = wm * WM + l31, rb = wn * WN + l31;
-            const unsigned ba = lds0 + ra * 128 + ((lhi ^ ((ra >> 1) & 7)) << 4);
-            const unsigned bb = lds0 + A_TILE + rb * 128 + ((lhi ^ ((rb >> 1) & 7)) << 4);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int lo = 0; lo < 2; ++lo) { adA[ks][lo] = ba ^ (ks << 5) ^ (lo << 6); adB[ks][lo] = bb ^ (ks << 5) ^ (lo << 6); }
-        }
-        const bool relu_frag = AMODE == A_CONV3 && p.relu_in;
-        // one K tile held in the stage at byte offset `so` (run-time: ONE loop body, so the two register sets keep their
-        // registers across the back edge); HO: the hand-over to tile kt+1 happens here; DMA: tile kt+2 exists and is issued.
-        // HO / DMA are compile-time (the last two tiles are peeled): a run-time branch around the wait statements makes
-        // hipcc merge the register sets through copies (16 v_mov per K tile and 32 more live registers).
-#define STA_KTILE(kt, HO, DMA)                                                                                               \
-        {                                                                                                                     \
-            pipe_read_frags<MT, NT>(fa[1], fb[1], adA[1], adB[1], so);                    /* K step 1 -> set 1 */              \
-            pipe_wait_set<MT, NT, NF>(fa[0], fb[0]);                                      /* set 0 (K step 0) has landed */     \
-            __builtin_amdgcn_sched_barrier(0);                                                                                \
-            pipe_mfma_set<MT, NT>(acc, fa[0], fb[0], relu_frag);                                                              \
-            __builtin_amdgcn_sched_barrier(0);                                                                                \
-            if (HO) {                                                                                                         \
-                /* hand-over: my pieces of tile kt+1 have landed and my reads of this stage are done; after the barrier that  \
-                   holds for every wave: the other stage may be read, this one may be overwritten by the DMA of tile kt+2 */  \
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                     \
-                pipe_read_frags<MT, NT>(fa[0], fb[0], adA[0], adB[0], STAGE - so);        /* next tile, K step 0 -> set 0 */   \
-                if (DMA) issue_tile(kt0 + (kt) + 2, (kt) & 1);                                                                \
-            }                                                                                                                 \
-            pipe_wait_set<MT, NT, (HO) ? NF : 0>(fa[1], fb[1]);                           /* set 1 (landed before the barrier when HO) */ \
-            __builtin_amdgcn_sched_barrier(0);                                                                                \
-            pipe_mfma_set<MT, NT>(acc, fa[1], fb[1], relu_frag);                                                              \
-            __builtin_amdgcn_sched_barrier(0);                                                                                \
-            so = STAGE - so;                                                                                                  \
-        }
-        issue_tile(kt0, 0);
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        if (nkt > 1) issue_tile(kt0 + 1, 1);
-        unsigned so = 0;
-        pipe_read_frags<MT, NT>(fa[0], fb[0], adA[0], adB[0], so);
-        int kt = 0;
-        for (; kt + 2 < nkt; ++kt) STA_KTILE(kt, true, true)
-        if (kt + 1 < nkt) { STA_KTILE(kt, true, false) ++kt; }
-        STA_KTILE(kt, false, false)
-#undef STA_KTILE
-    } else if (RING) {
+    if (RING) {
 #pragma unroll
         for (int s0 = 0; s0 < NSTG - 1; ++s0)
             if (s0 < nkt) issue_tile(kt0 + s0, s0);
@@ -302,7 +182,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (PIPE && BM * BN <= 192 * 12
     // K steps - so that one of them always has MFMAs to feed the matrix pipe while the other sits in the
     // (slow, back-pressured) LDS-DMA issue.
     const bool late_dma = (ABL & 8) && !RING && wave >= NW / 2;
-    for (int kt = 0; kt < nkt && !PIPE; ++kt) {
+    for (int kt = 0; kt < nkt; ++kt) {
         const int cur = RING ? kt % NSTG : (kt & 1);
         if (RING) {
             // tile kt has landed once at most `rem` younger tiles of this wave are outstanding

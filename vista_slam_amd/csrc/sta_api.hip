@@ -46,7 +46,10 @@ static inline Planes slice_rows(const Planes& p, int64_t r0) {
     q.hi = p.hi + r0 * es; if (p.lo) q.lo = q.hi + 32;
     return q;
 }
-struct Lin { Planes w; Planes wmx; float* bias = nullptr; int N = 0, K = 0; };   // wmx: second packed copy in the f16mx row format (transformer linears)
+// layer classes of the precision policy (mx_mask): which linears run "f16 main product + block-scaled fp8 corrections"
+enum { CLS_NONE = 0, CLS_QKV = 1 /* qkv, projq, projk|projv */, CLS_PROJ = 2 /* attn.proj, cross_attn.proj */,
+       CLS_FC1 = 4, CLS_FC2 = 8, CLS_HEAD = 16 /* DPT head convolutions */, CLS_ALL = 31 };
+struct Lin { Planes w; Planes wmx; float* bias = nullptr; int N = 0, K = 0; int cls = CLS_NONE; };   // wmx: second packed copy in the f16mx row format
 struct LNp { float* g = nullptr; float* b = nullptr; };
 struct EncBlk { LNp n1, n2; Lin qkv, proj, fc1, fc2; };
 struct DecBlk { LNp n1, n2, n3, ny; Lin qkv, proj, cq, ckv, cproj, fc1, fc2; };
@@ -73,6 +76,7 @@ struct sta_handle {
     sta_config cfg;
     int device = 0;
     int prec = STA_PREC_F16X3;
+    int mx_mask = 0;          // CLS_* bits of the layer classes that run in the f16mx arithmetic (set by the precision mode)
     bool finalized = false;
     std::unordered_map<std::string, Slot> slots;
     int n_loaded = 0;
@@ -98,7 +102,8 @@ struct sta_handle {
     // per-launch timing of the dominant kernel (gemm_kernel<*, A_DENSE, EPI_F32>) for the roofline report
     unsigned long long* clk_buf = nullptr;   // {shader cycles, 100 MHz ticks} summed over sampled workgroups of the timed GEMMs
     bool ktime = false; std::vector<hipEvent_t> kev; int kn = 0; std::vector<double> kflops, kbytes; std::vector<int> kvar;
-    bool ktime_all = false; std::vector<int> kshape;   // sta_kernel_timing(h, 2): every GEMM / conv launch is timed; {M, N, K, EPI, AMODE} per record
+    int kfilter[4] = {-1, -1, -1, -1};    // mode 3: {epilogue, A-loader, tile family, mx} of the one kernel symbol that is timed
+    bool ktime_all = false; std::vector<int> kshape;   // sta_kernel_timing(h, 2): every GEMM / conv launch is timed; {M, N, K, EPI, AMODE, mx} per record
     // optional two-slice concurrency (sta_set_concurrency)
     int n_streams = 1; hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     // f3 input-step tables (one cached geometry)
@@ -178,8 +183,9 @@ static void slot_f32(sta_handle* h, const std::string& name, std::vector<int64_t
 static void slot_drop(sta_handle* h, const std::string& name, std::vector<int64_t> shape) {
     Slot s; s.shape = std::move(shape); s.kind = SK_DROP; h->slots[name] = s;
 }
-static int reg_linear(sta_handle* h, const std::string& name, Lin& L, int N, int K, bool mx = false) {
+static int reg_linear(sta_handle* h, const std::string& name, Lin& L, int N, int K, bool mx = false, int cls = CLS_NONE) {
     CHK(make_lin(h, L, N, K, true, mx));
+    L.cls = cls;
     slot_w(h, name + ".weight", {N, K}, SK_W_ID, L);
     slot_f32(h, name + ".bias", {N}, L.bias);
     return 0;
@@ -191,13 +197,13 @@ static int reg_ln(sta_handle* h, const std::string& name, LNp& n, int C) {
 }
 // conv weight [Co,Ci,k,k] -> packed [Co][k][k][Ci]
 static int reg_conv(sta_handle* h, const std::string& name, Lin& L, int Co, int Ci, int k, bool bias) {
-    CHK(make_lin(h, L, Co, Ci * k * k, bias, true));
+    CHK(make_lin(h, L, Co, Ci * k * k, bias, true)); L.cls = CLS_HEAD;
     slot_w(h, name + ".weight", {Co, Ci, k, k}, k == 1 ? SK_W_ID : SK_W_CONV, L);
     if (bias) slot_f32(h, name + ".bias", {Co}, L.bias);
     return 0;
 }
 static int reg_convt(sta_handle* h, const std::string& name, Lin& L, int C, int k) {
-    CHK(make_lin(h, L, k * k * C, C, true, true));
+    CHK(make_lin(h, L, k * k * C, C, true, true)); L.cls = CLS_HEAD;
     slot_w(h, name + ".weight", {C, C, k, k}, SK_W_CONVT, L);
     Slot s; s.shape = {C}; s.kind = SK_B_CONVT; s.dst32 = L.bias; s.reps = k * k;
     h->slots[name + ".bias"] = s;
@@ -223,11 +229,11 @@ static int build_schema(sta_handle* h) {
         EncBlk& b = h->enc[i];
         snprintf(nm, sizeof nm, "enc_blocks.%d.", i); std::string p(nm);
         CHK(reg_ln(h, p + "norm1", b.n1, E));
-        CHK(reg_linear(h, p + "attn.qkv", b.qkv, 3 * E, E, true));
-        CHK(reg_linear(h, p + "attn.proj", b.proj, E, E, true));
+        CHK(reg_linear(h, p + "attn.qkv", b.qkv, 3 * E, E, true, CLS_QKV));
+        CHK(reg_linear(h, p + "attn.proj", b.proj, E, E, true, CLS_PROJ));
         CHK(reg_ln(h, p + "norm2", b.n2, E));
-        CHK(reg_linear(h, p + "mlp.fc1", b.fc1, R * E, E, true));
-        CHK(reg_linear(h, p + "mlp.fc2", b.fc2, E, R * E, true));
+        CHK(reg_linear(h, p + "mlp.fc1", b.fc1, R * E, E, true, CLS_FC1));
+        CHK(reg_linear(h, p + "mlp.fc2", b.fc2, E, R * E, true, CLS_FC2));
     }
     CHK(reg_ln(h, "enc_norm", h->enc_norm, E));   // only applied by _encode_image(normalize=True) (sta_model.py:172-173); the forward / SLAM paths pass False
     CHK(reg_linear(h, "decoder_embed", h->dec_embed, D, E));
@@ -236,20 +242,20 @@ static int build_schema(sta_handle* h) {
         DecBlk& b = h->dec[i];
         snprintf(nm, sizeof nm, "dec_block.%d.", i); std::string p(nm);
         CHK(reg_ln(h, p + "norm1", b.n1, D));
-        CHK(reg_linear(h, p + "attn.qkv", b.qkv, 3 * D, D, true));
-        CHK(reg_linear(h, p + "attn.proj", b.proj, D, D, true));
-        CHK(reg_linear(h, p + "cross_attn.projq", b.cq, D, D, true));
+        CHK(reg_linear(h, p + "attn.qkv", b.qkv, 3 * D, D, true, CLS_QKV));
+        CHK(reg_linear(h, p + "attn.proj", b.proj, D, D, true, CLS_PROJ));
+        CHK(reg_linear(h, p + "cross_attn.projq", b.cq, D, D, true, CLS_QKV));
         // projk + projv packed as one [2D, D] GEMM
-        CHK(make_lin(h, b.ckv, 2 * D, D, true, true));
+        CHK(make_lin(h, b.ckv, 2 * D, D, true, true)); b.ckv.cls = CLS_QKV;
         slot_w(h, p + "cross_attn.projk.weight", {D, D}, SK_W_ID, b.ckv, 0);
         slot_f32(h, p + "cross_attn.projk.bias", {D}, b.ckv.bias);
         slot_w(h, p + "cross_attn.projv.weight", {D, D}, SK_W_ID, b.ckv, D);
         slot_f32(h, p + "cross_attn.projv.bias", {D}, b.ckv.bias + D);
-        CHK(reg_linear(h, p + "cross_attn.proj", b.cproj, D, D, true));
+        CHK(reg_linear(h, p + "cross_attn.proj", b.cproj, D, D, true, CLS_PROJ));
         CHK(reg_ln(h, p + "norm2", b.n2, D));
         CHK(reg_ln(h, p + "norm3", b.n3, D));
-        CHK(reg_linear(h, p + "mlp.fc1", b.fc1, R * D, D, true));
-        CHK(reg_linear(h, p + "mlp.fc2", b.fc2, D, R * D, true));
+        CHK(reg_linear(h, p + "mlp.fc1", b.fc1, R * D, D, true, CLS_FC1));
+        CHK(reg_linear(h, p + "mlp.fc2", b.fc2, D, R * D, true, CLS_FC2));
         CHK(reg_ln(h, p + "norm_y", b.ny, D));
     }
     CHK(reg_ln(h, "dec_norm", h->dec_norm, D));
@@ -298,10 +304,14 @@ static int build_schema(sta_handle* h) {
 }
 
 // ------------------------------------------------------------------------------------------ API: lifecycle
+static int mask_of_precision(int prec) {
+    return prec == STA_PREC_F16MX ? CLS_ALL : (prec == STA_PREC_F16X3H ? CLS_HEAD : 0);
+}
+
 extern "C" void sta_default_config(sta_config* c) {
     c->patch_size = 16; c->enc_embed_dim = 1024; c->enc_depth = 24; c->enc_num_heads = 16;
     c->dec_embed_dim = 768; c->dec_depth = 12; c->dec_num_heads = 12; c->mlp_ratio = 4;
-    c->rope_base = 100.0f; c->ln_eps = 1e-6f; c->precision = STA_PREC_F16X3;
+    c->rope_base = 100.0f; c->ln_eps = 1e-6f; c->precision = STA_PREC_F16X3H;
 }
 
 extern "C" const char* sta_last_error(void) { return g_err; }
@@ -315,7 +325,7 @@ extern "C" int sta_create(const sta_config* cfg, int device, sta_handle** out) {
     REQUIRE(cfg->enc_embed_dim % 128 == 0 && cfg->enc_embed_dim <= 1024, "enc_embed_dim must be a multiple of 128, <= 1024");
     REQUIRE(cfg->dec_embed_dim % 128 == 0 && cfg->dec_embed_dim <= 1024, "dec_embed_dim must be a multiple of 128, <= 1024");
     REQUIRE(cfg->dec_depth > 9, "dec_depth must be > 9 (heads/dpt_head.py:102)");
-    REQUIRE(cfg->precision == STA_PREC_F16 || cfg->precision == STA_PREC_F16X3 || cfg->precision == STA_PREC_F16MX, "unknown precision %d", cfg->precision);
+    REQUIRE(cfg->precision == STA_PREC_F16 || cfg->precision == STA_PREC_F16X3 || cfg->precision == STA_PREC_F16MX || cfg->precision == STA_PREC_F16X3H, "unknown precision %d", cfg->precision);
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     REQUIRE(device >= 0 && device < ndev, "device %d out of range (%d visible)", device, ndev);
@@ -324,7 +334,7 @@ extern "C" int sta_create(const sta_config* cfg, int device, sta_handle** out) {
     HIPCHK(hipGetDeviceProperties(&prop, device));
     REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, "this library is built for gfx950 only, device reports %s", prop.gcnArchName);
     sta_handle* h = new sta_handle();
-    h->cfg = *cfg; h->device = device; h->prec = cfg->precision;
+    h->cfg = *cfg; h->device = device; h->prec = cfg->precision; h->mx_mask = mask_of_precision(cfg->precision);
     if (build_schema(h) != 0) { sta_destroy(h); return -1; }
     h->stage_elems = (int64_t)cfg->mlp_ratio * cfg->enc_embed_dim * cfg->enc_embed_dim;
     int64_t big = (int64_t)768 * 768 * 9;
@@ -360,8 +370,14 @@ extern "C" int sta_destroy(sta_handle* h) {
 
 extern "C" int sta_set_precision(sta_handle* h, int precision) {
     REQUIRE(h, "null handle");
-    REQUIRE(precision == STA_PREC_F16 || precision == STA_PREC_F16X3 || precision == STA_PREC_F16MX, "unknown precision %d", precision);
-    h->prec = precision;
+    REQUIRE(precision == STA_PREC_F16 || precision == STA_PREC_F16X3 || precision == STA_PREC_F16MX || precision == STA_PREC_F16X3H, "unknown precision %d", precision);
+    h->prec = precision; h->mx_mask = mask_of_precision(precision);
+    return 0;
+}
+extern "C" int sta_set_mx_mask(sta_handle* h, int mask) {
+    REQUIRE(h && mask >= 0 && mask <= CLS_ALL, "bad mask");
+    REQUIRE(h->prec != STA_PREC_F16, "the f16mx arithmetic needs the split (f16x3) plane format");
+    h->mx_mask = mask;
     return 0;
 }
 extern "C" int sta_set_concurrency(sta_handle* h, int n_slices) {
@@ -371,7 +387,7 @@ extern "C" int sta_set_concurrency(sta_handle* h, int n_slices) {
     return 0;
 }
 extern "C" int sta_set_gemm_variant(sta_handle* h, int variant) {
-    REQUIRE(h && variant >= 0 && variant <= 12, "bad gemm variant");
+    REQUIRE(h && variant >= 0 && variant <= 4, "bad gemm variant");
     h->gemm_variant = variant;
     return 0;
 }
@@ -429,24 +445,20 @@ extern "C" int sta_finalize_weights(sta_handle* h) {
 }
 
 // ------------------------------------------------------------------------------------------ launch helpers
-template <bool SPLIT, int AMODE, int EPI, int BM, int BN, int WMS, int WNS, int NSTG = 2, bool MX = false, int PIPE = 0>
+template <bool SPLIT, int AMODE, int EPI, int BM, int BN, int WMS, int WNS, int NSTG = 2, bool MX = false>
 static int launch_gemm2(const GemmParams& p, hipStream_t st) {
     static bool attr_done = false;
     constexpr int smem = gemm2_smem_bytes<SPLIT, BM, BN>(NSTG);
     if (!attr_done) {
-        HIPCHK(hipFuncSetAttribute((const void*)gemm2_kernel<SPLIT, AMODE, EPI, BM, BN, WMS, WNS, 0, NSTG, MX, PIPE>,
+        HIPCHK(hipFuncSetAttribute((const void*)gemm2_kernel<SPLIT, AMODE, EPI, BM, BN, WMS, WNS, 0, NSTG, MX>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_done = true;
     }
     int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
-    hipLaunchKernelGGL((gemm2_kernel<SPLIT, AMODE, EPI, BM, BN, WMS, WNS, 0, NSTG, MX, PIPE>), dim3((unsigned)(tm * tn * ks)), dim3(WMS * WNS * 64), smem, st, p);
+    hipLaunchKernelGGL((gemm2_kernel<SPLIT, AMODE, EPI, BM, BN, WMS, WNS, 0, NSTG, MX>), dim3((unsigned)(tm * tn * ks)), dim3(WMS * WNS * 64), smem, st, p);
     return 0;
 }
-
-// In-model correction of the 192x128 family (two workgroups per CU: one block's HBM-bound epilogue overlaps
-// the other's main loop, which the L2/MALL-warm micro-benchmark cannot see).  STA_COST5 overrides (experiments).
-static const double g_cost_scale5 = getenv("STA_COST5") ? atof(getenv("STA_COST5")) : 0.6;   // measured in-model: 130 -> 135 pairs/s
 
 template <int AMODE, int EPI>
 static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
@@ -457,47 +469,21 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
     if (AMODE == A_CONV3) REQUIRE(p.Cin % GEMM_BK == 0, "conv Cin=%d must be a multiple of %d", p.Cin, GEMM_BK);
     if (h->dry) return 0;
     const bool split = h->prec != STA_PREC_F16;
-    const bool timed = h->ktime && (h->ktime_all || (AMODE == A_DENSE && (EPI == EPI_F32 || EPI == EPI_F32R)));
-    if (timed) {
-        if ((int)h->kev.size() < 2 * (h->kn + 1)) {
-            hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-            h->kev.push_back(a); h->kev.push_back(b);
-        }
-        if ((int)h->kflops.size() <= h->kn) h->kflops.resize(h->kn + 1);
-        h->kflops[h->kn] = 2.0 * p.M * p.N * p.K;
-        if ((int)h->kshape.size() < 5 * (h->kn + 1)) h->kshape.resize(5 * (h->kn + 1));
-        { int* q = &h->kshape[5 * h->kn]; q[0] = p.M; q[1] = p.N; q[2] = p.K; q[3] = EPI; q[4] = AMODE; }
-        if ((int)h->kbytes.size() <= h->kn) h->kbytes.resize(h->kn + 1);
-        // algorithmic bytes: A and W planes (2 B x planes) read once, C written once (+ residual read)
-        h->kbytes[h->kn] = (split ? 4.0 : 2.0) * ((double)p.M * p.K + (double)p.N * p.K) + 4.0 * p.M * p.N * (p.resid ? 2.0 : 1.0);
-        HIPCHK(hipEventRecord(h->kev[2 * h->kn], st));
-        h->kn++;
-    }
-    // Tile selection by a measured cost model (tools/gemm_bench6/7.py on MI355X, f16x3):
-    //   time ~ rounds x (a*K + b) us, a = main-loop slope, b = fixed per-round cost (prologue + the
-    //   HBM-bound epilogue), rounds = tiles / resident slots.  Families whose LDS footprint admits two
-    //   workgroups per CU (192x128: 80 KiB, 128x128: 64 KiB) have 512 slots and overlap one block's
-    //   epilogue with the other's main loop, so their rounds are counted fractionally.
-    // It picks 192x256 for the encoder's N=1024 GEMMs (64x4 = 256 tiles = exactly one round instead of
-    // 192 tiles on 256 CUs), 256x256 for N=4096, 192x128 for the QKV epilogue and the decoder's odd
-    // grids, and the register-staged 128x128 kernel for small SLAM-scale problems.
-    struct Cand { int variant, bm, bn, slots; double a, b; };
-    static const Cand cands[] = {{2, 256, 256, 256, 0.0664, 26.0}, {4, 192, 256, 256, 0.0616, 17.7},
-                                 {3, 256, 128, 256, 0.0376, 16.0}, {5, 192, 128, 512, 0.0684, 11.4},
-                                 {1, 128, 128, 512, 0.056, 18.0}};
-    int variant = 1;
-    {
-        double best = 1e300;
-        for (const Cand& c : cands) {
-            if (c.variant != 1 && p.N % c.bn != 0) continue;
-            if (EPI == EPI_QKV && (c.variant == 2 || c.variant == 4)) continue;   // the RoPE epilogue spills beyond 96 accumulators/wave
-            const double tiles = (double)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn);
-            double rounds = tiles / c.slots;
-            rounds = c.slots == 256 ? ceil(rounds) : (rounds < 1.0 ? 1.0 : rounds + 0.1);
-            double cost = rounds * (c.a * p.K + c.b);
-            if (c.variant == 5) cost *= g_cost_scale5;
-            if (cost < best) { best = cost; variant = c.variant; }
-        }
+    // Tile family selection.  Measured in the model, per shape, with HIP events around every launch (tools/gemm_tiles.py
+    // shapes; profiles/r02_gemm_shapes.txt): every family saturates at the same 300-400 algorithmic TFLOP/s - the chip is
+    // power-bound on this instruction mix - so the choice is about tile quantisation and epilogue overlap:
+    //   5: 192x128, 8 waves, two workgroups per CU (one block's HBM-bound epilogue hides under the other's main loop):
+    //      best or equal on almost every shape of the path -> the default;
+    //   3: 192x256, 12 waves (wave tile 64x64), one workgroup per CU, 30 % less L2->LDS traffic per FLOP: wins the long-K
+    //      in-place-residual GEMMs (mlp.fc2: -4 %) and the mid-resolution convolutions (-9 %);
+    //   2: 256x256, 16 waves (wave tile 64x64): wins mlp.fc1 of the encoder (768 tiles = exactly 3 rounds of 256 CUs, -4 %)
+    //      and the 4x-resolution refinement convolutions (-9 %);
+    //   1: 128x128 register-staged kernel: shapes whose N is not a multiple of 128;  6: small-grid family, below.
+    int variant = p.N % 128 == 0 ? 5 : 1;
+    if (split && p.N % 256 == 0 && EPI != EPI_QKV) {
+        if (AMODE == A_DENSE && EPI == EPI_F32R && p.K >= 2048) variant = 3;
+        if (AMODE == A_DENSE && EPI == EPI_GELU && p.M % 256 == 0 && ((int64_t)(p.M / 256) * (p.N / 256)) % 256 == 0) variant = 2;
+        if (AMODE == A_CONV3 && p.N == 256 && p.K >= 864) variant = p.M >= 131072 ? 2 : (p.M >= 32768 ? 3 : 5);
     }
     // Small-M (SLAM-scale: 224x224, batch 1 -> M = 196..394 rows): 128x64 tiles, 3-stage DMA ring, and for
     // the in-place residual GEMMs (proj / fc2: out += A W^T + b) split-K with fp32 atomics so that ~256
@@ -517,7 +503,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
         // extra tiny launches only when the K loop is long and the grid leaves most of the chip idle (swept: <= 96 / 160 /
         // 256 tiles -> DPT 1.00 / 0.85 / 0.83 ms per view).  An in-kernel fix-up (last slice finishes the tile behind a
         // device-scope fence + ticket) was 1.7x SLOWER than this: the fence writes back / invalidates the XCD's L2.
-        if (EPI == EPI_F16 && !p.c_mx && !p.r_mx && tiles <= 192 && p.K >= 1024 && p.N % 4 == 0 && (int64_t)p.M * p.N <= SKBUF_ELEMS) {
+        if (EPI == EPI_F16 && tiles <= 192 && p.K >= 1024 && p.N % 4 == 0 && (int64_t)p.M * p.N <= SKBUF_ELEMS) {
             int ks = (256 + tiles - 1) / tiles;
             const int max_ks = p.K / 256;                 // keep >= 8 K tiles per slice
             if (ks > max_ks) ks = max_ks;
@@ -529,44 +515,46 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
             }
         }
     }
-    if (h->gemm_variant == 2 && p.N % 128 == 0) variant = (p.N % 256 == 0 && EPI != EPI_QKV) ? 2 : 3;
-    if (h->gemm_variant == 3 && p.N % 128 == 0) variant = (p.N % 256 == 0 && EPI != EPI_QKV) ? 4 : 5;
-    if (h->gemm_variant == 4 && p.N % 128 == 0) variant = 5;
+    // forced families (tests / tools): 1 = 128x128 register-staged, 2 = 256x256, 3 = 192x256 (both wherever N % 256 == 0 and
+    // the epilogue is not the RoPE one), 4 = 192x128 everywhere
+    if ((h->gemm_variant == 2 || h->gemm_variant == 3) && variant != 6 && p.N % 128 == 0)
+        variant = (p.N % 256 == 0 && EPI != EPI_QKV) ? h->gemm_variant : 5;
+    if (h->gemm_variant == 4 && variant != 6 && p.N % 128 == 0) variant = 5;
     if (h->gemm_variant == 1) variant = 1;
-    // experiments (bench / tools only): 7 = 192x128 with 6 waves (wave tile 64x64), 8 = 256x256 with 16 waves, 9 = 192x256 with 12 waves
-    if (h->gemm_variant >= 7 && h->gemm_variant <= 9 && split && !p.mx && variant != 6 && p.N % 128 == 0)
-        variant = (h->gemm_variant != 7 && p.N % 256 == 0) ? h->gemm_variant : 7;
-    // 10 / 11 / 12: the software-pipelined main loop (gemm2.h PIPE) on 192x128 (8 waves), 256x256 (8 waves), 192x256 (12 waves)
-    if (h->gemm_variant >= 10 && h->gemm_variant <= 12 && split && !p.mx && variant != 6 && p.N % 128 == 0)
-        variant = (h->gemm_variant != 10 && p.N % 256 == 0 && EPI != EPI_QKV) ? h->gemm_variant : 10;
     if (variant != 6) p.ksplit = 1;
-    if (p.mx && variant != 6) variant = 5;     // f16mx kernels exist for the 192x128 and the small-grid families
-    if (timed && variant == 5) p.clk_dbg = h->clk_buf;   // effective-clock probe of the dominant kernel (bench only)
+    if (p.mx && variant == 1) variant = 5;     // no f16mx form of the register-staged kernel (use_mx() already requires N % 64 == 0)
+    // per-launch HIP-event timing (bench / tools): every launch (mode 2), or only the launches of ONE kernel symbol
+    // (mode 3, sta_kernel_timing_filter: the event pairs break back-to-back dispatch, ~3.5 us each, so the timed region of
+    // bench.py carries them on the dominant kernel only)
+    const bool timed = h->ktime && (h->ktime_all || (h->kfilter[0] == EPI && h->kfilter[1] == AMODE && h->kfilter[2] == variant && h->kfilter[3] == p.mx));
+    if (timed) {
+        if ((int)h->kev.size() < 2 * (h->kn + 1)) {
+            hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+            h->kev.push_back(a); h->kev.push_back(b);
+        }
+        if ((int)h->kflops.size() <= h->kn) h->kflops.resize(h->kn + 1);
+        h->kflops[h->kn] = 2.0 * p.M * p.N * p.K;
+        if ((int)h->kshape.size() < 6 * (h->kn + 1)) h->kshape.resize(6 * (h->kn + 1));
+        { int* q = &h->kshape[6 * h->kn]; q[0] = p.M; q[1] = p.N; q[2] = p.K; q[3] = EPI; q[4] = AMODE; q[5] = p.mx; }
+        if ((int)h->kbytes.size() <= h->kn) h->kbytes.resize(h->kn + 1);
+        // algorithmic bytes: A and W planes (2 B x planes) read once, C written once (+ residual read)
+        h->kbytes[h->kn] = (split ? 4.0 : 2.0) * ((double)p.M * p.K + (double)p.N * p.K) + 4.0 * p.M * p.N * (p.resid ? 2.0 : 1.0);
+        HIPCHK(hipEventRecord(h->kev[2 * h->kn], st));
+        h->kn++;
+    }
+    if (timed && variant == 5) p.clk_dbg = h->clk_buf;   // effective-clock probe (bench only)
     if (variant == 2) {
-        if (split) CHK((launch_gemm2<true, AMODE, EPI, 256, 256, 2, 4>(p, st)));
-        else CHK((launch_gemm2<false, AMODE, EPI, 256, 256, 2, 4>(p, st)));
+        if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 256, 256, 4, 4, 2, true>(p, st)));
+        else if (split) CHK((launch_gemm2<true, AMODE, EPI, 256, 256, 4, 4>(p, st)));
+        else CHK((launch_gemm2<false, AMODE, EPI, 256, 256, 4, 4>(p, st)));
     } else if (variant == 3) {
-        if (split) CHK((launch_gemm2<true, AMODE, EPI, 256, 128, 4, 2>(p, st)));
-        else CHK((launch_gemm2<false, AMODE, EPI, 256, 128, 4, 2>(p, st)));
-    } else if (variant == 4) {
-        if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 256, 2, 4>(p, st)));
-        else CHK((launch_gemm2<false, AMODE, EPI, 192, 256, 2, 4>(p, st)));
+        if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 192, 256, 3, 4, 2, true>(p, st)));
+        else if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 256, 3, 4>(p, st)));
+        else CHK((launch_gemm2<false, AMODE, EPI, 192, 256, 3, 4>(p, st)));
     } else if (variant == 5) {
         if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4, 2, true>(p, st)));
         else if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4>(p, st)));
         else CHK((launch_gemm2<false, AMODE, EPI, 192, 128, 2, 4>(p, st)));
-    } else if (variant == 10) {
-        CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4, 2, false, 1>(p, st)));
-    } else if (variant == 11) {
-        CHK((launch_gemm2<true, AMODE, EPI, 256, 256, 2, 4, 2, false, 1>(p, st)));
-    } else if (variant == 12) {
-        CHK((launch_gemm2<true, AMODE, EPI, 192, 256, 3, 4, 2, false, 1>(p, st)));
-    } else if (variant == 7) {
-        CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 3, 2>(p, st)));
-    } else if (variant == 8) {
-        CHK((launch_gemm2<true, AMODE, EPI, 256, 256, 4, 4>(p, st)));
-    } else if (variant == 9) {
-        CHK((launch_gemm2<true, AMODE, EPI, 192, 256, 3, 4>(p, st)));
     } else if (variant == 6) {
         if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 2, 2, 3, true>(p, st)));
         else if (split) CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 2, 2, 3>(p, st)));
@@ -574,8 +562,8 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
         if (EPI == EPI_F16 && p.ksplit > 1) {
             const int64_t n4 = (int64_t)p.M * (p.N / 4);
             const int blocks = (int)((n4 + 255) / 256);
-            if (split) hipLaunchKernelGGL(splitk_finish_kernel<true>, dim3(blocks), dim3(256), 0, st, p.skbuf, p.bias, p.M, p.N, p.act, p.R1_hi, p.R2_hi, p.C_hi, p.c_rp);
-            else hipLaunchKernelGGL(splitk_finish_kernel<false>, dim3(blocks), dim3(256), 0, st, p.skbuf, p.bias, p.M, p.N, p.act, p.R1_hi, p.R2_hi, p.C_hi, p.c_rp);
+            if (split) hipLaunchKernelGGL(splitk_finish_kernel<true>, dim3(blocks), dim3(256), 0, st, p.skbuf, p.bias, p.M, p.N, p.act, p.R1_hi, p.R2_hi, p.C_hi, p.c_rp, p.r_mx, p.c_mx);
+            else hipLaunchKernelGGL(splitk_finish_kernel<false>, dim3(blocks), dim3(256), 0, st, p.skbuf, p.bias, p.M, p.N, p.act, p.R1_hi, p.R2_hi, p.C_hi, p.c_rp, 0, 0);
             HIPCHK(hipGetLastError());
         }
     } else {
@@ -609,7 +597,7 @@ static GemmParams gp_dense(const Planes& A, int lda, const Lin& W, int M, bool m
 
 // out fp32 = A*W^T + bias (+resid), optional row remap
 // an f16mx kernel exists for every tile family with N % 64 == 0 (the one exception on the path: act_postprocess[0], N = 96)
-static bool use_mx(const sta_handle* h, const Lin& W) { return h->prec == STA_PREC_F16MX && W.wmx.hi != nullptr && W.N % 64 == 0; }
+static bool use_mx(const sta_handle* h, const Lin& W) { return (h->mx_mask & W.cls) != 0 && W.wmx.hi != nullptr && W.N % 64 == 0; }
 
 static int gemm_f32(sta_handle* h, const Planes& A, const Lin& W, int M, float* out, int ldc,
                     const float* resid, hipStream_t st, int rows_in = 0, int rows_out = 0, int row_off = 0) {
@@ -671,10 +659,10 @@ static int conv3(sta_handle* h, const Planes& in, int nimg, int Hi, int Wi, int 
 }
 
 static int run_ln(sta_handle* h, const float* x, int M, int C, const LNp& a, const Planes& oa,
-                  const LNp* b, const Planes* ob, float* o32, hipStream_t st, bool allow_mx = true) {
+                  const LNp* b, const Planes* ob, float* o32, hipStream_t st, bool mx = false) {
     if (h->dry) return 0;
     LnParams p; memset(&p, 0, sizeof p);
-    p.mx = (allow_mx && h->prec == STA_PREC_F16MX) ? 1 : 0;     // every LayerNorm on the path feeds a transformer linear
+    p.mx = mx ? 1 : 0;     // plane format of the consumer GEMM (f16mx rows when that linear runs in the f16mx arithmetic)
     p.x = x; p.ldx = C; p.M = M; p.C = C; p.eps = h->cfg.ln_eps;
     p.g1 = a.g; p.b1 = a.b; p.o1_hi = oa.hi; p.o1_lo = oa.lo;
     if (b) { p.g2 = b->g; p.b2 = b->b; p.o2_hi = ob->hi; p.o2_lo = ob->lo; }
@@ -687,10 +675,10 @@ static int run_ln(sta_handle* h, const float* x, int M, int C, const LNp& a, con
 }
 
 static int run_attn(sta_handle* h, const QKVOut& qkv, const Planes& out, int ldo, int S, int heads,
-                    int nq, int nk, int kv_shift, hipStream_t st, bool allow_mx = true) {
+                    int nq, int nk, int kv_shift, hipStream_t st, bool o_mx = false) {
     if (h->dry) return 0;
     AttnParams p; memset(&p, 0, sizeof p);
-    p.o_mx = (allow_mx && h->prec == STA_PREC_F16MX) ? 1 : 0;   // attention output feeds attn.proj / cross_attn.proj
+    p.o_mx = o_mx ? 1 : 0;   // attention output feeds attn.proj / cross_attn.proj: their plane format
     p.Q_hi = qkv.q.hi; p.Q_lo = qkv.q.lo; p.K_hi = qkv.k.hi; p.K_lo = qkv.k.lo; p.Vt_hi = qkv.vt.hi; p.Vt_lo = qkv.vt.lo;
     p.O_hi = out.hi; p.O_lo = out.lo; p.ldo = ldo;
     p.S = S; p.heads = heads; p.nq = nq; p.nk = nk; p.npad = qkv.npad; p.kv_shift = kv_shift;
@@ -783,11 +771,11 @@ static int encode_impl(sta_handle* h, Bump& ws, const void* const* imgs, bool u8
     CHK(gemm_f32(h, patches, h->patch, M, feat, E, nullptr, st));
     for (int i = 0; i < c.enc_depth; ++i) {
         const EncBlk& b = h->enc[i];
-        CHK(run_ln(h, feat, M, E, b.n1, lnp, nullptr, nullptr, nullptr, st));
+        CHK(run_ln(h, feat, M, E, b.n1, lnp, nullptr, nullptr, nullptr, st, use_mx(h, b.qkv)));
         CHK(gemm_qkv(h, lnp, b.qkv, M, E, E, E, qkv, N, Hh, wp, 0, st));
-        CHK(run_attn(h, qkv, ao, E, n, Hh, N, N, 0, st));
+        CHK(run_attn(h, qkv, ao, E, n, Hh, N, N, 0, st, use_mx(h, b.proj)));
         CHK(gemm_f32(h, ao, b.proj, M, feat, E, feat, st));
-        CHK(run_ln(h, feat, M, E, b.n2, lnp, nullptr, nullptr, nullptr, st));
+        CHK(run_ln(h, feat, M, E, b.n2, lnp, nullptr, nullptr, nullptr, st, use_mx(h, b.fc1)));
         CHK(gemm_f16(h, lnp, b.fc1, M, f1, ACT_GELU, st, use_mx(h, b.fc2)));
         CHK(gemm_f32(h, f1, b.fc2, M, feat, E, feat, st));
     }
@@ -832,16 +820,16 @@ static int decode_impl(sta_handle* h, Bump& ws, const float* feat1, const float*
     for (int i = 0; i < c.dec_depth; ++i) {
         const DecBlk& b = h->dec[i];
         // norm1(x) and norm_y(x) from one read: y of one side == x of the other (sta_model.py:231-235)
-        CHK(run_ln(h, x, M, D, b.n1, a1, &b.ny, &ay, nullptr, st));
+        CHK(run_ln(h, x, M, D, b.n1, a1, &b.ny, &ay, nullptr, st, use_mx(h, b.qkv)));     // qkv and projk|projv: one class, one format
         CHK(gemm_qkv(h, a1, b.qkv, M, D, D, D, qkv, Np, Hh, wp, 1, st));
-        CHK(run_attn(h, qkv, ao, D, S, Hh, Np, Np, 0, st));
+        CHK(run_attn(h, qkv, ao, D, S, Hh, Np, Np, 0, st, use_mx(h, b.proj)));
         CHK(gemm_f32(h, ao, b.proj, M, x, D, x, st));
-        CHK(run_ln(h, x, M, D, b.n2, a1, nullptr, nullptr, nullptr, st));
+        CHK(run_ln(h, x, M, D, b.n2, a1, nullptr, nullptr, nullptr, st, use_mx(h, b.cq)));
         CHK(gemm_qkv(h, a1, b.cq, M, D, 0, 0, qkv, Np, Hh, wp, 1, st));
         CHK(gemm_qkv(h, ay, b.ckv, M, 0, D, D, qkv, Np, Hh, wp, 1, st));
-        CHK(run_attn(h, qkv, ao, D, S, Hh, Np, Np, B, st));
+        CHK(run_attn(h, qkv, ao, D, S, Hh, Np, Np, B, st, use_mx(h, b.cproj)));
         CHK(gemm_f32(h, ao, b.cproj, M, x, D, x, st));
-        CHK(run_ln(h, x, M, D, b.n3, a1, nullptr, nullptr, nullptr, st));
+        CHK(run_ln(h, x, M, D, b.n3, a1, nullptr, nullptr, nullptr, st, use_mx(h, b.fc1)));
         CHK(gemm_f16(h, a1, b.fc1, M, f1, ACT_GELU, st, use_mx(h, b.fc2)));
         CHK(gemm_f32(h, f1, b.fc2, M, x, D, x, st));
         if (i + 1 < c.dec_depth) {
@@ -896,7 +884,7 @@ static int dpt_impl(sta_handle* h, Bump& ws, const float* enc, int64_t enc_bs,
     const int M = n * N;
     // precision f16mx: every DPT buffer is in the f16mx row format, except the input of act_postprocess[0]
     // (N = 96: no f16mx kernel for that one GEMM, it reads f16x3 rows and WRITES f16mx rows)
-    const bool dmx = h->prec == STA_PREC_F16MX;
+    const bool dmx = (h->mx_mask & CLS_HEAD) != 0;
     auto act = [&](int64_t rows, int64_t cols, bool mx) { Planes q = ws.act(rows, cols, split); q.mx = mx; return q; };
     Planes t0 = act(M, E, use_mx(h, h->act0_0)), t1 = act(M, D, dmx);
     Planes t2 = act(M, D, dmx), t3 = act(M, D, dmx);
@@ -1169,6 +1157,12 @@ extern "C" int sta_kernel_timing(sta_handle* h, int enable) {
     if (enable && !h->clk_buf) { HIPCHK(hipMalloc((void**)&h->clk_buf, 16)); }
     if (h->clk_buf) HIPCHK(hipMemset(h->clk_buf, 0, 16));
     h->ktime = enable != 0; h->ktime_all = enable == 2; h->kn = 0;
+    if (enable != 3) h->kfilter[0] = h->kfilter[1] = h->kfilter[2] = h->kfilter[3] = -1;
+    return 0;
+}
+extern "C" int sta_kernel_timing_filter(sta_handle* h, int epilogue, int a_mode, int family, int mx) {
+    REQUIRE(h, "null handle");
+    h->kfilter[0] = epilogue; h->kfilter[1] = a_mode; h->kfilter[2] = family; h->kfilter[3] = mx;
     return 0;
 }
 extern "C" int sta_kernel_clock_read(sta_handle* h, float* ghz_out) {
@@ -1210,14 +1204,14 @@ extern "C" int sta_kernel_timing_dump(sta_handle* h, int cap, double* flops, flo
     return 0;
 }
 
-extern "C" int sta_kernel_timing_dump_shapes(sta_handle* h, int cap, int* shape5, float* ms, int* variant, int* n_out) {
-    REQUIRE(h && shape5 && ms && variant && n_out, "null argument");
+extern "C" int sta_kernel_timing_dump_shapes(sta_handle* h, int cap, int* shape6, float* ms, int* variant, int* n_out) {
+    REQUIRE(h && shape6 && ms && variant && n_out, "null argument");
     DEV_SCOPE(h->device);
     int n = 0;
     for (int i = 0; i < h->kn && n < cap; ++i, ++n) {
         HIPCHK(hipEventSynchronize(h->kev[2 * i + 1]));
         HIPCHK(hipEventElapsedTime(&ms[n], h->kev[2 * i], h->kev[2 * i + 1]));
-        for (int q = 0; q < 5; ++q) shape5[5 * n + q] = h->kshape[5 * i + q];
+        for (int q = 0; q < 6; ++q) shape6[6 * n + q] = h->kshape[6 * i + q];
         variant[n] = h->kvar[i];
     }
     *n_out = n;

@@ -29,7 +29,7 @@ def _stream_ptr(device=None) -> int:
 
 class STAFrontend:
     def __init__(self, cfg: W.STAConfig = W.FULL, device: str | torch.device = "cuda:0",
-                 precision: str = "f16x3", img_size=(224, 224)):
+                 precision: str = "f16x3h", img_size=(224, 224)):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.StaError("STAFrontend needs a ROCm GPU (MI355X / gfx950); there is no CPU fallback")
@@ -348,6 +348,12 @@ class STAFrontend:
         n, ms, fl, by = C.c_int(), C.c_double(), C.c_double(), C.c_double()
         _lib.check(self.lib.sta_kernel_timing_read(self._h, tile_family, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)))
         return int(n.value), float(ms.value), float(fl.value), float(by.value)
+
+    def kernel_timing_records(self, cap: int = 16384):
+        """Per-launch records since kernel_timing(2): list of (M, N, K, epilogue, a_mode, mx, family, ms)."""
+        sh = (C.c_int * (6 * cap))(); ms = (C.c_float * cap)(); var = (C.c_int * cap)(); n = C.c_int()
+        _lib.check(self.lib.sta_kernel_timing_dump_shapes(self._h, cap, sh, ms, var, C.byref(n)))
+        return [tuple(sh[6 * i + q] for q in range(6)) + (var[i], float(ms[i])) for i in range(n.value)]
 
     def bench_gemm(self, M: int, N: int, K: int, iters: int = 20, tile: int = 0, ablation: int = 0) -> float:
         ms = C.c_float()
