@@ -83,6 +83,13 @@ int sta_destroy(sta_handle* h);
 /* Change the arithmetic policy after creation (weights hold both split planes). */
 int sta_set_precision(sta_handle* h, int precision);
 
+/* Bit-reproducible mode.  At SLAM scale (a few hundred rows) the in-place residual GEMMs and the low-resolution DPT
+ * convolutions split K over workgroups and combine the slices with fp32 atomics: fast, but the summation order - hence
+ * the last bits of the result, and in principle a borderline `pose_conf < rel_pose_thres` decision (slam.py:169) - varies
+ * run to run.  on != 0 disables every split-K path: identical bits on every run of the same binary, at a 1.5-2x cost for
+ * B = 1 @224x224 (nothing changes at benchmark scale, where no GEMM is split).  Default: off. */
+int sta_set_deterministic(sta_handle* h, int on);
+
 /* Batch-slice concurrency of sta_forward_pair*: 1 = one slice on the caller's stream (default); n = 2..4: the batch is cut
  * in n slices that run on n library-owned streams, forked from / joined to the caller's stream by events, so the
  * hardware overlaps one slice's GEMM tail rounds and HBM-bound kernels with the other's MFMA main loops.  Results are

@@ -594,3 +594,35 @@ def test_multi_gpu_layer_on_real_outputs_nccl_world1(G):
         assert not res[3]["accepted"] and all(r["accepted"] for r in res[:3])
     finally:
         dist.destroy_process_group()
+
+
+def test_deterministic_mode_is_bit_reproducible_at_slam_scale(G):
+    """sta_set_deterministic: the B = 1 @224x224 split entry points (the regime whose GEMMs split K with fp32 atomics) give
+    identical bits on repeated runs, and stay within the parity bar of the default mode."""
+    import torch
+    from helpers import rel_l2
+    from vista_slam_amd import weights as W
+    G.drop_models()
+    m = G.model("full", 1.0, "f16x3h")
+    imgs = torch.from_numpy(W.synth_images(2, 224, 224, seed=43, tag=51)).cuda()
+    ts = torch.tensor([[224, 224]])
+
+    def run():
+        fa, pa = m._encode_image(imgs[:1], ts, normalize=False)
+        fb, pb = m._encode_image(imgs[1:], ts, normalize=False)
+        d1, d2 = m._decode_stereo(fa, fb, pa, pb, layers=[6, 9, 12])
+        pts = m.head_pts([fa] + [None if t is None else t[:, 1:, :] for t in d1], ts)
+        pose = m.head_pose_s(d1[-1][:, 0, :])
+        torch.cuda.synchronize()
+        return fa.clone(), d1[-1].clone(), pts["pts3d"].clone(), pose["conf"].clone()
+    ref = run()
+    m.set_deterministic(True)
+    try:
+        a, b = run(), run()
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+        for x, y in zip(a, ref):
+            assert rel_l2(x.cpu().numpy(), y.cpu().numpy()) < 1e-4
+    finally:
+        m.set_deterministic(False)
+    G.drop_models()

@@ -11,7 +11,10 @@ B, H, Wd = 8, 384, 512
 imgs = torch.from_numpy(W.synth_images(2 * B, H, Wd, seed=43, tag=0)).cuda()
 for rep in range(2):
     for prec, v, av in cfgs:
-        os.environ["STA_EXPERIMENT"] = av     # free slot for a one-off getenv knob in the library
+        if av == "nopair":
+            os.environ["STA_EXPERIMENT_NO_PAIR"] = "1"
+        else:
+            os.environ.pop("STA_EXPERIMENT_NO_PAIR", None)
         if prec.startswith("mask"):          # f16x3 with the given layer classes in the f16mx arithmetic (sta_set_mx_mask)
             m.set_precision("f16x3")
             _lib.check(m.lib.sta_set_mx_mask(m._h, int(prec[4:])))

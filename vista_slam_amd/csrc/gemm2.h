@@ -44,7 +44,7 @@ __device__ __forceinline__ int lds2_off(int row, int chunk) {
 // no gain on the big throughput shapes (DMA-throughput bound) but it is what makes the small-M /
 // split-K family (SLAM-scale GEMMs, a handful of K tiles per block) latency-tolerant.
 template <bool SPLIT, int AMODE, int EPI, int BM, int BN, int WAVES_M, int WAVES_N, int ABL = 0, int NSTG = 2, bool MX = false>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const GemmParams p) {
+__device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_id) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MT = WM / 32, NT = WN / 32;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
     const int nwg = tiles_m * tiles_n * ksplit;
     int t;
     {
-        const int bid = blockIdx.x, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+        const int bid = block_id, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
     }
     const int kslice = t % ksplit;
@@ -349,8 +349,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const Gemm
 #pragma unroll
         for (int i = 0; i < MT; ++i)
             epilogue_tile<SPLIT, EPI>(p, acc[i][j], m0 + wm * WM + i * 32, n0 + wn * WN + j * 32 + l31, lane, kslice == 0);
-    if (p.clk_dbg && tid == 0 && (blockIdx.x & 63) == 0) {      // effective shader clock = cycles / (ticks / 100 MHz)
+    if (p.clk_dbg && tid == 0 && (block_id & 63) == 0) {      // effective shader clock = cycles / (ticks / 100 MHz)
         atomicAdd(p.clk_dbg, __builtin_readcyclecounter() - clk0);
         atomicAdd(p.clk_dbg + 1, __builtin_amdgcn_s_memrealtime() - rt0);
     }
+}
+
+template <bool SPLIT, int AMODE, int EPI, int BM, int BN, int WAVES_M, int WAVES_N, int ABL = 0, int NSTG = 2, bool MX = false>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_kernel(const GemmParams p) {
+    gemm2_body<SPLIT, AMODE, EPI, BM, BN, WAVES_M, WAVES_N, ABL, NSTG, MX>(p, blockIdx.x);
+}
+
+// Two independent GEMMs of the same tile family in ONE launch: blocks [0, tiles_a) work on `pa`, the rest on `pb`.
+// Used for the decoder's attn.qkv (on norm1(x)) and cross_attn.projk|projv (on norm_y(other side)), which depend only on
+// the layer input: 1170 + 780 tiles of 192x128 are 3 + 2 rounds of the 512 resident slots as two launches, 4 as one.
+template <bool SPLIT, int AMODE, int EPI, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm2_pair_kernel(const GemmParams pa, const GemmParams pb, const int tiles_a) {
+    if ((int)blockIdx.x < tiles_a) gemm2_body<SPLIT, AMODE, EPI, BM, BN, WAVES_M, WAVES_N>(pa, blockIdx.x);
+    else gemm2_body<SPLIT, AMODE, EPI, BM, BN, WAVES_M, WAVES_N>(pb, blockIdx.x - tiles_a);
 }

@@ -76,6 +76,8 @@ struct sta_handle {
     sta_config cfg;
     int device = 0;
     int prec = STA_PREC_F16X3;
+    bool deterministic = false;   // sta_set_deterministic: no split-K (fp32 atomics): bit-reproducible results run to run
+    bool no_pairing = false;  // tests / A-B: launch the decoder's qkv and projk|projv GEMMs separately
     int mx_mask = 0;          // CLS_* bits of the layer classes that run in the f16mx arithmetic (set by the precision mode)
     bool finalized = false;
     std::unordered_map<std::string, Slot> slots;
@@ -380,6 +382,11 @@ extern "C" int sta_set_mx_mask(sta_handle* h, int mask) {
     h->mx_mask = mask;
     return 0;
 }
+extern "C" int sta_set_deterministic(sta_handle* h, int on) {
+    REQUIRE(h, "null handle");
+    h->deterministic = on != 0;
+    return 0;
+}
 extern "C" int sta_set_concurrency(sta_handle* h, int n_slices) {
     REQUIRE(h, "null handle");
     REQUIRE(n_slices >= 1 && n_slices <= 4, "n_slices must be 1..4");
@@ -491,7 +498,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
     const int64_t tiles_192 = (int64_t)((p.M + 191) / 192) * ((p.N + 127) / 128);
     if ((p.M <= 640 || tiles_192 < 128) && p.N % 64 == 0) {
         variant = 6;
-        const int tiles = ((p.M + 127) / 128) * (p.N / 64);
+        const int tiles = h->deterministic ? (1 << 30) : ((p.M + 127) / 128) * (p.N / 64);   // deterministic: no split-K below
         if (AMODE == A_DENSE && EPI == EPI_F32 && p.resid == p.C32 && p.rows_in == 0 && tiles < 256) {
             int ks = (256 + tiles - 1) / tiles;
             const int max_ks = p.K / 128;                 // keep >= 4 K tiles per slice
@@ -620,16 +627,60 @@ static int gemm_f16(sta_handle* h, const Planes& A, const Lin& W, int M, const P
     return launch_gemm<A_DENSE, EPI_F16>(h, p, st);
 }
 struct QKVOut { Planes q, k, vt; int npad; };
-static int gemm_qkv(sta_handle* h, const Planes& A, const Lin& W, int M, int nq, int nk, int nv,
-                    const QKVOut& o, int ntok, int heads, int wp, int has_pose, hipStream_t st) {
-    GemmParams p = gp_dense(A, W.K, W, M, use_mx(h, W));
+static int gp_qkv(sta_handle* h, GemmParams& p, const Planes& A, const Lin& W, int M, int nq, int nk, int nv,
+                  const QKVOut& o, int ntok, int heads, int wp, int has_pose) {
+    p = gp_dense(A, W.K, W, M, use_mx(h, W));
     p.Q_hi = o.q.hi; p.Q_lo = o.q.lo; p.K_hi = o.k.hi; p.K_lo = o.k.lo; p.Vt_hi = o.vt.hi; p.Vt_lo = o.vt.lo;
     p.nq = nq; p.nk = nk; p.nv = nv; p.ntok = ntok; p.npad = o.npad; p.heads = heads; p.wp = wp; p.has_pose_tok = has_pose;
     p.rope_tab = h->rope_tab;
     p.ntok_magic = ntok > 1 ? (unsigned)((1ull << 32) / (unsigned)ntok + 1) : 0u;
     p.wp_magic = wp > 1 ? (unsigned)((1ull << 32) / (unsigned)wp + 1) : 0u;
     REQUIRE(nq + nk + nv == W.N, "qkv segment mismatch");
+    return 0;
+}
+static int gemm_qkv(sta_handle* h, const Planes& A, const Lin& W, int M, int nq, int nk, int nv,
+                    const QKVOut& o, int ntok, int heads, int wp, int has_pose, hipStream_t st) {
+    GemmParams p;
+    CHK(gp_qkv(h, p, A, W, M, nq, nk, nv, o, ntok, heads, wp, has_pose));
     return launch_gemm<A_DENSE, EPI_QKV>(h, p, st);
+}
+// Two QKV-epilogue GEMMs that do not depend on each other as ONE launch (gemm2_pair_kernel) when both run on the 192x128
+// family at throughput scale; otherwise two launches.  Decoder: attn.qkv on norm1(x) + cross_attn.projk|projv on norm_y.
+static int gemm_qkv_pair(sta_handle* h, const GemmParams& pa_in, const GemmParams& pb_in, hipStream_t st) {
+    GemmParams pa = pa_in, pb = pb_in;
+    const bool split = h->prec != STA_PREC_F16;
+    auto big = [](const GemmParams& p) { return p.M > 640 && p.N % 128 == 0 && (int64_t)((p.M + 191) / 192) * (p.N / 128) >= 128; };
+    if (h->dry) return 0;
+    if (!split || pa.mx || pb.mx || !big(pa) || !big(pb) || pa.K != pb.K || pa.M != pb.M || h->gemm_variant != 0 || h->no_pairing || getenv("STA_EXPERIMENT_NO_PAIR")) {
+        CHK((launch_gemm<A_DENSE, EPI_QKV>(h, pa, st)));
+        return launch_gemm<A_DENSE, EPI_QKV>(h, pb, st);
+    }
+    pa.zero_page = pb.zero_page = h->zero_page;
+    pa.ksplit = pb.ksplit = 1;
+    const int ta = ((pa.M + 191) / 192) * (pa.N / 128), tb = ((pb.M + 191) / 192) * (pb.N / 128);
+    const bool timed = h->ktime && (h->ktime_all || (h->kfilter[0] == EPI_QKV && h->kfilter[1] == A_DENSE && h->kfilter[2] == 5 && h->kfilter[3] == 0));
+    if (timed) {      // one record: M x (Na + Nb) x K
+        if ((int)h->kev.size() < 2 * (h->kn + 1)) {
+            hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+            h->kev.push_back(a); h->kev.push_back(b);
+        }
+        if ((int)h->kflops.size() <= h->kn) h->kflops.resize(h->kn + 1);
+        h->kflops[h->kn] = 2.0 * pa.M * (pa.N + pb.N) * pa.K;
+        if ((int)h->kshape.size() < 6 * (h->kn + 1)) h->kshape.resize(6 * (h->kn + 1));
+        { int* q = &h->kshape[6 * h->kn]; q[0] = pa.M; q[1] = pa.N + pb.N; q[2] = pa.K; q[3] = EPI_QKV; q[4] = A_DENSE; q[5] = 0; }
+        if ((int)h->kbytes.size() <= h->kn) h->kbytes.resize(h->kn + 1);
+        h->kbytes[h->kn] = 4.0 * (2.0 * pa.M * pa.K + (double)(pa.N + pb.N) * pa.K) + 4.0 * pa.M * (pa.N + pb.N);
+        HIPCHK(hipEventRecord(h->kev[2 * h->kn], st));
+        h->kn++;
+    }
+    static bool attr_done = false;
+    constexpr int smem = gemm2_smem_bytes<true, 192, 128>(2);
+    auto kern = gemm2_pair_kernel<true, A_DENSE, EPI_QKV, 192, 128, 2, 4>;
+    if (!attr_done) { HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr_done = true; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ta + tb)), dim3(512), smem, st, pa, pb, ta);
+    HIPCHK(hipGetLastError());
+    if (timed) { HIPCHK(hipEventRecord(h->kev[2 * (h->kn - 1) + 1], st)); if ((int)h->kvar.size() < h->kn) h->kvar.resize(h->kn); h->kvar[h->kn - 1] = 5; }
+    return 0;
 }
 static int gemm_convt(sta_handle* h, const Planes& A, const Lin& W, int nimg, int hh, int ww, int k, int cout,
                       const Planes& out, hipStream_t st) {
@@ -799,10 +850,14 @@ static int decode_impl(sta_handle* h, Bump& ws, const float* feat1, const float*
     QKVOut qkv; qkv.npad = npad;
     int64_t hsz = (int64_t)S * Hh * npad * 64;
     qkv.q = ws.planes(hsz, split); qkv.k = ws.planes(hsz, split); qkv.vt = ws.planes(hsz, split);
+    QKVOut cqkv; cqkv.npad = npad;          // cross attention: its K / V^T are produced while the self-attention set is live
+    cqkv.q = ws.planes(hsz, split); cqkv.k = ws.planes(hsz, split); cqkv.vt = ws.planes(hsz, split);
     if (h->dry) return 0;
     REQUIRE(!ws.overflow, "internal: decode workspace overflow");
     HIPCHK(hipMemsetAsync(qkv.vt.hi, 0, hsz * 2, st));
     if (split) HIPCHK(hipMemsetAsync(qkv.vt.lo, 0, hsz * 2, st));
+    HIPCHK(hipMemsetAsync(cqkv.vt.hi, 0, hsz * 2, st));
+    if (split) HIPCHK(hipMemsetAsync(cqkv.vt.lo, 0, hsz * 2, st));
 
     Planes fp2 = slice_rows(fp, (int64_t)B * N);
     CHK(run_rows_to_planes(h, feat1, (int64_t)N * E, B, N, E, fp, st));
@@ -821,13 +876,19 @@ static int decode_impl(sta_handle* h, Bump& ws, const float* feat1, const float*
         const DecBlk& b = h->dec[i];
         // norm1(x) and norm_y(x) from one read: y of one side == x of the other (sta_model.py:231-235)
         CHK(run_ln(h, x, M, D, b.n1, a1, &b.ny, &ay, nullptr, st, use_mx(h, b.qkv)));     // qkv and projk|projv: one class, one format
-        CHK(gemm_qkv(h, a1, b.qkv, M, D, D, D, qkv, Np, Hh, wp, 1, st));
+        // self-attention q,k,v and the cross-attention k,v of the OTHER side depend only on the layer input: one launch.
+        // (They write disjoint buffers: qkv / ckv_out.)
+        {
+            GemmParams pq, pkv;
+            CHK(gp_qkv(h, pq, a1, b.qkv, M, D, D, D, qkv, Np, Hh, wp, 1));
+            CHK(gp_qkv(h, pkv, ay, b.ckv, M, 0, D, D, cqkv, Np, Hh, wp, 1));
+            CHK(gemm_qkv_pair(h, pq, pkv, st));
+        }
         CHK(run_attn(h, qkv, ao, D, S, Hh, Np, Np, 0, st, use_mx(h, b.proj)));
         CHK(gemm_f32(h, ao, b.proj, M, x, D, x, st));
         CHK(run_ln(h, x, M, D, b.n2, a1, nullptr, nullptr, nullptr, st, use_mx(h, b.cq)));
-        CHK(gemm_qkv(h, a1, b.cq, M, D, 0, 0, qkv, Np, Hh, wp, 1, st));
-        CHK(gemm_qkv(h, ay, b.ckv, M, 0, D, D, qkv, Np, Hh, wp, 1, st));
-        CHK(run_attn(h, qkv, ao, D, S, Hh, Np, Np, B, st, use_mx(h, b.cproj)));
+        CHK(gemm_qkv(h, a1, b.cq, M, D, 0, 0, cqkv, Np, Hh, wp, 1, st));
+        CHK(run_attn(h, cqkv, ao, D, S, Hh, Np, Np, B, st, use_mx(h, b.cproj)));
         CHK(gemm_f32(h, ao, b.cproj, M, x, D, x, st));
         CHK(run_ln(h, x, M, D, b.n3, a1, nullptr, nullptr, nullptr, st, use_mx(h, b.fc1)));
         CHK(gemm_f16(h, a1, b.fc1, M, f1, ACT_GELU, st, use_mx(h, b.fc2)));

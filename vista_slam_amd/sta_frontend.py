@@ -102,6 +102,10 @@ class STAFrontend:
         _lib.check(self.lib.sta_set_precision(self._h, _lib.PRECISIONS[precision]))
         self.precision = precision
 
+    def set_deterministic(self, on: bool = True):
+        """Bit-reproducible results (no split-K fp32 atomics at SLAM scale; include/sta_mi355.h)."""
+        _lib.check(self.lib.sta_set_deterministic(self._h, int(on)))
+
     def set_concurrency(self, n_slices):
         """1 = single stream (default); 2 = two batch slices on two internal streams (sta_mi355.h)."""
         _lib.check(self.lib.sta_set_concurrency(self._h, int(n_slices)))
