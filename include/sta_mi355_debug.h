@@ -69,7 +69,7 @@ int sta_kernel_timing_dump(sta_handle* h, int cap, double* flops, float* ms, int
 /* The same record for EVERY GEMM / convolution launch after sta_kernel_timing(h, 2) (experiments: per-shape in-model
  * durations per tile family, tools/gemm_tiles.py shapes; the roofline block of bench.py): shape6 = {M, N, K, epilogue id,
  * A-loader id (0 dense, 1 conv3x3), 1 if the launch ran in the f16mx arithmetic}; variant = tile family (1 = 128x128
- * register-staged, 2 = 256x256 / 16 waves, 3 = 192x256 / 12 waves, 5 = 192x128 / 8 waves, 6 = 128x64 small-grid ring). */
+ * register-staged, 2 = 256x256 / 16 waves, 3 = 192x256 / 12 waves, 5 = 192x128 / 8 waves, 6 = 128x64 small-grid ring, 7 = gemm2_pair_kernel: two 192x128 GEMMs in one launch). */
 int sta_kernel_timing_dump_shapes(sta_handle* h, int cap, int* shape6, float* ms, int* variant, int* n_out);
 
 /* Restrict the per-launch timing to ONE kernel symbol {epilogue id, A-loader id, tile family, f16mx flag}; then

@@ -9,7 +9,8 @@ import sys
 
 def short(name):
     name = re.sub(r"\[clone .*\]", "", name)
-    name = name.replace("void ", "").replace("(GemmParams)", "").replace("(AttnParams)", "").replace("(LnParams)", "")
+    name = name.replace("void ", "").replace("(AttnParams)", "").replace("(LnParams)", "")
+    name = re.sub(r"\(GemmParams(, GemmParams, int)?\)", "", name)
     return name[:110]
 
 

@@ -9,7 +9,7 @@
 //    Activations and weights live in the K-tile-blocked layout  [K/32][rows][hi32|lo32]  (blk_off in
 //    sta_common.h): one K tile of 8 consecutive rows is 1 KiB of CONTIGUOUS memory, i.e. every DMA
 //    wave-instruction reads 8 full 128-B lines (row-major operands gave half-line 64-B pieces and
-//    25 % less DMA throughput, tools/gemm_bench2.py).
+//    25 % less DMA throughput, round-1 micro-benchmark, now tools/gemm_tiles.py).
 //  * LDS image (f16x3): rows of 128 B = [hi 32 halves | lo 32 halves]; the 16-B chunk index is XORed
 //    with (row>>1)&7 so the fragment ds_read_b128 is bank-conflict free.  The DMA writes lane-linear,
 //    so the XOR is applied to the per-lane SOURCE chunk (same involution on both sides).

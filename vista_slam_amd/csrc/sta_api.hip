@@ -658,8 +658,8 @@ static int gemm_qkv_pair(sta_handle* h, const GemmParams& pa_in, const GemmParam
     pa.zero_page = pb.zero_page = h->zero_page;
     pa.ksplit = pb.ksplit = 1;
     const int ta = ((pa.M + 191) / 192) * (pa.N / 128), tb = ((pb.M + 191) / 192) * (pb.N / 128);
-    const bool timed = h->ktime && (h->ktime_all || (h->kfilter[0] == EPI_QKV && h->kfilter[1] == A_DENSE && h->kfilter[2] == 5 && h->kfilter[3] == 0));
-    if (timed) {      // one record: M x (Na + Nb) x K
+    const bool timed = h->ktime && (h->ktime_all || (h->kfilter[0] == EPI_QKV && h->kfilter[1] == A_DENSE && h->kfilter[2] == 7 && h->kfilter[3] == 0));
+    if (timed) {      // one record: M x (Na + Nb) x K, tile family id 7 = gemm2_pair_kernel
         if ((int)h->kev.size() < 2 * (h->kn + 1)) {
             hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
             h->kev.push_back(a); h->kev.push_back(b);
@@ -679,7 +679,7 @@ static int gemm_qkv_pair(sta_handle* h, const GemmParams& pa_in, const GemmParam
     if (!attr_done) { HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr_done = true; }
     hipLaunchKernelGGL(kern, dim3((unsigned)(ta + tb)), dim3(512), smem, st, pa, pb, ta);
     HIPCHK(hipGetLastError());
-    if (timed) { HIPCHK(hipEventRecord(h->kev[2 * (h->kn - 1) + 1], st)); if ((int)h->kvar.size() < h->kn) h->kvar.resize(h->kn); h->kvar[h->kn - 1] = 5; }
+    if (timed) { HIPCHK(hipEventRecord(h->kev[2 * (h->kn - 1) + 1], st)); if ((int)h->kvar.size() < h->kn) h->kvar.resize(h->kn); h->kvar[h->kn - 1] = 7; }
     return 0;
 }
 static int gemm_convt(sta_handle* h, const Planes& A, const Lin& W, int nimg, int hh, int ww, int k, int cout,
