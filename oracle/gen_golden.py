@@ -358,6 +358,10 @@ CASES = {
     "full512": [
         dict(name="full_384x512_b1", cfg=W.FULL, H=384, W_=512, B=1, sub=16),
     ],
+    # two DIFFERENT pairs at the benchmark resolution: the batch-8 parity test fills every batch slot with one of them
+    "full512b2": [
+        dict(name="full_384x512_b2", cfg=W.FULL, H=384, W_=512, B=2, sub=16),
+    ],
 }
 
 if __name__ == "__main__":

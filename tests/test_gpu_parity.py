@@ -150,7 +150,7 @@ def full_b8(G):
     import torch
     from vista_slam_amd import weights as W
     G.drop_models()
-    m = G.model("full", 1.0, "f16x3")
+    m = G.model("full", 1.0, DEFAULT)
     G.set_variant(m, 0)
     imgs = W.synth_images(16, 384, 512, seed=43, tag=0)
     a, b = torch.from_numpy(imgs[:8]).cuda(), torch.from_numpy(imgs[8:]).cuda()
@@ -221,6 +221,33 @@ def test_full_size_pair0_matches_reference_golden(full_b8):
     assert rel_l2(supp["conf"][:1].cpu().numpy()[:, ::sub, ::sub], g["supp_conf"]) < TOL
     assert rel_l2(main["relative_pose"][:1].cpu().numpy(), g["main_pose"]) < TOL
     assert rel_l2(supp["relative_pose"][:1].cpu().numpy(), g["supp_pose"]) < TOL
+
+
+def test_full_size_batch8_every_slot_matches_reference_golden(full_b8):
+    """BASELINE configs[1] at its full batch: every one of the 8 batch slots holds one of the two DIFFERENT pairs of the
+    reference golden `full_384x512_b2` (order 0,1,1,0,0,1,0,1), and all eight output tensors of every slot are compared
+    with the reference's outputs for that pair - a cross-slot mix-up or a slot-dependent error cannot hide."""
+    import numpy as np
+    import torch
+    from helpers import load_golden, rel_l2
+    from vista_slam_amd import weights as W
+    m = full_b8[0]
+    g, meta = load_golden("full_384x512_b2")
+    sub = int(meta["sub"])
+    imgs = W.synth_images(4, 384, 512, seed=int(meta["seed"]), tag=0)
+    order = [0, 1, 1, 0, 0, 1, 0, 1]
+    a = torch.from_numpy(np.ascontiguousarray(imgs[:2][order])).cuda()
+    b = torch.from_numpy(np.ascontiguousarray(imgs[2:][order])).cuda()
+    main, supp = m.forward_pair(a, b)
+    torch.cuda.synchronize()
+    for slot, src in enumerate(order):
+        for side, o in (("main", main), ("supp", supp)):
+            e = {"pts3d": rel_l2(o["pts3d_pred"][slot].cpu().numpy()[::sub, ::sub], g[f"{side}_pts3d"][src]),
+                 "conf": rel_l2(o["conf"][slot].cpu().numpy()[::sub, ::sub], g[f"{side}_conf"][src]),
+                 "pose": rel_l2(o["relative_pose"][slot].cpu().numpy(), g[f"{side}_pose"][src]),
+                 "pose_conf": rel_l2(o["relative_pose_conf"][slot].cpu().numpy(), g[f"{side}_pose_conf"][src])}
+            bad = {k: v for k, v in e.items() if v > TOL}
+            assert not bad, (slot, src, side, bad)
 
 
 def np_concat(x, y):
