@@ -5,16 +5,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import torch
 from vista_slam_amd import weights as W, _lib
 from vista_slam_amd.sta_frontend import STAFrontend
-cfgs = [(c.split(":")[0], int(c.split(":")[1]), (c.split(":") + ["0"])[2]) for c in (sys.argv[1:] or ["f16x3:0", "f16x3:4"])]   # prec:family[:attn variant]
+cfgs = [(c.split(":")[0], int(c.split(":")[1])) for c in (sys.argv[1:] or ["f16x3h:0", "f16x3:0"])]   # precision:forced tile family
 m = STAFrontend(W.FULL, "cuda:0", precision="f16x3").load_procedural(seed=43)
 B, H, Wd = 8, 384, 512
 imgs = torch.from_numpy(W.synth_images(2 * B, H, Wd, seed=43, tag=0)).cuda()
 for rep in range(2):
-    for prec, v, av in cfgs:
-        if av == "nopair":
-            os.environ["STA_EXPERIMENT_NO_PAIR"] = "1"
-        else:
-            os.environ.pop("STA_EXPERIMENT_NO_PAIR", None)
+    for prec, v in cfgs:
         if prec.startswith("mask"):          # f16x3 with the given layer classes in the f16mx arithmetic (sta_set_mx_mask)
             m.set_precision("f16x3")
             _lib.check(m.lib.sta_set_mx_mask(m._h, int(prec[4:])))
@@ -29,4 +25,4 @@ for rep in range(2):
             m.forward_pair(imgs[:B], imgs[B:])
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 8
-        print(f"pass {rep} {prec}:{v}:{av}: {B / dt:7.2f} pairs/s  {dt * 1e3:7.2f} ms/step", flush=True)
+        print(f"pass {rep} {prec}:{v}: {B / dt:7.2f} pairs/s  {dt * 1e3:7.2f} ms/step", flush=True)

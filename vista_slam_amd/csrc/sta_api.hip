@@ -77,7 +77,6 @@ struct sta_handle {
     int device = 0;
     int prec = STA_PREC_F16X3;
     bool deterministic = false;   // sta_set_deterministic: no split-K (fp32 atomics): bit-reproducible results run to run
-    bool no_pairing = false;  // tests / A-B: launch the decoder's qkv and projk|projv GEMMs separately
     int mx_mask = 0;          // CLS_* bits of the layer classes that run in the f16mx arithmetic (set by the precision mode)
     bool finalized = false;
     std::unordered_map<std::string, Slot> slots;
@@ -651,7 +650,7 @@ static int gemm_qkv_pair(sta_handle* h, const GemmParams& pa_in, const GemmParam
     const bool split = h->prec != STA_PREC_F16;
     auto big = [](const GemmParams& p) { return p.M > 640 && p.N % 128 == 0 && (int64_t)((p.M + 191) / 192) * (p.N / 128) >= 128; };
     if (h->dry) return 0;
-    if (!split || pa.mx || pb.mx || !big(pa) || !big(pb) || pa.K != pb.K || pa.M != pb.M || h->gemm_variant != 0 || h->no_pairing || getenv("STA_EXPERIMENT_NO_PAIR")) {
+    if (!split || pa.mx || pb.mx || !big(pa) || !big(pb) || pa.K != pb.K || pa.M != pb.M || h->gemm_variant != 0) {
         CHK((launch_gemm<A_DENSE, EPI_QKV>(h, pa, st)));
         return launch_gemm<A_DENSE, EPI_QKV>(h, pb, st);
     }
