@@ -63,7 +63,7 @@ int sta_debug_head_final(sta_handle* h, const float* x, const float* w, const fl
 int sta_debug_svd_orthogonalize(sta_handle* h, const float* m, float* r, int B, void* stream);
 
 /* Per-launch record of the timed dominant-kernel family since sta_kernel_timing(h, 1): algorithmic FLOPs, HIP-event
- * duration (ms) and tile family of up to `cap` launches (tools/inmodel_vs_micro.py). */
+ * duration (ms) and tile family of up to `cap` launches (superseded by sta_kernel_timing_dump_shapes). */
 int sta_kernel_timing_dump(sta_handle* h, int cap, double* flops, float* ms, int* variant, int* n_out);
 
 /* The same record for EVERY GEMM / convolution launch after sta_kernel_timing(h, 2) (experiments: per-shape in-model
