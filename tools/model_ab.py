@@ -5,12 +5,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import torch
 from vista_slam_amd import weights as W, _lib
 from vista_slam_amd.sta_frontend import STAFrontend
-cfgs = [(c.split(":")[0], int(c.split(":")[1])) for c in (sys.argv[1:] or ["f16x3h:0", "f16x3:0"])]   # precision:forced tile family
+cfgs = [(c.split(":")[0], int(c.split(":")[1]), (c.split(":") + [""])[2]) for c in (sys.argv[1:] or ["f16x3h:0", "f16x3:0"])]   # precision:forced tile family[:ENVVAR to set]
 m = STAFrontend(W.FULL, "cuda:0", precision="f16x3").load_procedural(seed=43)
 B, H, Wd = 8, 384, 512
 imgs = torch.from_numpy(W.synth_images(2 * B, H, Wd, seed=43, tag=0)).cuda()
 for rep in range(2):
-    for prec, v in cfgs:
+    for prec, v, envv in cfgs:
+        for k in [k for k in os.environ if k.startswith("STA_EXPERIMENT_")]:
+            del os.environ[k]
+        if envv:
+            os.environ["STA_EXPERIMENT_" + envv] = "1"
         if prec.startswith("mask"):          # f16x3 with the given layer classes in the f16mx arithmetic (sta_set_mx_mask)
             m.set_precision("f16x3")
             _lib.check(m.lib.sta_set_mx_mask(m._h, int(prec[4:])))
@@ -25,4 +29,4 @@ for rep in range(2):
             m.forward_pair(imgs[:B], imgs[B:])
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 8
-        print(f"pass {rep} {prec}:{v}: {B / dt:7.2f} pairs/s  {dt * 1e3:7.2f} ms/step", flush=True)
+        print(f"pass {rep} {prec}:{v}:{envv}: {B / dt:7.2f} pairs/s  {dt * 1e3:7.2f} ms/step", flush=True)
