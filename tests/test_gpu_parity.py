@@ -534,7 +534,7 @@ def test_forward_encodes_main_view_once_and_matches_forward_pair(G):
         out = m(views)
     finally:
         m._encode_image = orig
-    assert len(calls) == 3                                   # main once + one per support view
+    assert len(calls) == 2                                   # the main view once + ONE batched call for all support views
     for k, v in enumerate((imgs[1:2], imgs[2:3])):
         mm, ss = m.forward_pair(imgs[0:1], v)
         for key in ("pts3d_pred", "conf", "relative_pose", "relative_pose_conf"):

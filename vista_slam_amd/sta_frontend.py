@@ -308,7 +308,9 @@ class STAFrontend:
         return outs[0], outs[1]
 
     def forward(self, views: dict, loop_num: int = 0):
-        """sta_model.py:247-291: the main view is encoded ONCE (:257) and decoded against every support view."""
+        """sta_model.py:247-291.  The main view is encoded ONCE (:257); the k support views are encoded, decoded against
+        it and run through the heads as ONE batch of k pairs (the reference loops over them; pairs are independent, so the
+        results are the same to rounding)."""
         main_view = views["main_view"]
         support = list(views["neighbor_views"]) + list(views["loop_views"])   # eval: all loop views (sta_model.py:252-255)
         main_res, supp_res = [], []
@@ -316,19 +318,24 @@ class STAFrontend:
             return {"main_views": main_res, "support_views": supp_res}
         img_m = self._f32(main_view["img"])
         B, _c, H, W_ = img_m.shape
-        ts = [[H, W_]] * B
+        k = len(support)
         feat_m, pos_m = self._encode_image(img_m, None, normalize=False)
-        hooks = self.cfg.hooks                      # decoder list indices hooks[k] - 1 (dpt_head.py:112)
+        img_s = torch.cat([self._f32(v["img"]) for v in support], 0)             # [k*B, 3, H, W], support-major
+        assert img_s.shape[0] == k * B and img_s.shape[1:] == img_m.shape[1:], "support views must match the main view's shape"
+        feat_s, pos_s = self._encode_image(img_s, None, normalize=False)
+        feat_mk, pos_mk = feat_m.repeat(k, 1, 1), pos_m.repeat(k, 1, 1)
+        hooks = self.cfg.hooks                      # decoder list indices hooks[i] - 1 (dpt_head.py:112)
         layers = sorted({hk - 1 for hk in hooks[1:]})
-        for v in support:
-            feat_s, pos_s = self._encode_image(v["img"], None, normalize=False)
-            d1, d2 = self._decode_stereo(feat_m, feat_s, pos_m, pos_s, layers=layers)
-            for res, feat, dec in ((main_res, feat_m, d1), (supp_res, feat_s, d2)):
-                toks = [feat] + [None if t is None else t[:, 1:, :] for t in dec]
-                pts = self.head_pts(toks, ts)
-                pose = self.head_pose_s(dec[-1][:, 0, :])
-                res.append({"pts3d_pred": pts["pts3d"], "conf": pts["conf"],
-                            "relative_pose": pose["pose"], "relative_pose_conf": pose["conf"]})
+        d1, d2 = self._decode_stereo(feat_mk, feat_s, pos_mk, pos_s, layers=layers)
+        ts = [[H, W_]] * (k * B)
+        for res, feat, dec in ((main_res, feat_mk, d1), (supp_res, feat_s, d2)):
+            toks = [feat] + [None if t is None else t[:, 1:, :] for t in dec]
+            pts = self.head_pts(toks, ts)
+            pose = self.head_pose_s(dec[-1][:, 0, :])
+            for j in range(k):
+                sl = slice(j * B, (j + 1) * B)
+                res.append({"pts3d_pred": pts["pts3d"][sl], "conf": pts["conf"][sl],
+                            "relative_pose": pose["pose"][sl], "relative_pose_conf": pose["conf"][sl]})
         return {"main_views": main_res, "support_views": supp_res}
 
     __call__ = forward
