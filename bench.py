@@ -383,6 +383,23 @@ def main():
                                    "note": "NOT a parity-qualified mode (no credit claimed): f16 main product + one block-scaled fp8 correction MFMA; "
                                            "holds the reference-architecture goldens at <= 9e-5 but exceeds the 1e-3 bar on two sharpened "
                                            "tiny-config stress sets (1.1e-3 / 5.6e-3), see DESIGN.md section 2"}
+        if world == 1 and args.slices == 1 and not args.no_alt_precision:
+            # the same K steps with the batch split into two slices on internal streams (sta_set_concurrency(2)): a product
+            # mode with identical outputs (tests/test_gpu_parity.py); not the default `value` because per-kernel durations -
+            # and with them the roofline object - are not attributable while two kernels share the chip
+            model.set_concurrency(2)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t1
+            model.set_concurrency(1)
+            res["two_slice_concurrency"] = {"value": round(B * args.steps / dt3, 3), "unit": "pairs/s", "ms_per_step": round(dt3 / args.steps * 1e3, 3),
+                                            "note": "same precision, same inputs, bit-identical per-slice arithmetic; `python bench.py --slices 2` "
+                                                    "times it as the main region"}
         if world == 1 and not args.no_slam_probe:
             res["slam_224_b1"] = slam_probe(model, dev)
         if world == 1 and not args.no_cpu_baseline:
