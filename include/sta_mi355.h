@@ -29,8 +29,11 @@
  *     no host synchronisation inside, so ordering with surrounding torch ops is preserved.
  *   - Return value: 0 on success, negative on error; sta_last_error() returns a thread-local
  *     message.  A handle is not thread-safe; one handle per device.
- *   - Images are NCHW fp32 in [-1,1]; H and W must be multiples of 16 and W >= H
- *     (landscape incl. square; the portrait transpose of utils/misc.py:60 is not supported).
+ *   - Images are NCHW fp32 in [-1,1]; H and W must be multiples of 16.  Portrait frames (H > W) are tokenised row-major
+ *     as they are (PatchEmbedDust3R, patch_embed.py:15-26) and every per-pixel output of this ABI is in IMAGE orientation
+ *     [.., H, W, ..].  The reference's head wrapper returns portrait outputs as transposed VIEWS of exactly that memory
+ *     (`transposed(head(decout, (H, W)))`, utils/misc.py:60-61,81); the Python shim applies the same swapaxes(1, 2), and
+ *     sta_regress_views evaluates the shared intrinsics the way the reference does on those views (see there).
  *   - Token tensors are row-major fp32: encoder [B, N, enc_dim], decoder [B, N+1, dec_dim]
  *     (row 0 of every decoder sequence is the pose token, sta_model.py:206-219).
  */
@@ -175,12 +178,17 @@ int sta_estimate_scale(sta_handle* h, const float* Di, const float* Dj, const fl
  * 171-225: centre crop with an edge margin, cropping.rescale_image_depthmap LANCZOS rescale to cover the resolution
  * - vista_slam/utils/cropping.py:54-81 -, centre crop to the resolution) followed by ImgNorm (ToTensor +
  * Normalize(0.5,0.5)) and ImgGray (ToTensor + Grayscale).  src: one uint8 RGB frame [Hs,Ws,3] on the device.
+ * (res_H, res_W) is the configured resolution (landscape or square, like the reference's `resolution`, which asserts
+ * resolution[0] >= resolution[1]); the OUTPUT size (out_H, out_W) is the resolution, transposed when the first crop is
+ * portrait (crop height > 1.1 x crop width; base_view_graph_dataset.py:200-205) - sta_preprocess_geometry returns it
+ * (host only, no device work) so the caller can size the buffers.  A square crop (0.9 < h/w < 1.1) with a non-square
+ * resolution is an error: the reference draws the orientation from an rng there.
  * Outputs (device, any may be NULL): u8_out [out_H,out_W,3] uint8 = the PIL image the reference hands to its
  * transforms, bit-exact to Pillow's 8-bit LANCZOS resampler (feeds sta_encode_u8hwc directly); rgb_out
- * [3,out_H,out_W] fp32 = value['rgb']; gray_out [out_H,out_W] fp32 = value['gray'].  Landscape / square frames and
- * resolutions only (portrait -> error; the reference transposes the resolution there).  The coefficient tables of one
+ * [3,out_H,out_W] fp32 = value['rgb']; gray_out [out_H,out_W] fp32 = value['gray'].  The coefficient tables of one
  * geometry are cached in the handle; a geometry change synchronises `stream` once. */
-int sta_preprocess_frame(sta_handle* h, const uint8_t* src, int Hs, int Ws, int out_H, int out_W, int w_edge, int h_edge,
+int sta_preprocess_geometry(int Hs, int Ws, int res_H, int res_W, int w_edge, int h_edge, int* out_H, int* out_W);
+int sta_preprocess_frame(sta_handle* h, const uint8_t* src, int Hs, int Ws, int res_H, int res_W, int w_edge, int h_edge,
                          uint8_t* u8_out, float* rgb_out, float* gray_out, void* stream);
 
 /* output step of OnlineSLAM.save_data_all (vista_slam/slam.py:338-421).
@@ -210,7 +218,10 @@ int sta_mat_to_se3(sta_handle* h, const float* poses, int B, float* se3_out, voi
  * compact index s of edge e in the per-accepted-edge outputs, all device:
  *   pts [n_acc,2,H,W,3] (view order [ij, ji] = torch.cat order of slam.py:182), conf [n_acc,2,H,W],
  *   K [n_acc,3,3] (shared over the pair's two views), depth [n_acc,2,H,W].
- * The buffers must be sized for k edges.  k <= 16. */
+ * The buffers must be sized for k edges.  k <= 16.
+ * Portrait frames (H > W): pts / conf / depth stay in image orientation [..,H,W,..]; the reference computes K on the
+ * transposed views its head wrapper returns (utils/misc.py:60-61), i.e. with u = row - H/2 against X, v = col - W/2
+ * against Y and the principal point (H/2, W/2) - K holds exactly that. */
 int sta_regress_views(sta_handle* h, const float* feat_i, const float* const* feat_j, int k,
                       const uint8_t* adjacent, float rel_pose_thres, int H, int W,
                       float* pose, float* pose_conf_host, int* slot_host, int* n_accepted,

@@ -347,6 +347,12 @@ CASES = {
     # error ~100x, so a single one is a noisy judge of a precision policy; the policy must hold all of them
     "stress": [dict(name=f"tiny_48x80_sharp_s{sd}{'_smooth' if sm else ''}", cfg=W.TINY, H=48, W_=80, B=1, qk_gain=4.0, smooth=sm, seed=sd)
                for sd in (44, 45, 46, 47) for sm in (True, False)],
+    # portrait frames (H > W): the default patch embed tokenises them row-major as they are and the head wrapper returns
+    # every per-pixel output TRANSPOSED to landscape ([B, W, H, ...], utils/misc.py:60-61)
+    "portrait": [
+        dict(name="tiny_80x48_b2_portrait", cfg=W.TINY, H=80, W_=48, B=2, taps="light"),
+        dict(name="full_512x384_b1_portrait", cfg=W.FULL, H=512, W_=384, B=1, sub=16),
+    ],
     "full224": [
         dict(name="full_224_b1", cfg=W.FULL, H=224, W_=224, B=1, sub=8),
         # qk_gain 3: peaky attention yet still well conditioned at full depth (reference fp32 vs fp64 on the
@@ -377,6 +383,8 @@ if __name__ == "__main__":
         elif s == "f2":
             gen_f2("f2_tiny_48x64", W.TINY, 48, 64, nview=5)
             gen_f2("f2_full_224", W.FULL, 224, 224, nview=4, sub=8)
+        elif s == "f2portrait":
+            gen_f2("f2_tiny_80x48_portrait", W.TINY, 80, 48, nview=4, tag=22)
         else:
             for c in CASES[s]:
                 run_case(**c)

@@ -29,6 +29,10 @@ CASES = [  # (name, source H, W, target (w, h), tag)
     ("kitti_376x1241_to_512x384", 376, 1241, (512, 384), 3),
     ("upscale_250x330_to_224", 250, 330, (224, 224), 4),
     ("odd_487x651_to_224", 487, 651, (224, 224), 5),
+    # portrait frames: the resolution is transposed (base_view_graph_dataset.py:200-205)
+    ("portrait_640x480_to_512x384", 640, 480, (512, 384), 6),
+    ("portrait_1296x968_to_224", 1296, 968, (224, 224), 7),
+    ("portrait_700x300_to_512x384", 700, 300, (512, 384), 8),
 ]
 
 
@@ -41,6 +45,11 @@ def reference_process(image_np, resolution, w_edge=10, h_edge=10):
     l, t = max(l, w_edge), max(t, h_edge)
     r, b = min(r, Wd - w_edge), min(b, Hd - h_edge)
     image, _, _ = cropping.crop_image_depthmap(image, None, None, (l, t, r, b))
+    W1, H1 = image.size
+    assert resolution[0] >= resolution[1]
+    if H1 > 1.1 * W1:                       # portrait: transposed resolution (:203-205)
+        resolution = resolution[::-1]
+    assert not (0.9 < H1 / W1 < 1.1 and resolution[0] != resolution[1]), "rng branch (:206-209) not covered"
     target = np.array(resolution)
     image, _, _ = cropping.rescale_image_depthmap(image, None, None, target)
     cw, ch = image.size
@@ -56,7 +65,7 @@ def main():
     for name, Hs, Ws, res, tag in CASES:
         src = W.synth_frames_u8(Hs, Ws, seed=43, tag=tag)
         u8 = reference_process(src, res)
-        assert u8.shape == (res[1], res[0], 3) and u8.dtype == np.uint8
+        assert u8.shape in ((res[1], res[0], 3), (res[0], res[1], 3)) and u8.dtype == np.uint8
         # torchvision is absent: ToTensor / Normalize(0.5,0.5) / Grayscale(1) from their definitions, in torch fp32
         t = torch.from_numpy(u8).permute(2, 0, 1).to(torch.float32).div(255)
         rgb = t.clone().sub_(0.5).div_(0.5)

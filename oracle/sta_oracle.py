@@ -260,7 +260,10 @@ def head_pts(cfg, sd, tokens, H, W_):
     o = bilinear_up2(o)
     o = np.maximum(conv2d(o, sd[dp + "head.2.weight"], sd[dp + "head.2.bias"], 1, 1), 0)
     o = conv2d(o, sd[dp + "head.4.weight"], sd[dp + "head.4.bias"])
-    return postprocess(o)
+    pts, conf = postprocess(o)
+    if H > W_:      # portrait: model.head_pts = transpose_to_landscape(head) returns transposed(head(decout, (H, W))) (utils/misc.py:60-61,81)
+        pts, conf = pts.swapaxes(1, 2), conf.swapaxes(1, 2)
+    return pts, conf
 
 
 def forward_pair(cfg, sd, img_a, img_b):

@@ -159,7 +159,10 @@ def head_pts(cfg, sd, tokens, H, W_):
     xyz = fmap[..., :3]
     d = xyz.norm(dim=-1, keepdim=True)
     pts = xyz / d.clip(min=1e-8) * torch.expm1(d)
-    return pts, 1 + fmap[..., 3].exp()
+    conf = 1 + fmap[..., 3].exp()
+    if H > W_:      # portrait: transposed(head(decout, (H, W))) (utils/misc.py:60-61,81)
+        pts, conf = pts.swapaxes(1, 2), conf.swapaxes(1, 2)
+    return pts, conf
 
 
 @torch.no_grad()

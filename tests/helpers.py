@@ -17,6 +17,7 @@ def load_golden(name):
 
 def rel_l2(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
     return float(np.sqrt(((a - b) ** 2).sum()) / max(np.sqrt((b ** 2).sum()), 1e-30))
 
 

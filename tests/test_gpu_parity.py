@@ -66,6 +66,32 @@ def test_full_goldens_default_precision(G, case):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("case", ["tiny_80x48_b2_portrait", "full_512x384_b1_portrait"])
+def test_portrait_goldens_default_precision(G, case):
+    """Portrait frames (H > W): tokenised row-major as they are (PatchEmbedDust3R) and every per-pixel output returned as
+    the transposed view [B,W,H,..] the reference's head wrapper produces (utils/misc.py:60-61,81); the full-size case is
+    the benchmark resolution turned by 90 degrees (what f3 emits for a portrait camera)."""
+    import torch
+    from helpers import load_golden
+    from vista_slam_amd import weights as W
+    r = G.run_golden_case(case, DEFAULT)
+    bad = {k: v for k, v in r.items() if v > TOL}
+    assert not bad, bad
+    g, meta = load_golden(case)
+    H, W_, B = int(meta["H"]), int(meta["W"]), int(meta["B"])
+    assert H > W_
+    m = G.model("tiny" if case.startswith("tiny") else "full", 1.0, DEFAULT, int(meta["seed"]))
+    imgs = torch.from_numpy(W.synth_images(2 * B, H, W_, seed=int(meta["seed"]), tag=0)).cuda()
+    main, supp = m.forward_pair(imgs[:B], imgs[B:])
+    assert tuple(main["pts3d_pred"].shape) == (B, W_, H, 3) and tuple(supp["conf"].shape) == (B, W_, H)
+    out = m({"main_view": {"img": imgs[:B]}, "neighbor_views": [{"img": imgs[B:]}], "loop_views": []})
+    assert tuple(out["main_views"][0]["pts3d_pred"].shape) == (B, W_, H, 3)
+    assert torch.equal(out["support_views"][0]["conf"], supp["conf"]) or \
+        float((out["support_views"][0]["conf"] - supp["conf"]).abs().max() / supp["conf"].abs().max()) < 1e-5
+    if case.startswith("full"):
+        G.drop_models()
+
+
 def test_full_sharp_attention_golden(G):
     """Peaky-attention weight set: a wrong RoPE/softmax cannot hide under the tolerance."""
     G.drop_models()
@@ -129,7 +155,7 @@ def test_error_paths(G):
     with pytest.raises(AssertionError):
         m._encode_image(torch.zeros(1, 3, 30, 32, device="cuda:0"), None, normalize=False)
     with pytest.raises(AssertionError):
-        m.forward_pair(torch.zeros(1, 3, 64, 32, device="cuda:0"), torch.zeros(1, 3, 64, 32, device="cuda:0"))
+        m.forward_pair(torch.zeros(1, 3, 64, 40, device="cuda:0"), torch.zeros(1, 3, 64, 40, device="cuda:0"))
     fresh = STAFrontend(W.TINY, "cuda:0")
     with pytest.raises(_lib.StaError, match="unexpected key"):
         fresh._load_one("not.a.key", np.zeros(3, np.float32))
@@ -362,8 +388,14 @@ def test_input_step_f3_vs_oracle_random_geometries_and_encoder_handoff(G):
     fb, _ = m._encode_image(out["rgb"][None], None, normalize=False)
     torch.cuda.synchronize()
     assert rel_l2(fa.cpu().numpy(), fb.cpu().numpy()) < 2e-6
-    with pytest.raises(RuntimeError, match="portrait"):
-        process_image(m, W.synth_frames_u8(300, 200, seed=43, tag=71), (64, 48))
+    for Hs, Ws, res in ((300, 200, (64, 48)), (333, 290, (80, 80)), (512, 200, (96, 32))):     # portrait frames: transposed resolution
+        srcp = W.synth_frames_u8(Hs, Ws, seed=43, tag=71 + Hs)
+        want = P.process_image(srcp, res[0], res[1])
+        out = process_image(m, srcp, res)
+        torch.cuda.synchronize()
+        assert tuple(out["u8"].shape) == (res[0], res[1], 3) and tuple(out["rgb"].shape) == (3, res[0], res[1])
+        assert np.array_equal(out["u8"].cpu().numpy(), want["u8"]) and np.array_equal(out["rgb"].cpu().numpy(), want["rgb"])
+        assert np.array_equal(out["gray"].cpu().numpy(), want["gray"])
     with pytest.raises(RuntimeError, match="square frame"):
         process_image(m, W.synth_frames_u8(200, 200, seed=43, tag=72), (64, 48))
     with pytest.raises(RuntimeError, match="landscape or square"):
@@ -471,12 +503,13 @@ def test_keyframe_scheduler_f2_matches_sequential_edges(G, cfg, H, Wd, nview):
     assert 0 < n_rej < len(js)
 
 
-@pytest.mark.parametrize("name,cfg", [("f2_tiny_48x64", "tiny"), ("f2_full_224", "full")])
+@pytest.mark.parametrize("name,cfg", [("f2_tiny_48x64", "tiny"), ("f2_tiny_80x48_portrait", "tiny"), ("f2_full_224", "full")])
 def test_keyframe_scheduler_f2_vs_reference_golden(G, name, cfg):
     """f2 pinned by the reference: sta_regress_views (one batched call for all edges of the keyframe) and the per-edge
     split calls vs tests/golden/f2_*.npz = regress_two_views (slam.py:153-189) replayed on the reference model with the
     reference's estimate_intrinsic_from_pts3d (oracle/gen_golden.py gen_f2): accepted / rejected edges and the
-    adjacent-edge exemption of slam.py:169."""
+    adjacent-edge exemption of slam.py:169.  The portrait case: maps come back as the transposed views [2,W,H] the
+    reference works on, and K is what its estimate_intrinsic_from_pts3d derives from those views."""
     import numpy as np
     import torch
     from helpers import load_golden, rel_l2, max_rel

@@ -56,7 +56,8 @@ def test_postprocess(ops):
 
 
 @pytest.mark.parametrize("case", ["tiny_32x32_b1", "tiny_48x64_b2", "tiny_48x64_b2_sharp", "tiny_48x80_smooth_sharp",
-                                  "tiny_48x80_sharp_s44_smooth", "tiny_48x80_sharp_s45", "tiny_48x80_sharp_s46_smooth", "tiny_48x80_sharp_s47"])
+                                  "tiny_48x80_sharp_s44_smooth", "tiny_48x80_sharp_s45", "tiny_48x80_sharp_s46_smooth", "tiny_48x80_sharp_s47",
+                                  "tiny_80x48_b2_portrait"])
 def test_forward_vs_reference_golden(case):
     g, meta = load_golden(case)
     H, W_, B = int(meta["H"]), int(meta["W"]), int(meta["B"])
@@ -112,10 +113,12 @@ def _f2_case(name, cfg):
     return g, meta, H, W_, nview, sd, imgs
 
 
-def test_regress_two_views_f2_vs_reference_golden():
+@pytest.mark.parametrize("case", ["f2_tiny_48x64", "f2_tiny_80x48_portrait"])
+def test_regress_two_views_f2_vs_reference_golden(case):
     """oracle.regress_two_views (restating slam.py:153-189) vs the golden produced by replaying that method
-    on the reference model + the reference's slam_utils: accepted and rejected edges, the adjacent-edge exemption."""
-    g, meta, H, W_, nview, sd, imgs = _f2_case("f2_tiny_48x64", W.TINY)
+    on the reference model + the reference's slam_utils: accepted and rejected edges, the adjacent-edge exemption.
+    The portrait case holds transposed maps [2,W,H] and the intrinsics the reference derives from them."""
+    g, meta, H, W_, nview, sd, imgs = _f2_case(case, W.TINY)
     feats = [O.encode_image(W.TINY, sd, imgs[v:v + 1]) for v in range(nview)]
     i = nview - 1
     acc = g["accepted"]
@@ -142,7 +145,7 @@ def test_encode_image_normalize_true_vs_reference_golden():
     assert rel_l2(x, g["enc_feat_norm"]) < TOL
 
 
-@pytest.mark.parametrize("case", ["tiny_32x32_b1", "tiny_48x64_b2_sharp"])
+@pytest.mark.parametrize("case", ["tiny_32x32_b1", "tiny_48x64_b2_sharp", "tiny_80x48_b2_portrait"])
 def test_torch_cpu_port_vs_reference_golden(case):
     """oracle/torch_cpu.py (the torch-CPU re-expression bench.py times as the CPU baseline) vs the reference goldens."""
     from oracle import torch_cpu as T

@@ -13,7 +13,7 @@ GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "pre_*
 
 
 def test_goldens_present():
-    assert len(GOLD) >= 6
+    assert len(GOLD) >= 9
 
 
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[4:-4] for p in GOLD])
@@ -33,15 +33,19 @@ def test_oracle_is_bit_exact_to_pillow_and_reference_cropping(path):
 
 def test_geometry_tum_case():
     """640x480 with 10 px edges -> 620x460 crop -> 301x224 rescale -> columns 38..262 (np.round half-to-even)."""
-    crop, (rw, rh), (l2, t2) = P.crop_resize_geometry(480, 640, 224, 224, 10, 10)
-    assert crop == (10, 10, 630, 470) and (rw, rh) == (301, 224) and (l2, t2) == (38, 0)
+    crop, (rw, rh), (l2, t2), out = P.crop_resize_geometry(480, 640, 224, 224, 10, 10)
+    assert crop == (10, 10, 630, 470) and (rw, rh) == (301, 224) and (l2, t2) == (38, 0) and out == (224, 224)
 
 
-def test_portrait_and_ambiguous_square_are_rejected():
-    with pytest.raises(AssertionError):
-        P.crop_resize_geometry(640, 480, 224, 224, 10, 10)
+def test_portrait_transposes_the_resolution_and_ambiguous_square_is_rejected():
+    """base_view_graph_dataset.py:200-209: a portrait crop swaps (w, h); a square crop with a non-square resolution draws
+    the orientation from an rng in the reference and is refused here; a portrait RESOLUTION is refused like the reference's assert."""
+    assert P.crop_resize_geometry(640, 480, 512, 384, 10, 10)[3] == (384, 512)
+    assert P.crop_resize_geometry(640, 480, 224, 224, 10, 10)[3] == (224, 224)
     with pytest.raises(AssertionError):
         P.crop_resize_geometry(500, 500, 512, 384, 10, 10)
+    with pytest.raises(AssertionError):
+        P.crop_resize_geometry(480, 640, 384, 512, 10, 10)
 
 
 def test_identity_size_is_identity():

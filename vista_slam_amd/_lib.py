@@ -50,6 +50,7 @@ SIGNATURES = {
                                     C.POINTER(_vp), _vp]),
     "sta_estimate_intrinsics": (_i, [_vp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _vp]),
     "sta_estimate_scale": (_i, [_vp, _fp, _fp, _fp, _fp, _i64, _fp, _vp]),
+    "sta_preprocess_geometry": (_i, [_i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
     "sta_preprocess_frame": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _vp]),
     "sta_world_pointcloud": (_i, [_vp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _f, _fp, _fp, _fp, C.POINTER(_i64), _vp]),
     "sta_mat_to_se3": (_i, [_vp, _fp, _i, _fp, _vp]),

@@ -431,8 +431,10 @@ __global__ __launch_bounds__(256) void pose_final_kernel(const PoseParams p, con
 //  * depths = pts[...,2] (slam.py:185) and conf.mean() per image (pose_graph.py:37).
 // HBM-bound (16 B/pixel in, 4 B out).  Partial sums are fp64 per block (deterministic two-stage
 // reduction: block partials -> finalise kernel), which is at least as accurate as torch's fp32 sums.
+// tr != 0: the maps are portrait frames in image orientation [H,W] and the reference would see them TRANSPOSED
+// ([W,H] views, utils/misc.py:60-61,81): u = row - H/2 pairs with X, v = col - W/2 with Y, principal point (H/2, W/2).
 __global__ __launch_bounds__(256) void intrinsics_partial_kernel(const float* pts, const float* conf, int B, int H, int W,
-                                                                 float* depth, double* partial /*[B][nblk][5]*/, int nblk) {
+                                                                 float* depth, double* partial /*[B][nblk][5]*/, int nblk, int tr) {
     const int b = blockIdx.y;
     const int64_t hw = (int64_t)H * W;
     const float cx = W / 2.0f, cy = H / 2.0f;
@@ -446,7 +448,8 @@ __global__ __launch_bounds__(256) void intrinsics_partial_kernel(const float* pt
         float xz = X / Z, yz = Y / Z;
         if (!isfinite(xz)) xz = 0.f;
         if (!isfinite(yz)) yz = 0.f;
-        const float u = (float)(i % W) - cx, v = (float)(i / W) - cy;
+        const float col = (float)(i % W) - cx, row = (float)(i / W) - cy;
+        const float u = tr ? row : col, v = tr ? col : row;
         s[0] += (double)(w * xz * u); s[1] += (double)(w * xz * xz);
         s[2] += (double)(w * yz * v); s[3] += (double)(w * yz * yz);
         s[4] += (double)c;
@@ -468,8 +471,9 @@ __global__ __launch_bounds__(256) void intrinsics_partial_kernel(const float* pt
 // shared: 0 = one K per image, 1 = one K over all B images, g >= 2 = one K per group of g consecutive images
 // (g = 2: the two views of a pair, slam.py:184 shared_intrinsic=True) -> K [B/g,3,3].
 __global__ void intrinsics_final_kernel(const double* partial, int B, int nblk, int H, int W, int shared,
-                                        float* K /*[3,3] or [B,3,3] or [B/g,3,3]*/, float* conf_mean /*[B] or null*/) {
+                                        float* K /*[3,3] or [B,3,3] or [B/g,3,3]*/, float* conf_mean /*[B] or null*/, int tr) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float pcx = (tr ? H : W) / 2.0f, pcy = (tr ? W : H) / 2.0f;
     double tot[5] = {0, 0, 0, 0, 0};
     for (int b = 0; b < B; ++b) {
         double s[5] = {0, 0, 0, 0, 0};
@@ -478,21 +482,21 @@ __global__ void intrinsics_final_kernel(const double* partial, int B, int nblk, 
         for (int k = 0; k < 5; ++k) tot[k] += s[k];
         if (shared >= 2 && (b + 1) % shared == 0) {
             float* Kb = K + (b / shared) * 9;
-            Kb[0] = (float)(tot[0] / tot[1]); Kb[1] = 0.f; Kb[2] = W / 2.0f;
-            Kb[3] = 0.f; Kb[4] = (float)(tot[2] / tot[3]); Kb[5] = H / 2.0f;
+            Kb[0] = (float)(tot[0] / tot[1]); Kb[1] = 0.f; Kb[2] = pcx;
+            Kb[3] = 0.f; Kb[4] = (float)(tot[2] / tot[3]); Kb[5] = pcy;
             Kb[6] = 0.f; Kb[7] = 0.f; Kb[8] = 1.f;
             for (int k = 0; k < 5; ++k) tot[k] = 0;
         }
         if (!shared) {
             float* Kb = K + b * 9;
-            Kb[0] = (float)(s[0] / s[1]); Kb[1] = 0.f; Kb[2] = W / 2.0f;
-            Kb[3] = 0.f; Kb[4] = (float)(s[2] / s[3]); Kb[5] = H / 2.0f;
+            Kb[0] = (float)(s[0] / s[1]); Kb[1] = 0.f; Kb[2] = pcx;
+            Kb[3] = 0.f; Kb[4] = (float)(s[2] / s[3]); Kb[5] = pcy;
             Kb[6] = 0.f; Kb[7] = 0.f; Kb[8] = 1.f;
         }
     }
     if (shared == 1) {
-        K[0] = (float)(tot[0] / tot[1]); K[1] = 0.f; K[2] = W / 2.0f;
-        K[3] = 0.f; K[4] = (float)(tot[2] / tot[3]); K[5] = H / 2.0f;
+        K[0] = (float)(tot[0] / tot[1]); K[1] = 0.f; K[2] = pcx;
+        K[3] = 0.f; K[4] = (float)(tot[2] / tot[3]); K[5] = pcy;
         K[6] = 0.f; K[7] = 0.f; K[8] = 1.f;
     }
 }

@@ -1033,7 +1033,6 @@ static int check_ready(sta_handle* h, int B, int H, int W) {
     REQUIRE(h->finalized, "weights not finalized (call sta_finalize_weights)");
     REQUIRE(B > 0, "batch must be positive");
     REQUIRE(H % 16 == 0 && W % 16 == 0 && H > 0 && W > 0, "Input image size (%dx%d) is not a multiple of patch size (16)", H, W);
-    REQUIRE(W >= H, "img should be in landscape mode, but got W=%d H=%d", W, H);
     return 0;
 }
 

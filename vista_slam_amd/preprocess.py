@@ -8,6 +8,8 @@ ImgGray.  `process_image` here does the same on the GPU in two fused kernels of 
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -24,11 +26,14 @@ def process_image(frontend: STAFrontend, rgb_image, resolution=(224, 224), w_edg
     assert rgb_image.dtype == torch.uint8 and rgb_image.dim() == 3 and rgb_image.shape[2] == 3, "expected [H,W,3] uint8"
     src = rgb_image.to(frontend.device).contiguous()
     Hs, Ws, _ = src.shape
-    ow, oh = int(resolution[0]), int(resolution[1])
+    rw, rh = int(resolution[0]), int(resolution[1])
+    oh_, ow_ = C.c_int(0), C.c_int(0)     # the resolution, transposed for a portrait frame (base_view_graph_dataset.py:200-205)
+    _lib.check(frontend.lib.sta_preprocess_geometry(Hs, Ws, rh, rw, int(w_edge), int(h_edge), C.byref(oh_), C.byref(ow_)))
+    oh, ow = oh_.value, ow_.value
     u8 = torch.empty(oh, ow, 3, device=frontend.device, dtype=torch.uint8)
     rgb = torch.empty(3, oh, ow, device=frontend.device, dtype=torch.float32)
     gray = torch.empty(1, oh, ow, device=frontend.device, dtype=torch.float32)
-    _lib.check(frontend.lib.sta_preprocess_frame(frontend._h, src.data_ptr(), Hs, Ws, oh, ow, int(w_edge), int(h_edge),
+    _lib.check(frontend.lib.sta_preprocess_frame(frontend._h, src.data_ptr(), Hs, Ws, rh, rw, int(w_edge), int(h_edge),
                                                  u8.data_ptr(), rgb.data_ptr(), gray.data_ptr(), frontend._stream()))
     out = {"rgb": rgb, "gray": gray, "u8": u8}
     if img_name is not None:

@@ -59,6 +59,8 @@ def regress_views(frontend: STAFrontend, enc_feat_i: torch.Tensor, enc_feats_j: 
     _lib.check(frontend.lib.sta_regress_views(frontend._h, fi.data_ptr(), ptrs, k, adj, float(rel_pose_thres), H, W,
                                               pose.data_ptr(), pconf, slot, C.byref(nacc), pts.data_ptr(), conf.data_ptr(),
                                               Kt.data_ptr(), depth.data_ptr(), frontend._stream()))
+    if H > W:     # portrait: the reference sees transposed views of the same memory (utils/misc.py:60-61,81)
+        pts, conf, depth = pts.swapaxes(2, 3), conf.swapaxes(2, 3), depth.swapaxes(2, 3)
     out = []
     for e in range(k):
         s = slot[e]

@@ -156,7 +156,6 @@ class STAFrontend:
     def _check_hw(H: int, W_: int, P: int = 16):
         assert H % P == 0, f"Input image height ({H}) is not a multiple of patch size ({P})."
         assert W_ % P == 0, f"Input image width ({W_}) is not a multiple of patch size ({P})."
-        assert W_ >= H, f"img should be in landscape mode, but got W={W_} H={H}"
 
     # ------------------------------------------------------------------ split entry points
     def _encode_image(self, image: torch.Tensor, true_shape=None, normalize: bool = True):
@@ -247,9 +246,21 @@ class STAFrontend:
         _lib.check(self.lib.sta_head_pts(self._h, enc.data_ptr(), bs(enc), hk[0].data_ptr(), bs(hk[0]),
                                          hk[1].data_ptr(), bs(hk[1]), hk[2].data_ptr(), bs(hk[2]),
                                          B, H, W_, pts.data_ptr(), conf.data_ptr(), self._stream()))
+        if H > W_:      # portrait: the reference's head wrapper returns transposed views (utils/misc.py:60-61,81)
+            pts, conf = pts.swapaxes(1, 2), conf.swapaxes(1, 2)
         return {"pts3d": pts, "conf": conf}
 
     # ------------------------------------------------------------------ monolithic paths
+    @staticmethod
+    def _landscape_views(outs, H: int, W_: int):
+        """Portrait frames: per-pixel outputs as transposed views [B,W,H,..] of the image-orientation buffers, exactly what
+        `transpose_to_landscape(head)` returns in the reference (utils/misc.py:60-61,81)."""
+        if H > W_:
+            for o in outs:
+                o["pts3d_pred"] = o["pts3d_pred"].swapaxes(1, 2)
+                o["conf"] = o["conf"].swapaxes(1, 2)
+        return outs[0], outs[1]
+
     def forward_pair(self, img_a: torch.Tensor, img_b: torch.Tensor):
         """Batched two-view forward == forward({'main_view':a,'neighbor_views':[b],'loop_views':[]}).
         Returns (main, support) dicts with pts3d_pred, conf, relative_pose, relative_pose_conf."""
@@ -271,7 +282,7 @@ class STAFrontend:
                 a[k] = o[key].data_ptr()
         _lib.check(self.lib.sta_forward_pair(self._h, img_a.data_ptr(), img_b.data_ptr(), B, H, W_,
                                              arrs[0], arrs[1], arrs[2], arrs[3], self._stream()))
-        return outs[0], outs[1]
+        return self._landscape_views(outs, H, W_)
 
     def encode_u8hwc(self, image_u8: torch.Tensor):
         """Extension: encode uint8 HWC camera frames [B,H,W,3] directly; the reference
@@ -305,7 +316,7 @@ class STAFrontend:
                 arr[k] = o[key].data_ptr()
         _lib.check(self.lib.sta_forward_pair_u8hwc(self._h, a.data_ptr(), b.data_ptr(), B, H, W_,
                                                    arrs[0], arrs[1], arrs[2], arrs[3], self._stream()))
-        return outs[0], outs[1]
+        return self._landscape_views(outs, H, W_)
 
     def forward(self, views: dict, loop_num: int = 0):
         """sta_model.py:247-291.  The main view is encoded ONCE (:257); the k support views are encoded, decoded against
