@@ -1,6 +1,7 @@
 """Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls, total/avg/min/max duration.
 
     python tools/rocpd_stats.py gpurun_out/prof1/*/*.db > profiles/r01_kernel_stats.txt
+    python tools/rocpd_stats.py --tail N gpurun_out/prof1/*/*.db     # only the last N dispatches + the idle time between them
 """
 import re
 import sqlite3
@@ -16,8 +17,25 @@ def short(name):
 
 def main(paths):
     by_grid = "--by-grid" in paths            # split every kernel by its launch grid (one row per GEMM shape)
+    tail = int(paths[paths.index("--tail") + 1]) if "--tail" in paths else 0
+    if tail:
+        del paths[paths.index("--tail"):paths.index("--tail") + 2]
     paths = [p for p in paths if not p.startswith("--")]
     rows = {}
+    if tail:          # timeline of the last `tail` dispatches: busy time, idle gaps (start[i+1] - end[i] > 0), span
+        db = sqlite3.connect(paths[0])
+        cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+        namecol = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+        ev = sorted(db.execute(f"select start, end, {namecol} from kernels"))[-tail:]
+        busy = sum(e - s for s, e, _ in ev) / 1e3
+        gaps = [max(0, ev[i + 1][0] - ev[i][1]) / 1e3 for i in range(len(ev) - 1)]
+        span = (ev[-1][1] - ev[0][0]) / 1e3
+        print(f"last {len(ev)} dispatches: span {span:.1f} us, sum of kernel durations {busy:.1f} us, idle between kernels {sum(gaps):.1f} us "
+              f"({len([g for g in gaps if g > 0])} gaps, median {sorted(gaps)[len(gaps) // 2]:.2f} us, max {max(gaps):.1f} us)")
+        for s_, e_, n_ in ev:
+            r = rows.setdefault(short(n_)[:88], [0, 0.0, 1e30, 0.0]); d = (e_ - s_) / 1e3
+            r[0] += 1; r[1] += d; r[2] = min(r[2], d); r[3] = max(r[3], d)
+        paths = []
     for p in paths:
         db = sqlite3.connect(p)
         cols = [r[1] for r in db.execute("pragma table_info(kernels)")]

@@ -753,13 +753,14 @@ __global__ void mat_to_se3_kernel(const float* pose, int B, float* out) {
 // summed fp32 partials into skbuf [M,N]; this applies bias, activation and the residual planes exactly like
 // epilogue_tile<EPI_F16> and writes the blocked output planes.  One thread = 4 consecutive columns of one row.
 template <bool SPLIT>
-__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* skbuf, const float* bias, int M, int N, int act,
+__global__ __launch_bounds__(256) void splitk_finish_kernel(float* skbuf, const float* bias, int M, int N, int act,
                                                             const f16* R1, const f16* R2, f16* C, int64_t c_rp, int r_mx, int c_mx) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int n4 = N >> 2;
     if (i >= (int64_t)M * n4) return;
     const int row = (int)(i / n4), col = (int)(i - (int64_t)row * n4) * 4;
     const float4 a = *reinterpret_cast<const float4*>(skbuf + (size_t)row * N + col);
+    *reinterpret_cast<float4*>(skbuf + (size_t)row * N + col) = make_float4(0.f, 0.f, 0.f, 0.f);    // leave the slot zeroed for the next GEMM
     float v[4] = {a.x, a.y, a.z, a.w};
     const size_t o = blk_off<SPLIT>(row, col, c_rp);
     H4 oh, ol;
