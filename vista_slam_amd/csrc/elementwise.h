@@ -15,7 +15,48 @@ struct LnParams {
     const float* g2; const float* b2; f16* o2_hi; f16* o2_lo;   // optional (g2 == nullptr)
     float* o32; int ldo32;                                       // optional fp32 output with set 1
     int mx;                                                      // planes in the f16mx row format (sta_common.h)
+    // optional first half of a slab split-K residual GEMM (GemmParams::slab): x[row] += sum_s slab[s][row]; x is rewritten,
+    // then normalised as usual (g1 == nullptr: only the add)
+    const float* slab; int nslab; float* xw;
 };
+
+// normalised values n[4] of columns idx..idx+3 of `row` -> affine set 1 (fp32 copy and / or planes) and optional set 2
+template <bool SPLIT>
+__device__ __forceinline__ void ln_store4(const LnParams& p, int row, int idx, const float n[4]) {
+    {
+        float4 g = *reinterpret_cast<const float4*>(p.g1 + idx);
+        float4 b = *reinterpret_cast<const float4*>(p.b1 + idx);
+        float y[4] = {n[0] * g.x + b.x, n[1] * g.y + b.y, n[2] * g.z + b.z, n[3] * g.w + b.w};
+        if (p.o32) *reinterpret_cast<float4*>(p.o32 + (size_t)row * p.ldo32 + idx) = make_float4(y[0], y[1], y[2], y[3]);
+        if (p.o1_hi) {
+            const size_t o = blk_off<SPLIT>(row, idx, p.M);
+            if (SPLIT && p.mx) {
+                store_mx4(p.o1_hi, o, split_mx4<false>(y));
+            } else {
+                H4 h, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e]); else h.e[e] = to_f16_sat(y[e]); }
+                *reinterpret_cast<uint2*>(p.o1_hi + o) = h.u;
+                if (SPLIT) *reinterpret_cast<uint2*>(p.o1_hi + o + 32) = l.u;
+            }
+        }
+    }
+    if (p.g2) {
+        float4 g = *reinterpret_cast<const float4*>(p.g2 + idx);
+        float4 b = *reinterpret_cast<const float4*>(p.b2 + idx);
+        float y[4] = {n[0] * g.x + b.x, n[1] * g.y + b.y, n[2] * g.z + b.z, n[3] * g.w + b.w};
+        const size_t o = blk_off<SPLIT>(row, idx, p.M);
+        if (SPLIT && p.mx) {
+            store_mx4(p.o2_hi, o, split_mx4<false>(y));
+        } else {
+            H4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e]); else h.e[e] = to_f16_sat(y[e]); }
+            *reinterpret_cast<uint2*>(p.o2_hi + o) = h.u;
+            if (SPLIT) *reinterpret_cast<uint2*>(p.o2_hi + o + 32) = l.u;
+        }
+    }
+}
 
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
@@ -49,40 +90,43 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
         int idx = (i * 64 + lane) * 4;
         if (idx < p.C) {
             float n[4] = {(v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd};
-            {
-                float4 g = *reinterpret_cast<const float4*>(p.g1 + idx);
-                float4 b = *reinterpret_cast<const float4*>(p.b1 + idx);
-                float y[4] = {n[0] * g.x + b.x, n[1] * g.y + b.y, n[2] * g.z + b.z, n[3] * g.w + b.w};
-                if (p.o32) *reinterpret_cast<float4*>(p.o32 + (size_t)row * p.ldo32 + idx) = make_float4(y[0], y[1], y[2], y[3]);
-                if (p.o1_hi) {
-                    const size_t o = blk_off<SPLIT>(row, idx, p.M);
-                    if (SPLIT && p.mx) {
-                        store_mx4(p.o1_hi, o, split_mx4<false>(y));
-                    } else {
-                        H4 h, l;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e]); else h.e[e] = to_f16_sat(y[e]); }
-                        *reinterpret_cast<uint2*>(p.o1_hi + o) = h.u;
-                        if (SPLIT) *reinterpret_cast<uint2*>(p.o1_hi + o + 32) = l.u;
-                    }
-                }
-            }
-            if (p.g2) {
-                float4 g = *reinterpret_cast<const float4*>(p.g2 + idx);
-                float4 b = *reinterpret_cast<const float4*>(p.b2 + idx);
-                float y[4] = {n[0] * g.x + b.x, n[1] * g.y + b.y, n[2] * g.z + b.z, n[3] * g.w + b.w};
-                const size_t o = blk_off<SPLIT>(row, idx, p.M);
-                if (SPLIT && p.mx) {
-                    store_mx4(p.o2_hi, o, split_mx4<false>(y));
-                } else {
-                    H4 h, l;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e]); else h.e[e] = to_f16_sat(y[e]); }
-                    *reinterpret_cast<uint2*>(p.o2_hi + o) = h.u;
-                    if (SPLIT) *reinterpret_cast<uint2*>(p.o2_hi + o + 32) = l.u;
-                }
-            }
+            ln_store4<SPLIT>(p, row, idx, n);
         }
+    }
+}
+
+// Second half of a slab split-K residual GEMM (GemmParams::slab) + the LayerNorm that follows it (small-M regime):
+// x[row] += sum_s slab[s][row] (slice 0 carries the bias), x is rewritten, then normalised like ln_kernel (g1 == nullptr:
+// only the add).  One block per row, one float4 per thread (C <= 1024): 1 + nslab independent loads per thread.
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void resid_ln_kernel(const LnParams p) {
+    const int row = blockIdx.x, idx = threadIdx.x * 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool on = idx < p.C;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on) {
+        v = *reinterpret_cast<const float4*>(p.x + (size_t)row * p.ldx + idx);
+        for (int s = 0; s < p.nslab; ++s) {
+            const float4 a = *reinterpret_cast<const float4*>(p.slab + ((size_t)s * p.M + row) * p.C + idx);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        *reinterpret_cast<float4*>(p.xw + (size_t)row * p.ldx + idx) = v;
+    }
+    if (!p.g1) return;
+    __shared__ float red[2][4];
+    float sum = wave_sum((v.x + v.y) + (v.z + v.w));
+    if (lane == 0) red[0][wave] = sum;
+    __syncthreads();
+    const float mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)p.C;
+    float sq = 0.f;
+    if (on) { float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean; sq = (a * a + b * b) + (c * c + d * d); }
+    sq = wave_sum(sq);
+    if (lane == 0) red[1][wave] = sq;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)p.C + p.eps);
+    if (on) {
+        float n[4] = {(v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd};
+        ln_store4<SPLIT>(p, row, idx, n);
     }
 }
 
@@ -749,18 +793,21 @@ __global__ void mat_to_se3_kernel(const float* pose, int B, float* out) {
     o[0] = P[3]; o[1] = P[7]; o[2] = P[11]; o[3] = qx * nrm; o[4] = qy * nrm; o[5] = qz * nrm; o[6] = qw * nrm;
 }
 
-// Second half of a split-K GEMM / conv with the fp16-plane epilogue (small SLAM-scale grids): the K slices atomically
-// summed fp32 partials into skbuf [M,N]; this applies bias, activation and the residual planes exactly like
+// Second half of a split-K GEMM / conv with the fp16-plane epilogue (small SLAM-scale grids): every K slice stored its
+// fp32 partial tile to its own slab skbuf[s][M,N] (no atomics, fixed summation order); this sums them, applies bias, activation and the residual planes exactly like
 // epilogue_tile<EPI_F16> and writes the blocked output planes.  One thread = 4 consecutive columns of one row.
 template <bool SPLIT>
-__global__ __launch_bounds__(256) void splitk_finish_kernel(float* skbuf, const float* bias, int M, int N, int act,
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* skbuf, int ks, const float* bias, int M, int N, int act,
                                                             const f16* R1, const f16* R2, f16* C, int64_t c_rp, int r_mx, int c_mx) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int n4 = N >> 2;
     if (i >= (int64_t)M * n4) return;
     const int row = (int)(i / n4), col = (int)(i - (int64_t)row * n4) * 4;
-    const float4 a = *reinterpret_cast<const float4*>(skbuf + (size_t)row * N + col);
-    *reinterpret_cast<float4*>(skbuf + (size_t)row * N + col) = make_float4(0.f, 0.f, 0.f, 0.f);    // leave the slot zeroed for the next GEMM
+    float4 a = *reinterpret_cast<const float4*>(skbuf + (size_t)row * N + col);
+    for (int s = 1; s < ks; ++s) {
+        const float4 b = *reinterpret_cast<const float4*>(skbuf + ((size_t)s * M + row) * N + col);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
     float v[4] = {a.x, a.y, a.z, a.w};
     const size_t o = blk_off<SPLIT>(row, col, c_rp);
     H4 oh, ol;

@@ -42,13 +42,17 @@ struct GemmParams {
     int rows_in, rows_out, row_off;                      // out_row = (m/rows_in)*rows_out + row_off + m%rows_in
     int ksplit;                                          // >1: split-K, every slice atomically adds into C32 (which already
                                                          //     holds the residual); bias is added by slice 0 only
+    float* slab = nullptr;                               // split-K without atomics: slice s stores its partial tile (slice 0 with
+                                                         //     the bias) to slab[s][M][N]; ln_kernel adds the slices to the residual
+                                                         //     stream and applies the LayerNorm that follows (small-M regime)
     // ---- EPI_F16
     f16* C_hi; f16* C_lo; int ldc16; int act;            // blocked output planes with c_rp rows (ldc16 unused)
     int c_mx;                                            // EPI_F16 / EPI_CONVT output in the f16mx row format (consumer = f16mx GEMM)
     int r_mx;                                            // residual planes R1 / R2 are f16mx rows
     int64_t c_rp;
-    float* skbuf = nullptr;                              // EPI_F16 split-K: fp32 partial sums [M,N] (zeroed); splitk_finish_kernel
-                                                         //     applies bias / activation / residual planes and writes the planes
+    float* skbuf = nullptr;                              // EPI_F16 split-K: fp32 partial tiles [ksplit][M,N], one slab per K slice (no
+                                                         //     atomics); splitk_finish_kernel sums them, applies bias / activation /
+                                                         //     residual planes and writes the planes
     const f16* R1_hi; const f16* R1_lo; const f16* R2_hi; const f16* R2_lo;
     // ---- EPI_QKV
     f16* Q_hi; f16* Q_lo; f16* K_hi; f16* K_lo; f16* Vt_hi; f16* Vt_lo;
@@ -167,7 +171,8 @@ __device__ __forceinline__ void epilogue_qkv_tile(const GemmParams& p, const flo
 // of 64, so segment, head and the RoPE half (y for d<32, x for d>=32) are wave-uniform.
 template <bool SPLIT, int EPI>
 __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx16& acc, int row0, int col, int lane,
-                                              bool first_slice = true) {
+                                              int kslice = 0) {
+    const bool first_slice = kslice == 0;
     if (EPI == EPI_QKV) { epilogue_qkv_tile<SPLIT>(p, acc, row0, col, lane); return; }
     const int lhi = lane >> 5;
     const bool col_ok = col < p.N;
@@ -206,7 +211,9 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
             if (ok) {
                 int orow = row;
                 if (p.rows_in > 0) orow = (row / p.rows_in) * p.rows_out + p.row_off + row % p.rows_in;
-                if (p.ksplit > 1) {
+                if (p.ksplit > 1 && p.slab) {
+                    p.slab[((size_t)kslice * p.M + row) * p.N + col] = v;
+                } else if (p.ksplit > 1) {
                     unsafeAtomicAdd(p.C32 + (size_t)orow * p.ldc + col, v);       // hardware global_atomic_add_f32
                 } else {
                     if (p.resid) v += p.resid[(size_t)orow * p.ldr + col];
@@ -223,7 +230,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
             }
         } else if (EPI == EPI_F16) {
             if (ok && p.ksplit > 1) {
-                unsafeAtomicAdd(p.skbuf + (size_t)row * p.N + col, acc[r]);
+                p.skbuf[((size_t)kslice * p.M + row) * p.N + col] = acc[r];       // slab of this K slice; splitk_finish_kernel sums them
             } else if (ok) {
                 if (p.act == ACT_GELU) v = gelu_erf(v);
                 else if (p.act == ACT_RELU) v = fmaxf(v, 0.f);

@@ -348,7 +348,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
-            epilogue_tile<SPLIT, EPI>(p, acc[i][j], m0 + wm * WM + i * 32, n0 + wn * WN + j * 32 + l31, lane, kslice == 0);
+            epilogue_tile<SPLIT, EPI>(p, acc[i][j], m0 + wm * WM + i * 32, n0 + wn * WN + j * 32 + l31, lane, kslice);
     if (p.clk_dbg && tid == 0 && (block_id & 63) == 0) {      // effective shader clock = cycles / (ticks / 100 MHz)
         atomicAdd(p.clk_dbg, __builtin_readcyclecounter() - clk0);
         atomicAdd(p.clk_dbg + 1, __builtin_amdgcn_s_memrealtime() - rt0);

@@ -95,8 +95,8 @@ struct sta_handle {
     char* ws = nullptr; int64_t ws_cap = 0;
     f16* zero_page = nullptr;
     float* skbuf = nullptr;   // fp32 partial sums of split-K GEMMs with the plane epilogue (SKBUF_SLOTS x SKBUF_ELEMS floats)
-    int64_t skbuf_dirty[SKBUF_SLOTS] = {0, 0, 0, 0, 0};   // floats of the slot that may be non-zero: the finishing kernel zeroes what it reads,
-                                                         // so a slot is all-zero at rest and needs no memset per GEMM (one 5 us dispatch less)
+    float* slab = nullptr;    // slab split-K of the small-M in-place residual GEMMs (GemmParams::slab), same slots and size as skbuf
+    int slab_ks = 0;          // set by launch_gemm: K slices the last slab GEMM wrote (0: it did not take the slab path)
     int gemm_variant = 0;   // 0 auto, 1 force 128x128 kernel, 2 force 256-row kernel (tests/bench only)
     // rope table
     float* rope_tab = nullptr; int rope_P = 0;
@@ -343,8 +343,8 @@ extern "C" int sta_create(const sta_config* cfg, int device, sta_handle** out) {
     int64_t big = (int64_t)768 * 768 * 9;
     if (big > h->stage_elems) h->stage_elems = big;
     if (hipMalloc((void**)&h->stage, (size_t)h->stage_elems * 4) != hipSuccess) { sta_destroy(h); return set_err("staging alloc failed"); }
-    if (hipMalloc((void**)&h->skbuf, (size_t)SKBUF_SLOTS * SKBUF_ELEMS * 4) != hipSuccess ||
-        hipMemset(h->skbuf, 0, (size_t)SKBUF_SLOTS * SKBUF_ELEMS * 4) != hipSuccess) { sta_destroy(h); return set_err("split-K buffer alloc failed"); }
+    if (hipMalloc((void**)&h->skbuf, (size_t)SKBUF_SLOTS * SKBUF_ELEMS * 4) != hipSuccess) { sta_destroy(h); return set_err("split-K buffer alloc failed"); }
+    if (hipMalloc((void**)&h->slab, (size_t)SKBUF_SLOTS * SKBUF_ELEMS * 4) != hipSuccess) { sta_destroy(h); return set_err("split-K slab alloc failed"); }
     if (hipMalloc((void**)&h->zero_page, 256) != hipSuccess || hipMemset(h->zero_page, 0, 256) != hipSuccess) { sta_destroy(h); return set_err("zero page alloc failed"); }
     *out = h;
     return 0;
@@ -360,6 +360,7 @@ extern "C" int sta_destroy(sta_handle* h) {
     if (h->rope_tab) hipFree(h->rope_tab);
     if (h->zero_page) hipFree(h->zero_page);
     if (h->skbuf) hipFree(h->skbuf);
+    if (h->slab) hipFree(h->slab);
     if (h->pre_tab) hipFree(h->pre_tab);
     if (h->clk_buf) hipFree(h->clk_buf);
     if (h->ev_ok) for (auto& e : h->ev) hipEventDestroy(e);
@@ -489,7 +490,6 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
     //      and the 4x-resolution refinement convolutions (-9 %);
     //   1: 128x128 register-staged kernel: shapes whose N is not a multiple of 128;  6: small-grid family, below.
     int variant = p.N % 128 == 0 ? 5 : 1;
-    int skslot = -1;                                  // split-K scratch slot in use by this launch (plane-epilogue path)
     if (split && p.N % 256 == 0 && EPI != EPI_QKV) {
         if (AMODE == A_DENSE && EPI == EPI_F32R && p.K >= 2048) variant = 3;
         if (AMODE == A_DENSE && EPI == EPI_GELU && p.M % 256 == 0 && ((int64_t)(p.M / 256) * (p.N / 256)) % 256 == 0) variant = 2;
@@ -501,8 +501,18 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
     const int64_t tiles_192 = (int64_t)((p.M + 191) / 192) * ((p.N + 127) / 128);
     if ((p.M <= 640 || tiles_192 < 128) && p.N % 64 == 0) {
         variant = 6;
-        const int tiles = h->deterministic ? (1 << 30) : ((p.M + 127) / 128) * (p.N / 64);   // deterministic: no split-K below
-        if (AMODE == A_DENSE && EPI == EPI_F32 && p.resid == p.C32 && p.rows_in == 0 && tiles < 256) {
+        const int tiles_r = ((p.M + 127) / 128) * (p.N / 64);
+        const int tiles = h->deterministic ? (1 << 30) : tiles_r;    // deterministic: no ATOMIC split-K (the slab forms below have a fixed order)
+        if (AMODE == A_DENSE && EPI == EPI_F32 && p.resid == p.C32 && p.rows_in == 0 && p.slab) {
+            // the caller finishes the GEMM in the LayerNorm kernel that follows (gemm_resid_ln): slices store partial tiles
+            // to slabs instead of atomically adding to the residual stream (the device-scope fp32 atomics of 256 workgroups
+            // cost more than the 4-32 K tiles of a slice); fixed summation order -> also taken in deterministic mode
+            int ks = tiles_r < 256 ? (256 + tiles_r - 1) / tiles_r : 1;
+            const int max_ks = p.K / 128;                 // keep >= 4 K tiles per slice
+            if (ks > max_ks) ks = max_ks;
+            while (ks > 1 && (int64_t)ks * p.M * p.N > SKBUF_ELEMS) --ks;
+            if (ks > 1) { p.ksplit = ks; h->slab_ks = ks; } else p.slab = nullptr;
+        } else if (AMODE == A_DENSE && EPI == EPI_F32 && p.resid == p.C32 && p.rows_in == 0 && tiles < 256) {
             int ks = (256 + tiles - 1) / tiles;
             const int max_ks = p.K / 128;                 // keep >= 4 K tiles per slice
             if (ks > max_ks) ks = max_ks;
@@ -513,19 +523,15 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
         // extra tiny launches only when the K loop is long and the grid leaves most of the chip idle (swept: <= 96 / 160 /
         // 256 tiles -> DPT 1.00 / 0.85 / 0.83 ms per view).  An in-kernel fix-up (last slice finishes the tile behind a
         // device-scope fence + ticket) was 1.7x SLOWER than this: the fence writes back / invalidates the XCD's L2.
-        if (EPI == EPI_F16 && tiles <= 192 && p.K >= 1024 && p.N % 4 == 0 && (int64_t)p.M * p.N <= SKBUF_ELEMS) {
-            int ks = (256 + tiles - 1) / tiles;
+        if (EPI == EPI_F16 && tiles_r <= 192 && p.K >= 1024 && p.N % 4 == 0 && (int64_t)p.M * p.N <= SKBUF_ELEMS) {
+            int ks = (256 + tiles_r - 1) / tiles_r;
             const int max_ks = p.K / 256;                 // keep >= 8 K tiles per slice
             if (ks > max_ks) ks = max_ks;
+            while (ks > 1 && (int64_t)ks * p.M * p.N > SKBUF_ELEMS) --ks;      // one slab per K slice
             if (ks > 1) {
                 int slot = 0;                             // one scratch slot per stream the forward may be running on
                 for (int q = 0; q < 4; ++q) if (h->aux[q] && st == h->aux[q]) slot = q + 1;
                 p.ksplit = ks; p.skbuf = h->skbuf + (size_t)slot * SKBUF_ELEMS;
-                if (h->skbuf_dirty[slot]) {               // a previous GEMM of this slot never reached its finishing kernel
-                    HIPCHK(hipMemsetAsync(p.skbuf, 0, (size_t)h->skbuf_dirty[slot] * 4, st));
-                    h->skbuf_dirty[slot] = 0;
-                }
-                skslot = slot;
             }
         }
     }
@@ -535,7 +541,8 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
         variant = (p.N % 256 == 0 && EPI != EPI_QKV) ? h->gemm_variant : 5;
     if (h->gemm_variant == 4 && variant != 6 && p.N % 128 == 0) variant = 5;
     if (h->gemm_variant == 1) variant = 1;
-    if (variant != 6) p.ksplit = 1;
+    if (variant != 6) { p.ksplit = 1; h->slab_ks = 0; }
+    if (h->slab_ks == 0) p.slab = nullptr;
     if (p.mx && variant == 1) variant = 5;     // no f16mx form of the register-staged kernel (use_mx() already requires N % 64 == 0)
     // per-launch HIP-event timing (bench / tools): every launch (mode 2), or only the launches of ONE kernel symbol
     // (mode 3, sta_kernel_timing_filter: the event pairs break back-to-back dispatch, ~3.5 us each, so the timed region of
@@ -574,13 +581,11 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
         else if (split) CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 2, 2, 3>(p, st)));
         else CHK((launch_gemm2<false, AMODE, EPI, 128, 64, 2, 2, 3>(p, st)));
         if (EPI == EPI_F16 && p.ksplit > 1) {
-            if (skslot >= 0) h->skbuf_dirty[skslot] = (int64_t)p.M * p.N;        // until the finishing kernel below is enqueued
             const int64_t n4 = (int64_t)p.M * (p.N / 4);
             const int blocks = (int)((n4 + 255) / 256);
-            if (split) hipLaunchKernelGGL(splitk_finish_kernel<true>, dim3(blocks), dim3(256), 0, st, p.skbuf, p.bias, p.M, p.N, p.act, p.R1_hi, p.R2_hi, p.C_hi, p.c_rp, p.r_mx, p.c_mx);
-            else hipLaunchKernelGGL(splitk_finish_kernel<false>, dim3(blocks), dim3(256), 0, st, p.skbuf, p.bias, p.M, p.N, p.act, p.R1_hi, p.R2_hi, p.C_hi, p.c_rp, 0, 0);
+            if (split) hipLaunchKernelGGL(splitk_finish_kernel<true>, dim3(blocks), dim3(256), 0, st, p.skbuf, p.ksplit, p.bias, p.M, p.N, p.act, p.R1_hi, p.R2_hi, p.C_hi, p.c_rp, p.r_mx, p.c_mx);
+            else hipLaunchKernelGGL(splitk_finish_kernel<false>, dim3(blocks), dim3(256), 0, st, p.skbuf, p.ksplit, p.bias, p.M, p.N, p.act, p.R1_hi, p.R2_hi, p.C_hi, p.c_rp, 0, 0);
             HIPCHK(hipGetLastError());
-            if (skslot >= 0) h->skbuf_dirty[skslot] = 0;
         }
     } else {
         int tm = (p.M + GEMM_BM - 1) / GEMM_BM, tn = (p.N + GEMM_BN - 1) / GEMM_BN;
@@ -634,6 +639,35 @@ static int gemm_f16(sta_handle* h, const Planes& A, const Lin& W, int M, const P
     if (act == ACT_GELU && M > 640) return launch_gemm<A_DENSE, EPI_GELU>(h, p, st);   // mlp.fc1 at throughput scale: compile-time activation, no residual
                                                                                       // planes (small M keeps the generic epilogue and its split-K path)
     return launch_gemm<A_DENSE, EPI_F16>(h, p, st);
+}
+static int run_ln(sta_handle* h, const float* x, int M, int C, const LNp& a, const Planes& oa, const LNp* b, const Planes* ob,
+                  float* o32, hipStream_t st, bool mx, const float* slab, int nslab);
+// x += A W^T + b (attn.proj, mlp.fc2, cross_attn.proj) followed by the LayerNorm(s) of x the next GEMM(s) read (la == nullptr:
+// none).  Throughput scale: the in-place GEMM, then the LayerNorm kernel.  Small-M regime (SLAM scale): the K slices store
+// partial tiles to slabs and the LayerNorm kernel adds them into x before normalising - the same two dispatches without
+// the atomics epilogue (13-15 us -> 8 us per GEMM at M = 196), and bit-reproducible.
+static int gemm_resid_ln(sta_handle* h, const Planes& A, const Lin& W, int M, float* x, int ld, const LNp* la, const Planes* oa,
+                         const LNp* lb, const Planes* ob, bool ln_mx, hipStream_t st) {
+    static const LNp no_ln = {nullptr, nullptr};
+    static const Planes no_planes;
+    const int64_t tiles_192 = (int64_t)((M + 191) / 192) * ((W.N + 127) / 128);
+    const bool small = (M <= 640 || tiles_192 < 128) && W.N % 64 == 0 && W.N <= 1024 && h->gemm_variant == 0 && ld == W.N && !getenv("STA_EXPERIMENT_NOSLAB");
+    h->slab_ks = 0;
+    if (small) {
+        int slot = 0;
+        for (int q = 0; q < 4; ++q) if (h->aux[q] && st == h->aux[q]) slot = q + 1;
+        GemmParams p = gp_dense(A, W.K, W, M, use_mx(h, W));
+        p.C32 = x; p.ldc = ld; p.resid = x; p.ldr = ld; p.rows_in = 0; p.rows_out = 0; p.row_off = 0;
+        p.slab = h->slab + (size_t)slot * SKBUF_ELEMS;
+        CHK((launch_gemm<A_DENSE, EPI_F32>(h, p, st)));
+        const int ks = h->slab_ks;
+        h->slab_ks = 0;
+        if (ks > 1) return run_ln(h, x, M, W.N, la ? *la : no_ln, oa ? *oa : no_planes, lb, ob, nullptr, st, ln_mx, p.slab, ks);
+    } else {
+        CHK(gemm_f32(h, A, W, M, x, ld, x, st));
+    }
+    if (la) return run_ln(h, x, M, W.N, *la, *oa, lb, ob, nullptr, st, ln_mx, nullptr, 0);
+    return 0;
 }
 struct QKVOut { Planes q, k, vt; int npad; };
 static int gp_qkv(sta_handle* h, GemmParams& p, const Planes& A, const Lin& W, int M, int nq, int nk, int nv,
@@ -719,14 +753,23 @@ static int conv3(sta_handle* h, const Planes& in, int nimg, int Hi, int Wi, int 
 }
 
 static int run_ln(sta_handle* h, const float* x, int M, int C, const LNp& a, const Planes& oa,
-                  const LNp* b, const Planes* ob, float* o32, hipStream_t st, bool mx = false) {
+                  const LNp* b, const Planes* ob, float* o32, hipStream_t st, bool mx = false,
+                  const float* slab = nullptr, int nslab = 0) {
     if (h->dry) return 0;
     LnParams p; memset(&p, 0, sizeof p);
+    p.slab = slab; p.nslab = nslab; p.xw = const_cast<float*>(x);     // slab split-K: x += sum of the slices first (x is the residual stream)
     p.mx = mx ? 1 : 0;     // plane format of the consumer GEMM (f16mx rows when that linear runs in the f16mx arithmetic)
     p.x = x; p.ldx = C; p.M = M; p.C = C; p.eps = h->cfg.ln_eps;
     p.g1 = a.g; p.b1 = a.b; p.o1_hi = oa.hi; p.o1_lo = oa.lo;
     if (b) { p.g2 = b->g; p.b2 = b->b; p.o2_hi = ob->hi; p.o2_lo = ob->lo; }
     p.o32 = o32; p.ldo32 = C;
+    if (slab) {          // residual-GEMM finish + LayerNorm, one block per row
+        REQUIRE(C <= 1024 && C % 4 == 0, "internal: slab LayerNorm needs C <= 1024");
+        if (h->prec != STA_PREC_F16) hipLaunchKernelGGL(resid_ln_kernel<true>, dim3(M), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(resid_ln_kernel<false>, dim3(M), dim3(256), 0, st, p);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     dim3 grid((M + 3) / 4);
     if (h->prec != STA_PREC_F16) hipLaunchKernelGGL(ln_kernel<true>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(ln_kernel<false>, grid, dim3(256), 0, st, p);
@@ -829,15 +872,16 @@ static int encode_impl(sta_handle* h, Bump& ws, const void* const* imgs, bool u8
         HIPCHK(hipGetLastError());
     }
     CHK(gemm_f32(h, patches, h->patch, M, feat, E, nullptr, st));
+    // every in-place residual GEMM is issued together with the LayerNorm that reads its result (gemm_resid_ln)
+    if (c.enc_depth > 0) CHK(run_ln(h, feat, M, E, h->enc[0].n1, lnp, nullptr, nullptr, nullptr, st, use_mx(h, h->enc[0].qkv)));
     for (int i = 0; i < c.enc_depth; ++i) {
         const EncBlk& b = h->enc[i];
-        CHK(run_ln(h, feat, M, E, b.n1, lnp, nullptr, nullptr, nullptr, st, use_mx(h, b.qkv)));
         CHK(gemm_qkv(h, lnp, b.qkv, M, E, E, E, qkv, N, Hh, wp, 0, st));
         CHK(run_attn(h, qkv, ao, E, n, Hh, N, N, 0, st, use_mx(h, b.proj)));
-        CHK(gemm_f32(h, ao, b.proj, M, feat, E, feat, st));
-        CHK(run_ln(h, feat, M, E, b.n2, lnp, nullptr, nullptr, nullptr, st, use_mx(h, b.fc1)));
+        CHK(gemm_resid_ln(h, ao, b.proj, M, feat, E, &b.n2, &lnp, nullptr, nullptr, use_mx(h, b.fc1), st));
         CHK(gemm_f16(h, lnp, b.fc1, M, f1, ACT_GELU, st, use_mx(h, b.fc2)));
-        CHK(gemm_f32(h, f1, b.fc2, M, feat, E, feat, st));
+        if (i + 1 < c.enc_depth) CHK(gemm_resid_ln(h, f1, b.fc2, M, feat, E, &h->enc[i + 1].n1, &lnp, nullptr, nullptr, use_mx(h, h->enc[i + 1].qkv), st));
+        else CHK(gemm_resid_ln(h, f1, b.fc2, M, feat, E, nullptr, nullptr, nullptr, nullptr, false, st));
     }
     return 0;
 }
@@ -881,10 +925,11 @@ static int decode_impl(sta_handle* h, Bump& ws, const float* feat1, const float*
         return 0;
     };
     CHK(emit(0));
+    // norm1(x) and norm_y(x) from one read: y of one side == x of the other (sta_model.py:231-235); qkv and projk|projv:
+    // one class, one plane format.  Layer i+1's pair is issued with layer i's mlp.fc2 (gemm_resid_ln).
+    if (c.dec_depth > 0) CHK(run_ln(h, x, M, D, h->dec[0].n1, a1, &h->dec[0].ny, &ay, nullptr, st, use_mx(h, h->dec[0].qkv)));
     for (int i = 0; i < c.dec_depth; ++i) {
         const DecBlk& b = h->dec[i];
-        // norm1(x) and norm_y(x) from one read: y of one side == x of the other (sta_model.py:231-235)
-        CHK(run_ln(h, x, M, D, b.n1, a1, &b.ny, &ay, nullptr, st, use_mx(h, b.qkv)));     // qkv and projk|projv: one class, one format
         // self-attention q,k,v and the cross-attention k,v of the OTHER side depend only on the layer input: one launch.
         // (They write disjoint buffers: qkv / ckv_out.)
         {
@@ -894,17 +939,17 @@ static int decode_impl(sta_handle* h, Bump& ws, const float* feat1, const float*
             CHK(gemm_qkv_pair(h, pq, pkv, st));
         }
         CHK(run_attn(h, qkv, ao, D, S, Hh, Np, Np, 0, st, use_mx(h, b.proj)));
-        CHK(gemm_f32(h, ao, b.proj, M, x, D, x, st));
-        CHK(run_ln(h, x, M, D, b.n2, a1, nullptr, nullptr, nullptr, st, use_mx(h, b.cq)));
+        CHK(gemm_resid_ln(h, ao, b.proj, M, x, D, &b.n2, &a1, nullptr, nullptr, use_mx(h, b.cq), st));
         CHK(gemm_qkv(h, a1, b.cq, M, D, 0, 0, cqkv, Np, Hh, wp, 1, st));
         CHK(run_attn(h, cqkv, ao, D, S, Hh, Np, Np, B, st, use_mx(h, b.cproj)));
-        CHK(gemm_f32(h, ao, b.cproj, M, x, D, x, st));
-        CHK(run_ln(h, x, M, D, b.n3, a1, nullptr, nullptr, nullptr, st, use_mx(h, b.fc1)));
+        CHK(gemm_resid_ln(h, ao, b.cproj, M, x, D, &b.n3, &a1, nullptr, nullptr, use_mx(h, b.fc1), st));
         CHK(gemm_f16(h, a1, b.fc1, M, f1, ACT_GELU, st, use_mx(h, b.fc2)));
-        CHK(gemm_f32(h, f1, b.fc2, M, x, D, x, st));
         if (i + 1 < c.dec_depth) {
+            const DecBlk& nb = h->dec[i + 1];
+            CHK(gemm_resid_ln(h, f1, b.fc2, M, x, D, &nb.n1, &a1, &nb.ny, &ay, use_mx(h, nb.qkv), st));
             CHK(emit(i + 1));
         } else {   // final_x[-1] = dec_norm(final_x[-1])  (sta_model.py:241-242)
+            CHK(gemm_resid_ln(h, f1, b.fc2, M, x, D, nullptr, nullptr, nullptr, nullptr, false, st));
             Planes none;
             if (want1 && want1[i + 1]) CHK(run_ln(h, x, B * Np, D, h->dec_norm, none, nullptr, nullptr, want1[i + 1], st));
             if (want2 && want2[i + 1]) CHK(run_ln(h, x + (size_t)B * Np * D, B * Np, D, h->dec_norm, none, nullptr, nullptr, want2[i + 1], st));
