@@ -173,9 +173,17 @@ template <bool SPLIT, int EPI>
 __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx16& acc, int row0, int col, int lane,
                                               int kslice = 0) {
     const bool first_slice = kslice == 0;
-    if (EPI == EPI_QKV) { epilogue_qkv_tile<SPLIT>(p, acc, row0, col, lane); return; }
+    if (EPI == EPI_QKV && p.ksplit <= 1) { epilogue_qkv_tile<SPLIT>(p, acc, row0, col, lane); return; }
     const int lhi = lane >> 5;
     const bool col_ok = col < p.N;
+    if (EPI == EPI_QKV) {          // split-K (small-M regime): raw partial tile to the slab of this slice; qkv_finish_kernel does the rest
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (col_ok && row < p.M) p.skbuf[((size_t)kslice * p.M + row) * p.N + col] = acc[r];
+        }
+        return;
+    }
     const float bv = (p.bias != nullptr && col_ok && first_slice) ? p.bias[col] : 0.f;
     if ((EPI == EPI_F32R || EPI == EPI_GELU) && row0 + 32 <= p.M && __all(col_ok)) {
         // interior tile of a hot epilogue (every tile when M, N are tile multiples, as at bench scale): no per-element
@@ -258,6 +266,73 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
                 if (SPLIT && p.c_mx) store_mx1<false>(p.C_hi, o, v);
                 else if (SPLIT) { f16 h, l; split_f16(v, h, l); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
                 else p.C_hi[o] = to_f16_sat(v);
+            }
+        }
+    }
+}
+
+// Second half of a split-K GEMM with the QKV epilogue (small-M regime): sums the K-slice slabs skbuf[s][M,N], adds the
+// bias, rotates Q / K (RoPE pairs (d, d+16) sit in lanes l and l^16 of a wave: a wave is one 64-column head of one row) and
+// writes head-major Q / K and V^T exactly like epilogue_qkv_tile.  Threads [0, M*(nq+nk)): one Q/K element each;
+// threads after that: one V column x 4 consecutive rows each (one 8-byte run of V^T).
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void qkv_finish_kernel(const GemmParams p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nqk = p.nq + p.nk;
+    const int64_t n_qk = (int64_t)p.M * nqk;
+    const int lane = threadIdx.x & 63;
+    if (i < n_qk) {                                     // n_qk is a multiple of 64: the branch is wave-uniform
+        const int row = (int)(i / nqk), c = (int)(i - (int64_t)row * nqk);
+        float v = p.bias ? p.bias[c] : 0.f;
+        for (int s = 0; s < p.ksplit; ++s) v += p.skbuf[((size_t)s * p.M + row) * p.N + c];
+        const int seg = c >= p.nq ? 1 : 0, cc = c - (seg ? p.nq : 0);
+        const int head = cc >> 6, dcol = cc & 63, xpart = (dcol >> 5) & 1;
+        const int s_ = fast_div(row, p.ntok, p.ntok_magic), t = row - s_ * p.ntok;
+        const int tt = p.has_pose_tok ? t - 1 : t;
+        const int ty = tt < 0 ? 0 : fast_div(tt, p.wp, p.wp_magic);
+        const int pos = tt < 0 ? 0 : (xpart ? tt - ty * p.wp : ty) + 1;
+        const float2 cs = *reinterpret_cast<const float2*>(p.rope_tab + ((size_t)pos * 16 + (lane & 15)) * 2);
+        const float other = __shfl_xor(v, 16);
+        v = (lane & 16) ? (v * cs.x + other * cs.y) : (v * cs.x - other * cs.y);
+        f16* const dh = seg == 0 ? p.Q_hi : p.K_hi;
+        f16* const dl = seg == 0 ? p.Q_lo : p.K_lo;
+        const size_t o = ((size_t)(s_ * p.heads + head) * p.npad + t) * 64 + dcol;
+        if (SPLIT) { f16 h, l; split_f16(v, h, l); dh[o] = h; dl[o] = l; }
+        else dh[o] = to_f16_sat(v);
+        return;
+    }
+    const int64_t j = i - n_qk;
+    const int m4 = (p.M + 3) >> 2;
+    if (j >= (int64_t)m4 * p.nv) return;
+    const int g = (int)(j / p.nv), c = (int)(j - (int64_t)g * p.nv), col = nqk + c;
+    const int head = c >> 6, dcol = c & 63;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+    f16 hh[4], ll[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int row = g * 4 + e < p.M ? g * 4 + e : p.M - 1;
+        float v = bv;
+        for (int s = 0; s < p.ksplit; ++s) v += p.skbuf[((size_t)s * p.M + row) * p.N + col];
+        if (SPLIT) split_f16(v, hh[e], ll[e]); else { hh[e] = to_f16_sat(v); ll[e] = (f16)0; }
+    }
+    const int row0 = g * 4;
+    const int s0 = fast_div(row0, p.ntok, p.ntok_magic), t0 = row0 - s0 * p.ntok;
+    if (row0 + 3 < p.M && t0 + 3 < p.ntok) {
+        const size_t o = ((size_t)(s0 * p.heads + head) * 64 + dcol) * p.npad + t0;
+        H4 ph, pl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ph.e[e] = hh[e]; pl.e[e] = ll[e]; }
+        *reinterpret_cast<uint2_a2*>(p.Vt_hi + o) = ph.u;
+        if (SPLIT) *reinterpret_cast<uint2_a2*>(p.Vt_lo + o) = pl.u;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = row0 + e;
+            if (row < p.M) {
+                const int s2 = fast_div(row, p.ntok, p.ntok_magic), t2 = row - s2 * p.ntok;
+                const size_t o2 = ((size_t)(s2 * p.heads + head) * 64 + dcol) * p.npad + t2;
+                p.Vt_hi[o2] = hh[e];
+                if (SPLIT) p.Vt_lo[o2] = ll[e];
             }
         }
     }

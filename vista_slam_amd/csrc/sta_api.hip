@@ -507,6 +507,8 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
             // the caller finishes the GEMM in the LayerNorm kernel that follows (gemm_resid_ln): slices store partial tiles
             // to slabs instead of atomically adding to the residual stream (the device-scope fp32 atomics of 256 workgroups
             // cost more than the 4-32 K tiles of a slice); fixed summation order -> also taken in deterministic mode
+            // (swept at M = 196 / 394 / 1970: a target of 128 / 192 / 256 / 384 / 512 workgroups -> encode 2.50 / 2.40 / 2.38 /
+            // 2.49 / 2.55 ms: one workgroup per CU; more slices cost more slab traffic than their shorter K loops save)
             int ks = tiles_r < 256 ? (256 + tiles_r - 1) / tiles_r : 1;
             const int max_ks = p.K / 128;                 // keep >= 4 K tiles per slice
             if (ks > max_ks) ks = max_ks;
@@ -517,6 +519,19 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
             const int max_ks = p.K / 128;                 // keep >= 4 K tiles per slice
             if (ks > max_ks) ks = max_ks;
             if (ks > 1) p.ksplit = ks;
+        }
+        // QKV-epilogue GEMMs (attn.qkv, cross_attn.projq / projk|projv) on small grids: K slices to slabs, qkv_finish_kernel
+        // applies bias + RoPE and writes Q / K / V^T (un-split attn.qkv at M = 196: 96 workgroups x 32 K tiles = 25 us)
+        if (AMODE == A_DENSE && EPI == EPI_QKV && tiles_r <= 192 && p.K >= 512) {
+            int ks = (256 + tiles_r - 1) / tiles_r;
+            const int max_ks = p.K / 256;                 // keep >= 8 K tiles per slice
+            if (ks > max_ks) ks = max_ks;
+            while (ks > 1 && (int64_t)ks * p.M * p.N > SKBUF_ELEMS) --ks;
+            if (ks > 1) {
+                int slot = 0;
+                for (int q = 0; q < 4; ++q) if (h->aux[q] && st == h->aux[q]) slot = q + 1;
+                p.ksplit = ks; p.skbuf = h->skbuf + (size_t)slot * SKBUF_ELEMS;
+            }
         }
         // plane-epilogue GEMMs / convs on tiny grids (DPT levels at SLAM scale: 16-64 workgroups looping over K = 2304 ..
         // 6912): split K into fp32 partial sums, a finishing kernel applies bias / activation / residuals.  Worth two
@@ -580,6 +595,13 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
         if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 2, 2, 3, true>(p, st)));
         else if (split) CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 2, 2, 3>(p, st)));
         else CHK((launch_gemm2<false, AMODE, EPI, 128, 64, 2, 2, 3>(p, st)));
+        if (EPI == EPI_QKV && p.ksplit > 1) {
+            const int64_t nthr = (int64_t)p.M * (p.nq + p.nk) + (int64_t)((p.M + 3) / 4) * p.nv;
+            const int blocks = (int)((nthr + 255) / 256);
+            if (split) hipLaunchKernelGGL(qkv_finish_kernel<true>, dim3(blocks), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL(qkv_finish_kernel<false>, dim3(blocks), dim3(256), 0, st, p);
+            HIPCHK(hipGetLastError());
+        }
         if (EPI == EPI_F16 && p.ksplit > 1) {
             const int64_t n4 = (int64_t)p.M * (p.N / 4);
             const int blocks = (int)((n4 + 255) / 256);
@@ -651,7 +673,7 @@ static int gemm_resid_ln(sta_handle* h, const Planes& A, const Lin& W, int M, fl
     static const LNp no_ln = {nullptr, nullptr};
     static const Planes no_planes;
     const int64_t tiles_192 = (int64_t)((M + 191) / 192) * ((W.N + 127) / 128);
-    const bool small = (M <= 640 || tiles_192 < 128) && W.N % 64 == 0 && W.N <= 1024 && h->gemm_variant == 0 && ld == W.N && !getenv("STA_EXPERIMENT_NOSLAB");
+    const bool small = (M <= 640 || tiles_192 < 128) && W.N % 64 == 0 && W.N <= 1024 && h->gemm_variant == 0 && ld == W.N;
     h->slab_ks = 0;
     if (small) {
         int slot = 0;
