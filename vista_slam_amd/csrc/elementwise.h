@@ -516,12 +516,19 @@ __global__ __launch_bounds__(256) void intrinsics_partial_kernel(const float* pt
 // (g = 2: the two views of a pair, slam.py:184 shared_intrinsic=True) -> K [B/g,3,3].
 __global__ void intrinsics_final_kernel(const double* partial, int B, int nblk, int H, int W, int shared,
                                         float* K /*[3,3] or [B,3,3] or [B/g,3,3]*/, float* conf_mean /*[B] or null*/, int tr) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;          // one wave: lanes stride over the block partials, then a butterfly
+    const int lane = threadIdx.x;
     const float pcx = (tr ? H : W) / 2.0f, pcy = (tr ? W : H) / 2.0f;
     double tot[5] = {0, 0, 0, 0, 0};
     for (int b = 0; b < B; ++b) {
         double s[5] = {0, 0, 0, 0, 0};
-        for (int j = 0; j < nblk; ++j) for (int k = 0; k < 5; ++k) s[k] += partial[((int64_t)b * nblk + j) * 5 + k];
+        for (int j = lane; j < nblk; j += 64) for (int k = 0; k < 5; ++k) s[k] += partial[((int64_t)b * nblk + j) * 5 + k];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s[k] += __shfl_xor(s[k], o);
+        }
+        if (lane != 0) continue;                                // (every lane holds the sums; lane 0 writes)
         if (conf_mean) conf_mean[b] = (float)(s[4] / ((double)H * W));
         for (int k = 0; k < 5; ++k) tot[k] += s[k];
         if (shared >= 2 && (b + 1) % shared == 0) {
@@ -538,7 +545,7 @@ __global__ void intrinsics_final_kernel(const double* partial, int B, int nblk, 
             Kb[6] = 0.f; Kb[7] = 0.f; Kb[8] = 1.f;
         }
     }
-    if (shared == 1) {
+    if (shared == 1 && lane == 0) {
         K[0] = (float)(tot[0] / tot[1]); K[1] = 0.f; K[2] = pcx;
         K[3] = 0.f; K[4] = (float)(tot[2] / tot[3]); K[5] = pcy;
         K[6] = 0.f; K[7] = 0.f; K[8] = 1.f;

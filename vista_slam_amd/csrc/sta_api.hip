@@ -535,10 +535,10 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
         }
         // plane-epilogue GEMMs / convs on tiny grids (DPT levels at SLAM scale: 16-64 workgroups looping over K = 2304 ..
         // 6912): split K into fp32 partial sums, a finishing kernel applies bias / activation / residuals.  Worth two
-        // extra tiny launches only when the K loop is long and the grid leaves most of the chip idle (swept: <= 96 / 160 /
-        // 256 tiles -> DPT 1.00 / 0.85 / 0.83 ms per view).  An in-kernel fix-up (last slice finishes the tile behind a
+        // extra tiny launches only when the K loop is long and the grid leaves most of the chip idle (swept with atomics: <= 96 /
+        // 160 / 256 tiles -> DPT 1.00 / 0.85 / 0.83 ms per view; with slabs, 5-edge scheduler: <= 192 / 256 tiles -> 6.04 / 5.89 ms).  An in-kernel fix-up (last slice finishes the tile behind a
         // device-scope fence + ticket) was 1.7x SLOWER than this: the fence writes back / invalidates the XCD's L2.
-        if (EPI == EPI_F16 && tiles_r <= 192 && p.K >= 1024 && p.N % 4 == 0 && (int64_t)p.M * p.N <= SKBUF_ELEMS) {
+        if (EPI == EPI_F16 && tiles_r <= 256 && p.K >= 1024 && p.N % 4 == 0 && (int64_t)p.M * p.N <= SKBUF_ELEMS) {
             int ks = (256 + tiles_r - 1) / tiles_r;
             const int max_ks = p.K / 256;                 // keep >= 8 K tiles per slice
             if (ks > max_ks) ks = max_ks;
