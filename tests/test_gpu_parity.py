@@ -119,8 +119,8 @@ def test_goldens_f16mx_experimental_precision(G, case, tol):
 
 
 def test_random_shapes_and_batches_vs_oracle(G):
-    """Beyond the fixed golden shapes: random (H, W, B) - odd token grids, ragged last tiles, square and wide frames -
-    against the oracle (itself pinned to the reference goldens) on the tiny configuration, default and opt-in precision."""
+    """Beyond the fixed golden shapes: random (H, W, B) - odd token grids, ragged last tiles, square, wide and portrait
+    frames, a single 16x16 token - against the oracle (itself pinned to the reference goldens) on the tiny configuration, default and opt-in precision."""
     import numpy as np
     import torch
     from helpers import rel_l2
@@ -128,8 +128,9 @@ def test_random_shapes_and_batches_vs_oracle(G):
     from vista_slam_amd import weights as W
     rng = np.random.default_rng(5)
     sd = W.state_dict(W.TINY, seed=43)
-    for it in range(5):
-        hp = int(rng.integers(1, 6)); wp = int(rng.integers(hp, 8)); B = int(rng.integers(1, 4))
+    shapes = [(int(hp), int(rng.integers(hp, 8)), int(rng.integers(1, 4))) for hp in rng.integers(1, 6, size=5)]
+    shapes += [(1, 1, 2), (1, 7, 1), (7, 1, 1), (5, 2, 3), (6, 4, 1)]      # one-token frames, one-row / one-column grids, portrait
+    for it, (hp, wp, B) in enumerate(shapes):
         H, Wd = 16 * hp, 16 * wp
         imgs = (W.smooth_images if it % 2 else W.synth_images)(2 * B, H, Wd, seed=43, tag=30 + it)
         want = O.forward_pair(W.TINY, sd, imgs[:B], imgs[B:])
