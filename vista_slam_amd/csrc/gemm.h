@@ -24,8 +24,11 @@
 enum { A_DENSE = 0, A_CONV3 = 1 };
 enum { EPI_F32 = 0, EPI_F16 = 1, EPI_QKV = 2, EPI_CONVT = 3,
        EPI_GELU = 4,     // mlp.fc1: fp16-plane epilogue with the activation fixed at compile time and no residual planes
-       EPI_F32R = 5 };   // attn.proj / mlp.fc2 at throughput scale: fp32 output added IN PLACE to the residual stream,
+       EPI_F32R = 5,     // attn.proj / mlp.fc2 at throughput scale: fp32 output added IN PLACE to the residual stream,
                          // no row remap, no split-K - the common case of EPI_F32 without its per-element flag branches
+       EPI_HEAD = 6 };   // DPT head tail at throughput scale: 3x3 conv 128->128 + ReLU (head.2/.3) whose 192x128 tile holds every
+                         // channel of its pixels, so the 1x1 conv 128->4 (head.4) and the point-map / confidence activations
+                         // (postprocess.py:10-62) run in the epilogue and the [pixels,128] map never reaches HBM (gemm2.h)
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
 
 struct GemmParams {
@@ -61,6 +64,8 @@ struct GemmParams {
     const float* rope_tab;                               // [(pos+1)][16][2] cos,sin ; pos = -1 .. P-1
     // ---- EPI_CONVT
     int ct_k, ct_cout, ct_h, ct_w;
+    // ---- EPI_HEAD: head.4 weights [4][128] / bias [4] (fp32); pixels [0, hsplit) -> (hptsA, hconfA), the rest -> (hptsB, hconfB)
+    const float* hw4; const float* hb4; float* hptsA; float* hconfA; float* hptsB; float* hconfB; int64_t hsplit;
     // ---- misc
     const f16* zero_page;                                // >= 64 B of zeros (OOB taps of the direct-to-LDS conv loader)
     unsigned long long* clk_dbg = nullptr;               // bench only: block 0 stores {shader cycles, 100 MHz ticks} of its lifetime

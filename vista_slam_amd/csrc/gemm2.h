@@ -43,6 +43,67 @@ __device__ __forceinline__ int lds2_off(int row, int chunk) {
 // ahead and stays in flight across the barrier (counted vmcnt + raw s_barrier in one asm statement) -
 // no gain on the big throughput shapes (DMA-throughput bound) but it is what makes the small-M /
 // split-K family (SLAM-scale GEMMs, a handful of K tiles per block) latency-tolerant.
+// EPI_HEAD epilogue of one workgroup (BN == 128 == N: the tile holds all channels of its BM pixels; a wave holds 32 of them
+// for MT x 32 pixels).  Per 32x32 accumulator tile: v = relu(acc + bias), the four head.4 partial dot products of the lane's
+// channel, then a halving butterfly over the 32 channel lanes (62 shuffles for 64 (pixel, output) sums instead of 320);
+// the four waves of a pixel row meet in LDS, and BM threads apply the activations and store pts / conf.
+template <int BM, int MT, int WM, int WAVES_N>
+__device__ __forceinline__ void head_epilogue(const GemmParams& p, const floatx16 (&acc)[MT][1], int m0, int wm, int wn, int tid, char* smem) {
+    float* red = reinterpret_cast<float*>(smem);                 // [WAVES_N][BM][4]
+    const int lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+    const int col = wn * 32 + l31;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+    float w4[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) w4[o] = p.hw4[o * 128 + col];
+    __syncthreads();                                             // every wave has left the operand stages
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        float part[64];                                          // [r][o]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = fmaxf(acc[i][0][r] + bv, 0.f);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) part[r * 4 + o] = v * w4[o];
+        }
+#pragma unroll
+        for (int m = 16, n = 64; m >= 1; m >>= 1, n >>= 1) {     // after the step a lane keeps n/2 sums: the upper half if its bit is set
+            const bool up = (l31 & m) != 0;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                if (k < n / 2) {
+                    const float send = up ? part[k] : part[k + n / 2];
+                    const float keep = up ? part[k + n / 2] : part[k];
+                    part[k] = keep + __shfl_xor(send, m);
+                }
+            }
+        }
+        // lane l31 now holds sums 2*l31, 2*l31+1 of [r][o]: r = l31 >> 1, o = (l31 & 1) * 2 + {0, 1}
+        const int r = l31 >> 1, row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        *reinterpret_cast<float2*>(red + ((size_t)wn * BM + row) * 4 + (l31 & 1) * 2) = make_float2(part[0], part[1]);
+    }
+    __syncthreads();
+    if (tid < BM) {
+        const int64_t pix = (int64_t)m0 + tid;
+        if (pix < p.M) {
+            float4 a = *reinterpret_cast<const float4*>(red + (size_t)tid * 4);
+#pragma unroll
+            for (int w = 1; w < WAVES_N; ++w) {
+                const float4 b = *reinterpret_cast<const float4*>(red + ((size_t)w * BM + tid) * 4);
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+            const float x = a.x + p.hb4[0], y = a.y + p.hb4[1], z = a.z + p.hb4[2], c = a.w + p.hb4[3];
+            const float d = sqrtf(x * x + y * y + z * z);
+            const float sc = expm1f(d) / fmaxf(d, 1e-8f);
+            const bool second = pix >= p.hsplit;
+            const int64_t q = second ? pix - p.hsplit : pix;
+            float* pts = (second ? p.hptsB : p.hptsA) + q * 3;
+            pts[0] = x * sc; pts[1] = y * sc; pts[2] = z * sc;
+            (second ? p.hconfB : p.hconfA)[q] = 1.0f + expf(c);
+        }
+    }
+}
+
 template <bool SPLIT, int AMODE, int EPI, int BM, int BN, int WAVES_M, int WAVES_N, int ABL = 0, int NSTG = 2, bool MX = false>
 __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_id) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -344,11 +405,15 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
         }
     }
 
+    if constexpr (EPI == EPI_HEAD) {
+        if constexpr (NT == 1 && BN == 128 && WAVES_N == 4) head_epilogue<BM, MT, WM, WAVES_N>(p, acc, m0, wm, wn, tid, smem);
+    } else {
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
-            epilogue_tile<SPLIT, EPI>(p, acc[i][j], m0 + wm * WM + i * 32, n0 + wn * WN + j * 32 + l31, lane, kslice);
+            for (int i = 0; i < MT; ++i)
+                epilogue_tile<SPLIT, EPI>(p, acc[i][j], m0 + wm * WM + i * 32, n0 + wn * WN + j * 32 + l31, lane, kslice);
+    }
     if (p.clk_dbg && tid == 0 && (block_id & 63) == 0) {      // effective shader clock = cycles / (ticks / 100 MHz)
         atomicAdd(p.clk_dbg, __builtin_readcyclecounter() - clk0);
         atomicAdd(p.clk_dbg + 1, __builtin_amdgcn_s_memrealtime() - rt0);

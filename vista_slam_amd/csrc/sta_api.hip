@@ -579,6 +579,12 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
         h->kn++;
     }
     if (timed && variant == 5) p.clk_dbg = h->clk_buf;   // effective-clock probe (bench only)
+    if constexpr (EPI == EPI_HEAD) {      // exists for the 192x128 family only (conv3_head checks the shape)
+        REQUIRE(variant == 5 && p.N == 128, "internal: fused head epilogue on a tile family without it");
+        if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4, 2, true>(p, st)));
+        else if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4>(p, st)));
+        else CHK((launch_gemm2<false, AMODE, EPI, 192, 128, 2, 4>(p, st)));
+    } else
     if (variant == 2) {
         if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 256, 256, 4, 4, 2, true>(p, st)));
         else if (split) CHK((launch_gemm2<true, AMODE, EPI, 256, 256, 4, 4>(p, st)));
@@ -772,6 +778,28 @@ static int conv3(sta_handle* h, const Planes& in, int nimg, int Hi, int Wi, int 
     if (r1) { p.R1_hi = r1->hi; p.R1_lo = r1->lo; p.r_mx = r1->mx ? 1 : 0; REQUIRE(h->dry || r1->rp == out.rp, "internal: residual rows mismatch"); }
     if (r2) { p.R2_hi = r2->hi; p.R2_lo = r2->lo; REQUIRE(h->dry || (r2->rp == out.rp && (!r1 || r1->mx == r2->mx)), "internal: residual rows / format mismatch"); p.r_mx = r2->mx ? 1 : 0; }
     return launch_gemm<A_CONV3, EPI_F16>(h, p, st);
+}
+
+// head.2 (3x3 conv 128 -> 128) + ReLU + head.4 (1x1 conv 128 -> 4) + point-map / confidence activations as ONE kernel
+// (EPI_HEAD): true when it was launched; false = the caller runs conv3 + head_final_kernel (small grids, forced tile families).
+static bool conv3_head_ok(sta_handle* h, const Lin& W, int64_t M) {
+    return W.N == 128 && h->gemm_variant == 0 && (M + 191) / 192 >= 128;
+}
+static int conv3_head(sta_handle* h, const Planes& in, int nimg, int Hi, int Wi, int Cin, const Lin& W, const F32Lin& W4,
+                      float* ptsA, float* confA, int nA, float* ptsB, float* confB, hipStream_t st) {
+    GemmParams p; memset(&p, 0, sizeof p);
+    p.A_hi = in.hi; p.A_lo = in.lo; p.a_rp = in.rp;
+    p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.cstride = 1; p.relu_in = 0; p.Ho = Hi; p.Wo = Wi;
+    const bool mx = use_mx(h, W);
+    REQUIRE(h->dry || in.mx == mx, "internal: conv input format mismatch");
+    p.mx = mx ? 1 : 0;
+    p.B_hi = mx ? W.wmx.hi : W.w.hi; p.B_lo = mx ? W.wmx.lo : W.w.lo; p.bias = W.bias;
+    p.M = nimg * Hi * Wi; p.N = W.N; p.K = W.K;
+    REQUIRE(W.K == 9 * Cin && W.N == 128, "conv weight shape mismatch (fused head)");
+    REQUIRE(h->dry || (int64_t)nimg * Hi * Wi == in.rp, "internal: conv plane rows mismatch");
+    p.hw4 = W4.w; p.hb4 = W4.b; p.hptsA = ptsA; p.hconfA = confA; p.hptsB = ptsB; p.hconfB = confB;
+    p.hsplit = (int64_t)(nA < nimg ? nA : nimg) * Hi * Wi;
+    return launch_gemm<A_CONV3, EPI_HEAD>(h, p, st);
 }
 
 static int run_ln(sta_handle* h, const float* x, int M, int C, const LNp& a, const Planes& oa,
@@ -1084,11 +1112,13 @@ static int dpt_impl(sta_handle* h, Bump& ws, const float* enc, int64_t enc_bs,
     // head: 3x3 256->128, up x2, 3x3 128->128 + ReLU, 1x1 128->4 + postprocess (dpt_block.py:316-324)
     Planes h0 = act((int64_t)n * ph * pw, 128, dmx);
     Planes h0u = act((int64_t)n * H * W, 128, dmx);
-    Planes h2o = act((int64_t)n * H * W, 128, dmx);
+    const bool fused_tail = conv3_head_ok(h, h->head2, (int64_t)n * H * W);     // the [pixels,128] map of head.2 stays on chip
+    Planes h2o; if (!fused_tail) h2o = act((int64_t)n * H * W, 128, dmx);
     REQUIRE(!ws.overflow, "internal: dpt workspace overflow (head)");
     REQUIRE(2 * ph == H && 2 * pw == W, "internal: head size mismatch");
     CHK(conv3(h, path, n, ph, pw, 256, h->head0, 1, false, ACT_NONE, h0, nullptr, nullptr, st));
     CHK(run_up2(h, h0, n, ph, pw, 128, H, W, h0u, st));
+    if (fused_tail) return conv3_head(h, h0u, n, H, W, 128, h->head2, h->head4, ptsA, confA, nA, ptsB, confB, st);
     CHK(conv3(h, h0u, n, H, W, 128, h->head2, 1, false, ACT_RELU, h2o, nullptr, nullptr, st));
     for (int part = 0; part < 2 && !h->dry; ++part) {
         int i0 = part == 0 ? 0 : nA, cnt = part == 0 ? (nA < n ? nA : n) : n - nA;
