@@ -267,27 +267,32 @@ __global__ void fill_pose_token_kernel(float* x, int S, int ntok, int D, const f
 // ---------------------------------------------------------------------------------------------
 // Bilinear x2 upsample, align_corners=True (dpt_block.py:215-216,320), NHWC fp16 planes.
 // Output may be cropped to (Hc,Wc) <= (2Hi,2Wi) (dpt_head.py:58); interpolation ratios always use
-// the full (2Hi,2Wi) grid.  One thread = 8 channels of one output pixel.
+// the full (2Hi,2Wi) grid.  One workgroup = one output row (b, y): the row's taps / weights are block-uniform and the
+// per-element index math is 32-bit; one thread = 8 channels of one output pixel per step.
 template <bool SPLIT>
-__global__ void bilinear_up2_kernel(const f16* i_hi, const f16* i_lo, int n, int Hi, int Wi, int C,
-                                    int Hc, int Wc, f16* o_hi, f16* o_lo, int mx = 0 /* input and output are f16mx rows */) {
+__global__ __launch_bounds__(256) void bilinear_up2_kernel(const f16* i_hi, const f16* i_lo, int n, int Hi, int Wi, int C,
+                                                           int Hc, int Wc, f16* o_hi, f16* o_lo, int mx = 0 /* input and output are f16mx rows */) {
     const int c8 = C / 8;
-    const int64_t total = (int64_t)n * Hc * Wc * c8;
     const float ry = Hi > 1 ? (float)(Hi - 1) / (float)(2 * Hi - 1) : 0.f;
     const float rx = Wi > 1 ? (float)(Wi - 1) / (float)(2 * Wi - 1) : 0.f;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t step = (int64_t)gridDim.x * blockDim.x;
-    for (; i < total; i += step) {
-        int c = (int)(i % c8) * 8; int64_t t = i / c8;
-        int x = (int)(t % Wc); t /= Wc; int y = (int)(t % Hc); int b = (int)(t / Hc);
-        float sy = ry * y, sx = rx * x;
-        int y0 = (int)sy, x0 = (int)sx;
-        int y1 = y0 + (y0 < Hi - 1), x1 = x0 + (x0 < Wi - 1);
-        float fy = sy - y0, fx = sx - x0;
-        const size_t base = (size_t)b * Hi * Wi;
-        const int64_t irows = (int64_t)n * Hi * Wi;
-        const size_t o00 = blk_off<SPLIT>(base + (size_t)y0 * Wi + x0, c, irows), o01 = blk_off<SPLIT>(base + (size_t)y0 * Wi + x1, c, irows);
-        const size_t o10 = blk_off<SPLIT>(base + (size_t)y1 * Wi + x0, c, irows), o11 = blk_off<SPLIT>(base + (size_t)y1 * Wi + x1, c, irows);
+    const int b = blockIdx.x / Hc, y = blockIdx.x - b * Hc;
+    const float sy = ry * y;
+    const int y0 = (int)sy, y1 = y0 + (y0 < Hi - 1);
+    const float fy = sy - y0;
+    const int64_t irows = (int64_t)n * Hi * Wi, orows = (int64_t)n * Hc * Wc;
+    const size_t r0 = (size_t)b * Hi * Wi + (size_t)y0 * Wi, r1 = (size_t)b * Hi * Wi + (size_t)y1 * Wi;
+    const size_t orow = ((size_t)b * Hc + y) * Wc;
+    const bool pow2 = (c8 & (c8 - 1)) == 0;
+    const int sh = __ffs(c8) - 1;
+    const int per_row = Wc * c8;
+    for (int i = threadIdx.x; i < per_row; i += 256) {
+        const int x = pow2 ? i >> sh : i / c8;
+        const int c = (i - x * c8) * 8;
+        const float sx = rx * x;
+        const int x0 = (int)sx, x1 = x0 + (x0 < Wi - 1);
+        const float fx = sx - x0;
+        const size_t o00 = blk_off<SPLIT>(r0 + x0, c, irows), o01 = blk_off<SPLIT>(r0 + x1, c, irows);
+        const size_t o10 = blk_off<SPLIT>(r1 + x0, c, irows), o11 = blk_off<SPLIT>(r1 + x1, c, irows);
         H8 a, b_, c_, d; a.u = ldg16(i_hi + o00); b_.u = ldg16(i_hi + o01); c_.u = ldg16(i_hi + o10); d.u = ldg16(i_hi + o11);
         H8 al, bl, cl, dl;
         if (SPLIT) { al.u = ldg16(i_hi + o00 + 32); bl.u = ldg16(i_hi + o01 + 32); cl.u = ldg16(i_hi + o10 + 32); dl.u = ldg16(i_hi + o11 + 32); }
@@ -311,7 +316,7 @@ __global__ void bilinear_up2_kernel(const f16* i_hi, const f16* i_lo, int n, int
             vout[e] = v;
             if (SPLIT) split_f16(v, oh.e[e], ol.e[e]); else oh.e[e] = to_f16_sat(v);
         }
-        const size_t o = blk_off<SPLIT>(((size_t)b * Hc + y) * Wc + x, c, (int64_t)n * Hc * Wc);
+        const size_t o = blk_off<SPLIT>(orow + x, c, orows);
         if (SPLIT && mx) {
             store_mx4(o_hi, o, split_mx4<false>(vout)); store_mx4(o_hi, o + 4, split_mx4<false>(vout + 4));
             continue;

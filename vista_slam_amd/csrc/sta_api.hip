@@ -860,9 +860,8 @@ static int run_rows_to_planes(sta_handle* h, const float* x, int64_t bstride, in
 
 static int run_up2(sta_handle* h, const Planes& in, int n, int Hi, int Wi, int C, int Hc, int Wc, const Planes& out, hipStream_t st) {
     if (h->dry) return 0;
-    int64_t total = (int64_t)n * Hc * Wc * (C / 8);
-    int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
-    REQUIRE(in.mx == out.mx, "internal: bilinear format mismatch");
+    const int blocks = n * Hc;            // one workgroup per output row
+    REQUIRE(in.mx == out.mx && C % 8 == 0, "internal: bilinear format mismatch");
     if (h->prec != STA_PREC_F16) hipLaunchKernelGGL(bilinear_up2_kernel<true>, dim3(blocks), dim3(256), 0, st, in.hi, in.lo, n, Hi, Wi, C, Hc, Wc, out.hi, out.lo, in.mx ? 1 : 0);
     else hipLaunchKernelGGL(bilinear_up2_kernel<false>, dim3(blocks), dim3(256), 0, st, in.hi, in.lo, n, Hi, Wi, C, Hc, Wc, out.hi, out.lo, 0);
     HIPCHK(hipGetLastError());
