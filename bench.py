@@ -65,7 +65,8 @@ def summarize_gemm_records(recs, precision):
         g = groups.setdefault(sym, {"ms": 0.0, "fl": 0.0, "by": 0.0, "n": 0, "mx": mx, "epi": epi, "amode": amode, "fam": fam})
         g["ms"] += ms_; g["fl"] += 2.0 * M_ * N_ * K_; g["n"] += 1
         # algorithmic bytes: A and W planes (4 B per element in the split formats) once, output once (+ residual read)
-        g["by"] += 4.0 * (float(M_) * K_ / (9.0 if amode else 1.0) + float(N_) * K_) + 4.0 * M_ * N_ * (2.0 if epi == 5 else 1.0)
+        out_b = 16.0 * M_ if epi == 6 else 4.0 * M_ * N_ * (2.0 if epi == 5 else 1.0)     # fused DPT tail: pts (12 B) + conf (4 B) per pixel
+        g["by"] += 4.0 * (float(M_) * K_ / (9.0 if amode else 1.0) + float(N_) * K_) + out_b
     return groups
 
 
@@ -319,7 +320,8 @@ def main():
         # is directly comparable) carried a HIP-event pair in the timed region, recorded by the library on its launch stream;
         # achieved = sum of algorithmic 2MNK over those launches / sum of their event durations.
         epi_name = {0: "fp32 epilogue", 1: "fp16-plane epilogue", 2: "QKV + RoPE epilogue (attn.qkv, cross_attn.projq/k/v)",
-                    3: "ConvTranspose scatter epilogue", 4: "GELU epilogue (mlp.fc1)", 5: "in-place residual epilogue (attn.proj, mlp.fc2, cross_attn.proj)"}
+                    3: "ConvTranspose scatter epilogue", 4: "GELU epilogue (mlp.fc1)", 5: "in-place residual epilogue (attn.proj, mlp.fc2, cross_attn.proj)",
+                    6: "fused DPT tail (head.2 + ReLU + head.4 + point-map / confidence activations)"}
         groups = summarize_gemm_records(model.kernel_timing_records(), args.precision)
         model.kernel_timing(False)
         if groups:

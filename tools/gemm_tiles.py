@@ -70,7 +70,7 @@ def shapes(variants, steps=3):
     """Per-shape in-model duration (HIP events around every GEMM / conv launch) for each forced tile family."""
     import collections
     import ctypes as C
-    m = STAFrontend(W.FULL, "cuda:0", precision="f16x3").load_procedural(seed=43)
+    m = STAFrontend(W.FULL, "cuda:0", precision=os.environ.get("STA_PRECISION", "f16x3h")).load_procedural(seed=43)
     B, H, Wd = 8, 384, 512
     imgs = torch.from_numpy(W.synth_images(2 * B, H, Wd, seed=43, tag=0)).cuda()
     table = collections.OrderedDict()
@@ -88,16 +88,17 @@ def shapes(variants, steps=3):
         _lib.check(m.lib.sta_kernel_timing_dump_shapes(m._h, cap, sh, ms, var, C.byref(n)))
         m.kernel_timing(False)
         for i in range(n.value):
-            key = tuple(sh[6 * i + q] for q in range(5))
+            key = tuple(sh[6 * i + q] for q in range(6))
             table.setdefault(key, collections.defaultdict(list))[v].append((ms[i] * 1e3, var[i]))
-    epi = {0: "f32", 1: "f16", 2: "qkv", 3: "convT", 4: "gelu", 5: "f32r"}
-    print(f"{'M':>8s} {'N':>5s} {'K':>5s} {'epi':>5s} {'A':>4s} {'n/step':>6s} {'GF':>8s} | " + " | ".join(f"v{v}: us (TF) [family]" for v in variants))
+    epi = {0: "f32", 1: "f16", 2: "qkv", 3: "convT", 4: "gelu", 5: "f32r", 6: "head"}
+    print("(* = f16mx arithmetic: 2 MFMA units per algorithmic FLOP instead of 3)")
+    print(f"{'M':>8s} {'N':>5s} {'K':>5s} {'epi':>5s} {'A':>4s}  {'n/step':>5s} {'GF':>8s} | " + " | ".join(f"v{v}: us (TF) [family]" for v in variants))
     tot = {v: 0.0 for v in variants}
     for key, per in table.items():
-        M, N, K, e, a = key
+        M, N, K, e, a, mx = key
         gf = 2.0 * M * N * K / 1e9
         cnt = len(per[variants[0]]) // steps
-        row = f"{M:8d} {N:5d} {K:5d} {epi[e]:>5s} {'conv' if a else 'dns':>4s} {cnt:6d} {gf:8.2f} |"
+        row = f"{M:8d} {N:5d} {K:5d} {epi[e]:>5s} {'conv' if a else 'dns':>4s}{'*' if mx else ' '} {cnt:5d} {gf:8.2f} |"
         for v in variants:
             ts = [t for t, _ in per[v]]
             avg = sum(ts) / len(ts)
