@@ -134,8 +134,9 @@ struct Bump {
     Planes planes(int64_t elems, bool split) {      // row-major pair of planes (Q / K / V^T buffers)
         Planes p; p.hi = (f16*)take(elems * 2); p.lo = split ? (f16*)take(elems * 2) : nullptr; return p;
     }
-    Planes act(int64_t rows, int64_t cols, bool split) {   // blocked activation planes, cols % 32 == 0
+    Planes act(int64_t rows, int64_t cols, bool split) {   // blocked activation planes [ceil(cols/32)][rows][32 (+32)]
         Planes p; p.rp = rows;
+        cols = (cols + 31) & ~int64_t(31);                 // (a 16-column test tensor still occupies whole 32-column blocks)
         p.hi = (f16*)take(rows * cols * (split ? 4 : 2) + 256);
         p.lo = split ? p.hi + 32 : nullptr;
         return p;
