@@ -86,11 +86,13 @@ int sta_destroy(sta_handle* h);
 /* Change the arithmetic policy after creation (weights hold both split planes). */
 int sta_set_precision(sta_handle* h, int precision);
 
-/* Bit-reproducible mode.  At SLAM scale (a few hundred rows) the in-place residual GEMMs and the low-resolution DPT
- * convolutions split K over workgroups and combine the slices with fp32 atomics: fast, but the summation order - hence
- * the last bits of the result, and in principle a borderline `pose_conf < rel_pose_thres` decision (slam.py:169) - varies
- * run to run.  on != 0 disables every split-K path: identical bits on every run of the same binary, at a 1.5-2x cost for
- * B = 1 @224x224 (nothing changes at benchmark scale, where no GEMM is split).  Default: off. */
+/* Bit-reproducible mode.  At SLAM scale (a few hundred rows) the GEMMs and the low-resolution DPT convolutions split K
+ * over workgroups.  Since round 2 every product path combines the slices in a FIXED order (each slice stores its partial
+ * tile to its own fp32 slab; resid_ln_kernel / qkv_finish_kernel / splitk_finish_kernel sum them), so repeated runs of the
+ * same binary give identical bits by default.  One fp32-atomics split-K form is left (in-place residual GEMMs reached
+ * outside the fused GEMM + LayerNorm call, e.g. with a forced tile family): on != 0 disables it, at no cost on the product
+ * path.  (Why it matters: a borderline `pose_conf < rel_pose_thres` decision, slam.py:169, must not flip run to run.)
+ * Default: off. */
 int sta_set_deterministic(sta_handle* h, int on);
 
 /* Batch-slice concurrency of sta_forward_pair*: 1 = one slice on the caller's stream (default); n = 2..4: the batch is cut

@@ -658,8 +658,9 @@ def test_multi_gpu_layer_on_real_outputs_nccl_world1(G):
 
 
 def test_deterministic_mode_is_bit_reproducible_at_slam_scale(G):
-    """sta_set_deterministic: the B = 1 @224x224 split entry points (the regime whose GEMMs split K with fp32 atomics) give
-    identical bits on repeated runs, and stay within the parity bar of the default mode."""
+    """The B = 1 @224x224 split entry points (the regime whose GEMMs split K over workgroups) give identical bits on repeated
+    runs - in the default mode (K slices are combined in a fixed order: slabs) and with sta_set_deterministic, which takes the
+    same path on the product shapes."""
     import torch
     from helpers import rel_l2
     from vista_slam_amd import weights as W
@@ -676,14 +677,16 @@ def test_deterministic_mode_is_bit_reproducible_at_slam_scale(G):
         pose = m.head_pose_s(d1[-1][:, 0, :])
         torch.cuda.synchronize()
         return fa.clone(), d1[-1].clone(), pts["pts3d"].clone(), pose["conf"].clone()
-    ref = run()
+    ref, ref2 = run(), run()
+    for x, y in zip(ref, ref2):
+        assert torch.equal(x, y)                # default mode: no atomics on the product path any more
     m.set_deterministic(True)
     try:
         a, b = run(), run()
         for x, y in zip(a, b):
             assert torch.equal(x, y)
         for x, y in zip(a, ref):
-            assert rel_l2(x.cpu().numpy(), y.cpu().numpy()) < 1e-4
+            assert torch.equal(x, y) or rel_l2(x.cpu().numpy(), y.cpu().numpy()) < 1e-4
     finally:
         m.set_deterministic(False)
     G.drop_models()

@@ -76,7 +76,7 @@ struct sta_handle {
     sta_config cfg;
     int device = 0;
     int prec = STA_PREC_F16X3;
-    bool deterministic = false;   // sta_set_deterministic: no split-K (fp32 atomics): bit-reproducible results run to run
+    bool deterministic = false;   // sta_set_deterministic: no ATOMIC split-K (the slab forms have a fixed summation order anyway)
     int mx_mask = 0;          // CLS_* bits of the layer classes that run in the f16mx arithmetic (set by the precision mode)
     bool finalized = false;
     std::unordered_map<std::string, Slot> slots;
