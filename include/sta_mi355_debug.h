@@ -30,7 +30,9 @@ int sta_debug_gemm(sta_handle* h, const float* A, const float* W, const float* b
 
 /* qkv = Linear(x); RoPE2D(q), RoPE2D(k) (sta_blocks.py:132-138, pos_embed.py:169-185).
  * x [S*ntok,K], W [3C,K]; q,k out [S,C/64,ntok,64]; v out is the TRANSPOSED buffer
- * [S*C/64*64, roundup(ntok,64)] exactly as the attention kernel consumes it. */
+ * [S*C/64*64, roundup(ntok,64)] exactly as the attention kernel consumes it.
+ * has_pose_tok: 0 none, 1 = token 0 of every sequence (reference order), 2 = the decoder's row order: x = [S*ntok patch rows |
+ * S pose rows], outputs hold ntok + 1 tokens per sequence with the pose token last (roundup(ntok + 1, 64) columns of V^T). */
 int sta_debug_qkv_rope(sta_handle* h, const float* x, const float* W, const float* bias, int S, int ntok, int K, int C,
                        int wp, int has_pose_tok, float* q, float* k, float* v, void* stream);
 
@@ -38,6 +40,16 @@ int sta_debug_qkv_rope(sta_handle* h, const float* x, const float* W, const floa
  * q [S,heads,nq,64], k,v [S,heads,nk,64] -> out [S,nq,heads*64]. */
 int sta_debug_attention(sta_handle* h, const float* q, const float* k, const float* v, int S, int heads,
                         int nq, int nk, int kv_shift, float* out, void* stream);
+
+/* The decoder form of the same kernel: q, k, v [S,heads,n+1,64] with the pose token LAST (as a key it is folded into the
+ * initial softmax state, as a query it is served by the pose blocks) -> out [S*n + S, heads*64] in the decoder's row order
+ * (patch rows sequence-major, then the S pose rows).  sta_blocks.py:129-148,201-205 on n + 1 tokens. */
+int sta_debug_attention_pose(sta_handle* h, const float* q, const float* k, const float* v, int S, int heads,
+                             int n, int kv_shift, float* out, void* stream);
+
+/* Row-tail hint for the dense GEMMs (what the decoder sets to its 2B pose-token rows): the last `rows` (<= 32) rows of the
+ * following sta_debug_gemm calls are computed by skinny tail blocks when the shape qualifies.  Sticky; 0 resets. */
+int sta_debug_set_tail_hint(sta_handle* h, int rows);
 
 /* nn.Conv2d 3x3 pad 1 stride 1|2 on NHWC data, weights in the reference [Co,Cin,3,3] layout;
  * optional ReLU on the input, activation on the output, residual add (dpt_block.py:94-142). */

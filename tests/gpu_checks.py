@@ -119,6 +119,72 @@ def check_attention(precision, S=2, heads=2, nq=197, nk=197, kv_shift=0, sharp=1
     return {"rel_l2": rel_l2(o, ref.numpy()), "max_rel": max_rel(o, ref.numpy()), "nan": float(np.isnan(o).sum())}
 
 
+def check_gemm_tail(precision, tiles_m=8, tail=16, N=2304, K=256, act=0, via_f16=0, resid=False, variant=0, seed=11):
+    """Dense GEMM whose last `tail` rows run on the skinny tail blocks (GemmParams::m_tail, the decoder's pose-token
+    rows): M = tiles_m x 192 (or 256) + tail at a size where the throughput families are selected."""
+    m, lib, h = kernel_handle(precision, variant)
+    bm = 256 if variant == 2 else 192
+    M = tiles_m * bm + tail
+    _lib.check(lib.sta_debug_set_tail_hint(h, tail))
+    try:
+        r = check_gemm(precision, M=M, N=N, K=K, act=act, via_f16=via_f16, resid=resid, seed=seed, variant=variant)
+    finally:
+        _lib.check(lib.sta_debug_set_tail_hint(h, 0))
+    return r
+
+
+def check_qkv_rope_decoder_rows(precision, S=2, hp=3, wp=4, K=128, Cdim=128, seed=12, variant=0):
+    """QKV + RoPE epilogue on the decoder's row order: x = [S*N patch rows | S pose rows]; the buffers hold N + 1 tokens per
+    sequence with the pose token (position -1) last."""
+    m, lib, h = kernel_handle(precision, variant)
+    g = torch.Generator().manual_seed(seed)
+    N = hp * wp
+    ntok = N + 1
+    xs = torch.randn(S, ntok, K, generator=g)                 # reference order: pose token first
+    Wt = torch.randn(3 * Cdim, K, generator=g) * 0.1
+    b = torch.randn(3 * Cdim, generator=g) * 0.1
+    heads = Cdim // 64
+    npad = (ntok + 63) // 64 * 64
+    x_dec = torch.cat([xs[:, 1:].reshape(S * N, K), xs[:, 0]], 0).contiguous()
+    q = torch.empty(S, heads, ntok, 64, device=DEV)
+    k = torch.empty_like(q)
+    vt = torch.empty(S * heads * 64, npad, device=DEV)
+    xd, Wd, bd = x_dec.to(DEV), Wt.to(DEV), b.to(DEV)
+    _lib.check(lib.sta_debug_qkv_rope(h, xd.data_ptr(), Wd.data_ptr(), bd.data_ptr(), S, N, K, Cdim,
+                                      wp, 2, q.data_ptr(), k.data_ptr(), vt.data_ptr(), st()))
+    torch.cuda.synchronize()
+    y = (xs.reshape(S * ntok, K).double() @ Wt.double().T + b.double()).float().reshape(S, ntok, 3, heads, 64).permute(2, 0, 3, 1, 4).numpy()
+    pos = grid_pos(S, hp, wp, pose_tok=True)
+    qr, kr, vr = rope2d_ref(y[0], pos), rope2d_ref(y[1], pos), y[2]
+    order = list(range(1, ntok)) + [0]                          # device token order: patches, then the pose token
+    v = vt.cpu().numpy().reshape(S, heads, 64, npad)[..., :ntok].transpose(0, 1, 3, 2)
+    pad = vt.cpu().numpy().reshape(S, heads, 64, npad)[..., ntok:]
+    return {"q": max_rel(q.cpu().numpy(), qr[:, :, order]), "k": max_rel(k.cpu().numpy(), kr[:, :, order]), "v": max_rel(v, vr[:, :, order]),
+            "vpad_abs": float(np.abs(pad).max()) if pad.size else 0.0}
+
+
+def check_attention_pose(precision, S=2, heads=2, n=196, kv_shift=0, sharp=1.0, seed=13):
+    """Decoder form of the attention kernel: n patch tokens + the pose token (last): as a key it is folded into the initial
+    softmax state, as a query it is served by the pose blocks."""
+    m, lib, h = kernel_handle(precision)
+    g = torch.Generator().manual_seed(seed)
+    nt = n + 1
+    q = torch.randn(S, heads, nt, 64, generator=g) * sharp
+    k = torch.randn(S, heads, nt, 64, generator=g)
+    v = torch.randn(S, heads, nt, 64, generator=g)
+    idx = [(s + kv_shift) % S for s in range(S)]
+    a = (q.double() @ k[idx].double().transpose(-1, -2)) * 0.125
+    ref = (a.softmax(-1) @ v[idx].double()).permute(0, 2, 1, 3).reshape(S, nt, heads * 64)
+    ref = torch.cat([ref[:, :n].reshape(S * n, heads * 64), ref[:, n]], 0)       # decoder row order
+    out = torch.empty(S * n + S, heads * 64, device=DEV)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    _lib.check(lib.sta_debug_attention_pose(h, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), S, heads, n, kv_shift, out.data_ptr(), st()))
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    return {"rel_l2": rel_l2(o, ref.numpy()), "rel_l2_pose": rel_l2(o[S * n:], ref.numpy()[S * n:]),
+            "max_rel": max_rel(o, ref.numpy()), "nan": float(np.isnan(o).sum())}
+
+
 def check_conv3(precision, n=2, H=7, W_=5, Cin=32, Co=48, stride=1, relu_in=0, act=0, resid=False, seed=3, variant=0):
     m, lib, h = kernel_handle(precision, variant)
     g = torch.Generator().manual_seed(seed)

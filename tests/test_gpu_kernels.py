@@ -41,6 +41,32 @@ def test_qkv_rope(G, prec, kw):
     assert r["vpad_abs"] == 0.0, "V^T padding must stay zero (0 * garbage = NaN otherwise)"
 
 
+@pytest.mark.parametrize("prec", ["f16x3", "f16"])
+@pytest.mark.parametrize("kw", [dict(), dict(resid=True), dict(act=1, via_f16=1), dict(variant=3, N=768, K=1024, tiles_m=22, resid=True),
+                                dict(variant=2, N=4096, K=128, tiles_m=6, act=1, via_f16=1), dict(tail=1), dict(tail=32, resid=True)])
+def test_gemm_tail_rows(G, prec, kw):
+    """Skinny tail blocks (the decoder's pose-token rows) on every family / epilogue the decoder uses them with."""
+    r = G.check_gemm_tail(prec, **kw)
+    assert r["rel_l2"] < TOL[prec], r
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("kw", [dict(), dict(hp=14, wp=14, S=2), dict(hp=14, wp=14, S=2, variant=3), dict(hp=24, wp=32, S=4, K=64)])
+def test_qkv_rope_decoder_rows(G, prec, kw):
+    r = G.check_qkv_rope_decoder_rows(prec, **kw)
+    assert r["q"] < TOL[prec] and r["k"] < TOL[prec] and r["v"] < TOL[prec], r
+    assert r["vpad_abs"] == 0.0, r
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("kw", [dict(), dict(kv_shift=1), dict(n=768, S=2, heads=1, sharp=3.0), dict(n=12, sharp=6.0), dict(n=64),
+                                dict(n=129, sharp=10.0, S=3, heads=1, kv_shift=2)])
+def test_attention_pose_token(G, prec, kw):
+    r = G.check_attention_pose(prec, **kw)
+    assert r["nan"] == 0, r
+    assert r["rel_l2"] < TOL[prec] and r["rel_l2_pose"] < TOL[prec], r
+
+
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("kw", [dict(), dict(kv_shift=1), dict(nq=70, nk=130, sharp=6.0),
                                 dict(S=1, heads=1, nq=769, nk=769, sharp=3.0), dict(nq=1, nk=1), dict(nq=64, nk=64),

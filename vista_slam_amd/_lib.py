@@ -78,6 +78,8 @@ SIGNATURES = {
     "sta_debug_gemm": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _vp]),
     "sta_debug_qkv_rope": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _vp]),
     "sta_debug_attention": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _vp]),
+    "sta_debug_attention_pose": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _vp]),
+    "sta_debug_set_tail_hint": (_i, [_vp, _i]),
     "sta_debug_conv3x3": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _fp, _fp, _vp]),
     "sta_debug_convt": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _vp]),
     "sta_debug_up2": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _i, _fp, _vp]),
@@ -91,6 +93,19 @@ _lib = None
 
 class StaError(RuntimeError):
     pass
+
+
+def load_other(path):
+    """A SECOND build of the library next to the product one (tools/ab_inproc.py: same-process A/B of two builds).  Binds
+    the symbols that build exports; never used by the product path."""
+    import torch  # noqa: F401
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
+    return lib
 
 
 def load():

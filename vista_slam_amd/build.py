@@ -25,11 +25,23 @@ def hipcc_path():
 HASH_FILE = LIB + ".srchash"
 
 
+def extra_flags():
+    """STA_DEV_FAST=1: development build without the precision-f16 kernel forms (half the compile time; the f16 tests fail
+    loudly on it).  STA_BENCH_EXPERIMENTS=1: the retired tile shapes / main-loop ablations of tools/gemm_tiles.py."""
+    f = []
+    if os.environ.get("STA_DEV_FAST") == "1":
+        f.append("-DSTA_DEV_FAST")
+    if os.environ.get("STA_BENCH_EXPERIMENTS") == "1":
+        f.append("-DSTA_BENCH_EXPERIMENTS")
+    return f
+
+
 def source_hash():
     """Content hash of every source the library is built from (mtimes do not survive the gpurun
-    snapshot copy, so staleness is decided by content)."""
+    snapshot copy, so staleness is decided by content) and of the build flags."""
     import hashlib
     h = hashlib.sha256()
+    h.update(" ".join(extra_flags()).encode())
     for d in DEPS:
         with open(os.path.join(CSRC, d), "rb") as f:
             h.update(f.read())
@@ -50,7 +62,7 @@ def build_lib(force=False, verbose=True):
     if hipcc is None:
         raise RuntimeError("hipcc not found: cannot build libsta_mi355.so (ROCm toolchain required)")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-o", LIB] + extra_flags() + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)

@@ -32,6 +32,9 @@ struct AttnParams {
     int kv_shift;            // K/V come from sequence (s + kv_shift) % S
     float scale_log2e;       // head_dim^-0.5 * log2(e)
     int o_mx;                // write the output planes in the f16mx row format (the consumer is an f16mx GEMM)
+    int pose;                // decoder: token index nk (== nq) of Q / K / V^T is the pose token.  As a KEY it is folded into the
+                             // initial online-softmax state of every query (no 13th key tile for one key); as a QUERY it is served by
+                             // the pose blocks (one wave per (sequence, head), plain fp32 dot products); its output row is S*nq + s
 };
 
 #define ATT_KV 64
@@ -40,11 +43,86 @@ struct AttnParams {
 template <bool SPLIT>
 constexpr int attn_smem_bytes() { return 2 * (SPLIT ? 4 : 2) * ATT_TILE_BYTES; }
 
+// The pose-token query of one (sequence, head) per wave: 1 x (nk + 1) scores, softmax and 1 x 64 output as fp32 dot products
+// (an MFMA tile would carry 31 dead queries through every key tile).  Phase 1: lane = key (K rows are 128 contiguous bytes),
+// phase 2: wave-wide max / sum, probabilities parked in LDS, phase 3: lane = d (V^T rows are contiguous along the keys).
+template <bool SPLIT>
+__device__ __forceinline__ void attn_pose_query(const AttnParams& p, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nsh = p.S * p.heads;
+    int sh = blockIdx.x * 4 + wave;
+    const bool live = sh < nsh;
+    if (!live) sh = nsh - 1;                                  // duplicate work, no store: every wave reaches the barriers
+    const int s = sh / p.heads, h = sh - s * p.heads;
+    const int skv = (s + p.kv_shift) % p.S;
+    const size_t qoff = ((size_t)(s * p.heads + h) * p.npad + p.nq) * 64;
+    const size_t koff = (size_t)(skv * p.heads + h) * p.npad * 64;
+    const size_t voff = (size_t)(skv * p.heads + h) * 64 * p.npad;
+    float* pl = reinterpret_cast<float*>(smem) + (size_t)wave * p.npad;
+    float q[64];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        H8 a, b; a.u = ldg16(p.Q_hi + qoff + c * 8);
+        if (SPLIT) b.u = ldg16(p.Q_lo + qoff + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[c * 8 + e] = (float)a.e[e] + (SPLIT ? (float)b.e[e] : 0.f);
+    }
+    const int nkeys = p.nk + 1;
+    float mx = -INFINITY;
+    for (int j = lane; j < p.npad; j += 64) {
+        float t = -INFINITY;
+        if (j < nkeys) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                H8 a, b; a.u = ldg16(p.K_hi + koff + (size_t)j * 64 + c * 8);
+                if (SPLIT) b.u = ldg16(p.K_lo + koff + (size_t)j * 64 + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(q[c * 8 + e], (float)a.e[e] + (SPLIT ? (float)b.e[e] : 0.f), acc);
+            }
+            t = acc * p.scale_log2e;
+        }
+        pl[j] = t;
+        mx = fmaxf(mx, t);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int j = lane; j < p.npad; j += 64) {
+        const float e = __builtin_amdgcn_exp2f(pl[j] - mx);       // exp2(-inf) = 0 for the padding
+        pl[j] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    __syncthreads();
+    const f16* vh = p.Vt_hi + voff + (size_t)lane * p.npad;
+    const f16* vl = SPLIT ? p.Vt_lo + voff + (size_t)lane * p.npad : nullptr;
+    float o = 0.f;
+    for (int c = 0; c < p.npad; c += 8) {                          // V^T columns >= nkeys are zero (memset) and their p is 0
+        H8 a, b; a.u = ldg16(vh + c);
+        if (SPLIT) b.u = ldg16(vl + c);
+        const float4 p0 = *reinterpret_cast<const float4*>(pl + c), p1 = *reinterpret_cast<const float4*>(pl + c + 4);
+        const float pe[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o = __builtin_fmaf(pe[e], (float)a.e[e] + (SPLIT ? (float)b.e[e] : 0.f), o);
+    }
+    if (!live) return;
+    o /= sum;
+    const int64_t orow = (int64_t)p.S * p.nq + s, orows = (int64_t)p.S * p.nq + p.S;
+    const size_t oo = blk_off<SPLIT>(orow, h * 64 + lane, orows);
+    if (SPLIT && p.o_mx) store_mx1<false>(p.O_hi, oo, o);
+    else if (SPLIT) { f16 hh, ll; split_f16(o, hh, ll); p.O_hi[oo] = hh; p.O_hi[oo + 32] = ll; }
+    else p.O_hi[oo] = to_f16_sat(o);
+}
+
 template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NPL = SPLIT ? 2 : 1;
     constexpr int STAGE = 2 * NPL * ATT_TILE_BYTES;   // K planes then V^T planes
+    // pose blocks first in the grid (short: they end while the first round of query blocks is still running)
+    const int npose_blocks = p.pose ? (p.S * p.heads + 3) / 4 : 0;
+    if ((int)blockIdx.x < npose_blocks) { attn_pose_query<SPLIT>(p, smem); return; }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -54,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     const int nwg = nqb * p.heads * p.S;
     int logical;
     {
-        const int bid = blockIdx.x, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+        const int bid = blockIdx.x - npose_blocks, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
     }
     const int qb = logical % nqb;
@@ -115,6 +193,32 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
         for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;       // running max in scaled (log2) units
     const bool wave_active = q0 < p.nq;         // decoder: 769 = 6 x 128 + 1 queries -> the last block has one live wave
+
+    // ---- the pose token as a key (index nk): initial online-softmax state m = s_p, l = 1, O = v_p in fp32
+    if (p.pose && wave_active) {
+        float sp = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            H8 a, b; a.u = ldg16(p.K_hi + koff + (size_t)p.nk * 64 + kk * 16 + lhi * 8);
+            if (SPLIT) b.u = ldg16(p.K_lo + koff + (size_t)p.nk * 64 + kk * 16 + lhi * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float kv = (float)a.e[e] + (SPLIT ? (float)b.e[e] : 0.f);
+                const float qv = (float)qf_hi[kk][e] + (SPLIT ? (float)qf_lo[kk][e] : 0.f);
+                sp = __builtin_fmaf(qv, kv, sp);
+            }
+        }
+        sp += __shfl_xor(sp, 32);
+        m_run = sp * p.scale_log2e;
+        l_run = lhi == 0 ? 1.f : 0.f;              // the two lane halves of a query add their l at the end
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const size_t o = voff + (size_t)(d * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * p.npad + p.nk;
+                oacc[d][r] = (float)p.Vt_hi[o] + (SPLIT ? (float)p.Vt_lo[o] : 0.f);
+            }
+    }
 
     // per-lane fragment byte offset inside a plane tile: row l31 (+32 rows = +4096 B: same swizzle since 16 & 7 == 0),
     // chunk c = 2*kk + lhi -> (c ^ swz) << 4  (identical for K rows = keys and V^T rows = d)
@@ -265,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     const float inv = 1.0f / l_tot;
     const int q = q0 + l31;
     if (q < p.nq) {
-        const int64_t orow = (int64_t)s * p.nq + q, orows = (int64_t)p.S * p.nq;
+        const int64_t orow = (int64_t)s * p.nq + q, orows = (int64_t)p.S * p.nq + (p.pose ? p.S : 0);
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll

@@ -264,6 +264,19 @@ __global__ void fill_pose_token_kernel(float* x, int S, int ntok, int D, const f
     if (i < S * D) { int s = i / D, d = i - s * D; x[(size_t)s * ntok * D + d] = tok[d]; }
 }
 
+// Decoder rows -> the reference's token order: out[b, 0, :] = pose row of sequence s0 + b, out[b, 1 + t, :] = patch row
+// (s0 + b) * N + t  (x: [S*N patch rows | S pose rows], pose_row0 = S*N; sta_model.py:206-213 prepends the pose token)
+__global__ void emit_tokens_kernel(const float* x, int s0, int B, int N, int D, int64_t pose_row0, float* out) {
+    const int d4 = D / 4;
+    const int64_t total = (int64_t)B * (N + 1) * d4, step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const int c = (int)(i % d4); const int64_t r = i / d4;
+        const int t = (int)(r % (N + 1)); const int b = (int)(r / (N + 1));
+        const int64_t src = t == 0 ? pose_row0 + s0 + b : (int64_t)(s0 + b) * N + (t - 1);
+        reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(x + src * D)[c];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Bilinear x2 upsample, align_corners=True (dpt_block.py:215-216,320), NHWC fp16 planes.
 // Output may be cropped to (Hc,Wc) <= (2Hi,2Wi) (dpt_head.py:58); interpolation ratios always use

@@ -39,6 +39,9 @@ struct GemmParams {
     // ---- B operand (weights, [N,K] planes) and bias
     const f16* B_hi; const f16* B_lo; const float* bias;
     int M, N, K;
+    int m_tail;                                          // gemm2 families: the last m_tail (<= 32) rows are computed by skinny tail
+                                                         //     blocks (one 32-row MFMA tile per wave, K split over the waves) instead
+                                                         //     of a (BM-row) tile row of their own; (M - m_tail) % BM == 0
     int mx;                                              // A and B are f16mx rows (sta_common.h); dense GEMMs only
     // ---- EPI_F32
     float* C32; int ldc; const float* resid; int ldr;
@@ -60,6 +63,9 @@ struct GemmParams {
     // ---- EPI_QKV
     f16* Q_hi; f16* Q_lo; f16* K_hi; f16* K_lo; f16* Vt_hi; f16* Vt_lo;
     int nq, nk, nv, ntok, npad, heads, wp, has_pose_tok;
+    int pose_base;                                       // > 0: rows >= pose_base are the pose tokens of sequences row - pose_base,
+                                                         //     stored at token index ntok of the Q / K / V^T buffers (decoder row order
+                                                         //     [S x ntok patch rows | S pose rows]; has_pose_tok must be 0)
     unsigned ntok_magic, wp_magic;                       // floor(2^32/d)+1 (0 when d == 1): exact n/d for n*d < 2^32
     const float* rope_tab;                               // [(pos+1)][16][2] cos,sin ; pos = -1 .. P-1
     // ---- EPI_CONVT
@@ -99,6 +105,18 @@ __device__ __forceinline__ uint4 relu_pair_hi(uint4 hi, uint4& lo) {
 __device__ __forceinline__ int fast_div(int n, int d, unsigned magic) {
     return magic ? (int)__umulhi((unsigned)n, magic) : n;   // magic == 0 encodes d == 1
 }
+// QKV epilogue: GEMM row -> (sequence, token index in the Q / K / V^T buffers, is it the pose token)
+__device__ __forceinline__ void qkv_row_token(const GemmParams& p, int row, int& s, int& t, bool& pose) {
+    if (p.pose_base > 0 && row >= p.pose_base) { s = row - p.pose_base; t = p.ntok; pose = true; }
+    else { s = fast_div(row, p.ntok, p.ntok_magic); t = row - s * p.ntok; pose = p.has_pose_tok && t == 0; }
+}
+// table row of the RoPE cos/sin table for token t along the y (xpart == 0) or x axis; row 0 == position -1 (pose token)
+__device__ __forceinline__ int qkv_rope_pos(const GemmParams& p, int t, bool pose, int xpart) {
+    if (pose) return 0;
+    const int tt = p.has_pose_tok ? t - 1 : t;
+    const int ty = fast_div(tt, p.wp, p.wp_magic);
+    return (xpart ? tt - ty * p.wp : ty) + 1;
+}
 typedef uint2 __attribute__((aligned(2))) uint2_a2;   // 8-byte store of 4 halves at 2-byte alignment
 
 // QKV epilogue of one 32x32 accumulator tile: +bias, 2-D RoPE on q/k (pair partner = lane^16, cos/sin
@@ -119,7 +137,8 @@ __device__ __forceinline__ void epilogue_qkv_tile(const GemmParams& p, const flo
         for (int g = 0; g < 4; ++g) {
             const int rowg = row0 + 8 * g + 4 * lhi;
             const int rc = rowg < p.M ? rowg : p.M - 1;
-            const int s = fast_div(rc, p.ntok, p.ntok_magic), t = rc - s * p.ntok;
+            int s, t; bool pose_row;
+            qkv_row_token(p, rc, s, t, pose_row);
             f16 hh[4], ll[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -138,7 +157,8 @@ __device__ __forceinline__ void epilogue_qkv_tile(const GemmParams& p, const flo
                 for (int e = 0; e < 4; ++e) {
                     const int row = rowg + e;
                     if (row < p.M) {
-                        const int s2 = fast_div(row, p.ntok, p.ntok_magic), t2 = row - s2 * p.ntok;
+                        int s2, t2; bool pr2;
+                        qkv_row_token(p, row, s2, t2, pr2);
                         const size_t o2 = ((size_t)(s2 * p.heads + head) * 64 + dcol) * p.npad + t2;
                         p.Vt_hi[o2] = hh[e];
                         if (SPLIT) p.Vt_lo[o2] = ll[e];
@@ -154,10 +174,9 @@ __device__ __forceinline__ void epilogue_qkv_tile(const GemmParams& p, const flo
     for (int r = 0; r < 16; ++r) {
         const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
         const int rowc = row < p.M ? row : p.M - 1;
-        const int s = fast_div(rowc, p.ntok, p.ntok_magic), t = rowc - s * p.ntok;
-        const int tt = p.has_pose_tok ? t - 1 : t;
-        const int ty = tt < 0 ? 0 : fast_div(tt, p.wp, p.wp_magic);
-        const int pos = tt < 0 ? 0 : (xpart ? tt - ty * p.wp : ty) + 1;   // table row 0 == position -1 (pose token)
+        int s, t; bool pose_row;
+        qkv_row_token(p, rowc, s, t, pose_row);
+        const int pos = qkv_rope_pos(p, t, pose_row, xpart);               // table row 0 == position -1 (pose token)
         const float2 cs = *reinterpret_cast<const float2*>(p.rope_tab + ((size_t)pos * 16 + (lane & 15)) * 2);
         float v = acc[r] + bv;
         const float other = __shfl_xor(v, 16);
@@ -292,10 +311,9 @@ __global__ __launch_bounds__(256) void qkv_finish_kernel(const GemmParams p) {
         for (int s = 0; s < p.ksplit; ++s) v += p.skbuf[((size_t)s * p.M + row) * p.N + c];
         const int seg = c >= p.nq ? 1 : 0, cc = c - (seg ? p.nq : 0);
         const int head = cc >> 6, dcol = cc & 63, xpart = (dcol >> 5) & 1;
-        const int s_ = fast_div(row, p.ntok, p.ntok_magic), t = row - s_ * p.ntok;
-        const int tt = p.has_pose_tok ? t - 1 : t;
-        const int ty = tt < 0 ? 0 : fast_div(tt, p.wp, p.wp_magic);
-        const int pos = tt < 0 ? 0 : (xpart ? tt - ty * p.wp : ty) + 1;
+        int s_, t; bool pose_row;
+        qkv_row_token(p, row, s_, t, pose_row);
+        const int pos = qkv_rope_pos(p, t, pose_row, xpart);
         const float2 cs = *reinterpret_cast<const float2*>(p.rope_tab + ((size_t)pos * 16 + (lane & 15)) * 2);
         const float other = __shfl_xor(v, 16);
         v = (lane & 16) ? (v * cs.x + other * cs.y) : (v * cs.x - other * cs.y);
@@ -321,7 +339,8 @@ __global__ __launch_bounds__(256) void qkv_finish_kernel(const GemmParams p) {
         if (SPLIT) split_f16(v, hh[e], ll[e]); else { hh[e] = to_f16_sat(v); ll[e] = (f16)0; }
     }
     const int row0 = g * 4;
-    const int s0 = fast_div(row0, p.ntok, p.ntok_magic), t0 = row0 - s0 * p.ntok;
+    int s0, t0; bool pr0;
+    qkv_row_token(p, row0 < p.M ? row0 : p.M - 1, s0, t0, pr0);
     if (row0 + 3 < p.M && t0 + 3 < p.ntok) {
         const size_t o = ((size_t)(s0 * p.heads + head) * 64 + dcol) * p.npad + t0;
         H4 ph, pl;
@@ -334,7 +353,8 @@ __global__ __launch_bounds__(256) void qkv_finish_kernel(const GemmParams p) {
         for (int e = 0; e < 4; ++e) {
             const int row = row0 + e;
             if (row < p.M) {
-                const int s2 = fast_div(row, p.ntok, p.ntok_magic), t2 = row - s2 * p.ntok;
+                int s2, t2; bool pr2;
+                qkv_row_token(p, row, s2, t2, pr2);
                 const size_t o2 = ((size_t)(s2 * p.heads + head) * 64 + dcol) * p.npad + t2;
                 p.Vt_hi[o2] = hh[e];
                 if (SPLIT) p.Vt_lo[o2] = ll[e];

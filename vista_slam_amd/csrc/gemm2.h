@@ -104,8 +104,74 @@ __device__ __forceinline__ void head_epilogue(const GemmParams& p, const floatx1
     }
 }
 
+// Skinny tail of a dense GEMM (GemmParams::m_tail <= 32 rows after a whole number of BM-row tiles; the decoder's M = 2B x
+// (768 patch tokens) + 2B pose tokens is 64 tiles of 192 rows + 16 rows).  A tile row of their own would cost every N tile a
+// BM-row tile for 16 rows - and, worse, a whole extra round of the 512 resident slots (65 x 24 tiles = 3.05 rounds).
+// Tail block tb owns the 32 columns [32 tb, 32 tb + 32): its NW waves split K between them, every wave runs one
+// 32x32 MFMA tile straight from global memory (the operands are L2-hot: the main tiles stream the same weights), the
+// partial tiles meet in LDS and wave 0 runs the ordinary epilogue.  ~2-4 us of work per block, dispatched first.
+template <bool SPLIT, int EPI, int NW>
+__device__ __forceinline__ void gemm2_tail(const GemmParams& p, const int tb, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int A_ES = SPLIT ? 64 : 32;
+    const int row0 = p.M - p.m_tail, col0 = tb * 32;
+    const int arow = row0 + l31 < p.M ? row0 + l31 : p.M - 1;
+    const int brow = col0 + l31 < p.N ? col0 + l31 : p.N - 1;
+    const f16* ap = p.A_hi + (size_t)arow * A_ES + lhi * 8;
+    const f16* bp = p.B_hi + (size_t)brow * 64 + lhi * 8;
+    const size_t a_kstride = (size_t)p.a_rp * A_ES, b_kstride = (size_t)p.N * 64;
+    const int nkt_all = p.K / GEMM_BK;
+    const int kt0 = (int)((int64_t)wave * nkt_all / NW), kt1 = (int)((int64_t)(wave + 1) * nkt_all / NW);
+    struct Frag { uint4 ah[2], al[2], bh[2], bl[2]; };
+    auto load = [&](int kt, Frag& f) {
+        const f16* a = ap + kt * a_kstride;
+        const f16* b = bp + kt * b_kstride;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f.ah[ks] = ldg16(a + ks * 16); f.bh[ks] = ldg16(b + ks * 16);
+            if (SPLIT) { f.al[ks] = ldg16(a + 32 + ks * 16); f.bl[ks] = ldg16(b + 32 + ks * 16); }
+        }
+    };
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    auto mma = [&](const Frag& f) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            H8 ah, al, bh, bl; ah.u = f.ah[ks]; bh.u = f.bh[ks];
+            if (SPLIT) {
+                al.u = f.al[ks]; bl.u = f.bl[ks];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.h, bh.h, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h, bl.h, acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h, bh.h, acc, 0, 0, 0);
+        }
+    };
+    // one K tile in flight per wave (32 VGPRs of fragments: the tail must stay under the register budget of the main loop it
+    // shares a kernel with - two 192x128 workgroups per CU need <= 128); the NW waves of the block and the other resident
+    // blocks cover the load latency
+#pragma unroll 1
+    for (int kt = kt0; kt < kt1; ++kt) {
+        Frag f;
+        load(kt, f);
+        mma(f);
+    }
+    float* red = reinterpret_cast<float*>(smem);    // [NW][16][64]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll 1
+    for (int w = 1; w < NW; ++w) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += red[(w * 16 + r) * 64 + lane];
+    }
+    epilogue_tile<SPLIT, EPI>(p, acc, row0, col0 + l31, lane, 0);
+}
+
 template <bool SPLIT, int AMODE, int EPI, int BM, int BN, int WAVES_M, int WAVES_N, int ABL = 0, int NSTG = 2, bool MX = false>
-__device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_id) {
+__device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_id_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MT = WM / 32, NT = WN / 32;
@@ -118,6 +184,17 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
     constexpr int A_ES = SPLIT ? 64 : 32;                    // global elements per activation row block
     static_assert(BM % 32 == 0 && BN % 32 == 0 && WM % 32 == 0 && WN % 32 == 0, "tile/wave mismatch");
 
+    // skinny tail blocks come first in the grid (launch_gemm2 adds them): short, they overlap the first round of tiles
+    int block_id = block_id_in;
+    constexpr bool HAS_TAIL = AMODE == A_DENSE && !MX && NSTG == 2 && ABL == 0 && BM >= 192 &&
+                              (EPI == EPI_F32 || EPI == EPI_F32R || EPI == EPI_GELU || EPI == EPI_QKV);
+    if constexpr (HAS_TAIL) {
+        if (p.m_tail > 0) {
+            const int ntail = (p.N + 31) >> 5;
+            if (block_id < ntail) { gemm2_tail<SPLIT, EPI, NW>(p, block_id, smem); return; }
+            block_id -= ntail;
+        }
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -126,7 +203,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
     if (p.clk_dbg) { clk0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 
     // ---- block id -> (tile, K slice) (XCD-aware, band-major; the slices of one tile are consecutive ids)
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M - (HAS_TAIL ? p.m_tail : 0) + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
     const int nwg = tiles_m * tiles_n * ksplit;
     int t;

@@ -37,6 +37,14 @@ struct DevScope {
 #define DEV_SCOPE(dev) DevScope dev_scope_(dev); do { if (!dev_scope_.ok) return set_err("hipSetDevice(%d) failed", (int)(dev)); } while (0)
 #define REQUIRE(c, ...) do { if (!(c)) return set_err(__VA_ARGS__); } while (0)
 
+// Development builds (python -m vista_slam_amd.build with STA_DEV_FAST=1; never shipped): the single-product f16 forms of the
+// MFMA kernels are not instantiated - half the compile time while iterating on the f16x3 path.
+#ifdef STA_DEV_FAST
+#define STA_F16ONLY(x) return set_err("development build (-DSTA_DEV_FAST): precision f16 kernels are not compiled in")
+#else
+#define STA_F16ONLY(x) x
+#endif
+
 // ------------------------------------------------------------------------------------------ types
 // fp16 planes.  Activations / weights use the K-tile-blocked layout [cols/32][rp rows][hi32|lo32]
 // (lo == hi + 32 in f16x3, lo == nullptr in f16); rp == 0 marks the row-major Q/K/V^T buffers.
@@ -97,6 +105,7 @@ struct sta_handle {
     float* skbuf = nullptr;   // fp32 partial sums of split-K GEMMs with the plane epilogue (SKBUF_SLOTS x SKBUF_ELEMS floats)
     float* slab = nullptr;    // slab split-K of the small-M in-place residual GEMMs (GemmParams::slab), same slots and size as skbuf
     int slab_ks = 0;          // set by launch_gemm: K slices the last slab GEMM wrote (0: it did not take the slab path)
+    int tail_hint = 0;      // decode_impl: the last tail_hint rows of every dense GEMM are pose-token rows (GemmParams::m_tail)
     int gemm_variant = 0;   // 0 auto, 1 force 128x128 kernel, 2 force 256-row kernel (tests/bench only)
     // rope table
     float* rope_tab = nullptr; int rope_P = 0;
@@ -457,19 +466,25 @@ extern "C" int sta_finalize_weights(sta_handle* h) {
 
 // ------------------------------------------------------------------------------------------ launch helpers
 template <bool SPLIT, int AMODE, int EPI, int BM, int BN, int WMS, int WNS, int NSTG = 2, bool MX = false>
-static int launch_gemm2(const GemmParams& p, hipStream_t st) {
-    static bool attr_done = false;
+static int launch_gemm2(const GemmParams& p, hipStream_t st, int dev = 0) {
+    static unsigned attr_done = 0;        // one bit per device: the attribute is set on the current device's copy of the function
     constexpr int smem = gemm2_smem_bytes<SPLIT, BM, BN>(NSTG);
-    if (!attr_done) {
+    if (!(attr_done >> (dev & 31) & 1u)) {
         HIPCHK(hipFuncSetAttribute((const void*)gemm2_kernel<SPLIT, AMODE, EPI, BM, BN, WMS, WNS, 0, NSTG, MX>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_done = true;
+        attr_done |= 1u << (dev & 31);
     }
-    int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
+    int tm = (p.M - p.m_tail + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
-    hipLaunchKernelGGL((gemm2_kernel<SPLIT, AMODE, EPI, BM, BN, WMS, WNS, 0, NSTG, MX>), dim3((unsigned)(tm * tn * ks)), dim3(WMS * WNS * 64), smem, st, p);
+    const int ntail = p.m_tail > 0 ? (p.N + 31) / 32 : 0;     // skinny tail blocks (gemm2_tail), first in the grid
+    hipLaunchKernelGGL((gemm2_kernel<SPLIT, AMODE, EPI, BM, BN, WMS, WNS, 0, NSTG, MX>), dim3((unsigned)(tm * tn * ks + ntail)), dim3(WMS * WNS * 64), smem, st, p);
     return 0;
 }
+
+// The ONE small-grid predicate (SLAM scale: 224x224, batch 1..6 -> M = 196..2400 rows): below it the 128x64 split-K family
+// runs (launch_gemm), in-place residual GEMMs hand their K slices to resid_ln_kernel (gemm_resid_ln), and the specialised
+// throughput epilogues / the paired launch are not used (gemm_f32, gemm_qkv_pair).
+static inline bool small_grid(int64_t M, int N) { return M <= 640 || ((M + 191) / 192) * (int64_t)((N + 127) / 128) < 128; }
 
 template <int AMODE, int EPI>
 static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
@@ -478,8 +493,19 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
     REQUIRE(p.K % GEMM_BK == 0, "GEMM K=%d must be a multiple of %d", p.K, GEMM_BK);
     REQUIRE(p.M > 0 && p.N > 0, "empty GEMM");
     if (AMODE == A_CONV3) REQUIRE(p.Cin % GEMM_BK == 0, "conv Cin=%d must be a multiple of %d", p.Cin, GEMM_BK);
+    // the LDS-DMA loaders address a K tile with 32-bit byte offsets (128 B per row of a row block)
+    REQUIRE((AMODE != A_DENSE || (int64_t)p.M * 128 < ((int64_t)1 << 32)) && (int64_t)p.N * 128 < ((int64_t)1 << 32),
+            "GEMM with M=%d, N=%d exceeds the 32-bit row-offset range of the DMA loaders", p.M, p.N);
     if (h->dry) return 0;
     const bool split = h->prec != STA_PREC_F16;
+    // Row tail hint (decode_impl: the 2B pose-token rows after the 2B x N patch rows).  Tile rules below look at the
+    // patch rows; the tail is kept only where a gemm2 family tiles them exactly (checked after the family is chosen).
+    p.m_tail = 0;
+    if (AMODE == A_DENSE && h->tail_hint > 0 && h->tail_hint <= 32 && p.M > h->tail_hint && !p.mx && p.N % 128 == 0 && h->gemm_variant != 1) {
+        if (!small_grid(p.M - h->tail_hint, p.N)) p.m_tail = h->tail_hint;   // throughput scale only (the small-grid family splits K instead)
+    }
+    const int M_all = p.M;
+    p.M -= p.m_tail;
     // Tile family selection.  Measured in the model, per shape, with HIP events around every launch (tools/gemm_tiles.py
     // shapes; profiles/r02_gemm_shapes.txt): every family saturates at the same 300-400 algorithmic TFLOP/s - the chip is
     // power-bound on this instruction mix - so the choice is about tile quantisation and epilogue overlap:
@@ -499,8 +525,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
     // Small-M (SLAM-scale: 224x224, batch 1 -> M = 196..394 rows): 128x64 tiles, 3-stage DMA ring, and for
     // the in-place residual GEMMs (proj / fc2: out += A W^T + b) split-K with fp32 atomics so that ~256
     // workgroups stream the weights once instead of 16-64 workgroups looping over all of K.
-    const int64_t tiles_192 = (int64_t)((p.M + 191) / 192) * ((p.N + 127) / 128);
-    if ((p.M <= 640 || tiles_192 < 128) && p.N % 64 == 0) {
+    if (small_grid(p.M, p.N) && p.N % 64 == 0) {
         variant = 6;
         const int tiles_r = ((p.M + 127) / 128) * (p.N / 64);
         const int tiles = h->deterministic ? (1 << 30) : tiles_r;    // deterministic: no ATOMIC split-K (the slab forms below have a fixed order)
@@ -559,6 +584,12 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
     if (h->gemm_variant == 1) variant = 1;
     if (variant != 6) { p.ksplit = 1; h->slab_ks = 0; }
     if (h->slab_ks == 0) p.slab = nullptr;
+    p.M = M_all;
+    {
+        const int bm_v = variant == 2 ? 256 : ((variant == 3 || variant == 5) ? 192 : 0);
+        constexpr bool tail_epi = EPI == EPI_F32 || EPI == EPI_F32R || EPI == EPI_GELU || EPI == EPI_QKV;   // gemm2_body: HAS_TAIL
+        if (p.m_tail && (bm_v == 0 || (p.M - p.m_tail) % bm_v != 0 || !tail_epi)) p.m_tail = 0;
+    }
     if (p.mx && variant == 1) variant = 5;     // no f16mx form of the register-staged kernel (use_mx() already requires N % 64 == 0)
     // per-launch HIP-event timing (bench / tools): every launch (mode 2), or only the launches of ONE kernel symbol
     // (mode 3, sta_kernel_timing_filter: the event pairs break back-to-back dispatch, ~3.5 us each, so the timed region of
@@ -582,26 +613,26 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
     if (timed && variant == 5) p.clk_dbg = h->clk_buf;   // effective-clock probe (bench only)
     if constexpr (EPI == EPI_HEAD) {      // exists for the 192x128 family only (conv3_head checks the shape)
         REQUIRE(variant == 5 && p.N == 128, "internal: fused head epilogue on a tile family without it");
-        if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4, 2, true>(p, st)));
-        else if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4>(p, st)));
-        else CHK((launch_gemm2<false, AMODE, EPI, 192, 128, 2, 4>(p, st)));
+        if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4, 2, true>(p, st, h->device)));
+        else if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4>(p, st, h->device)));
+        else STA_F16ONLY(CHK((launch_gemm2<false, AMODE, EPI, 192, 128, 2, 4>(p, st, h->device))));
     } else
     if (variant == 2) {
-        if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 256, 256, 4, 4, 2, true>(p, st)));
-        else if (split) CHK((launch_gemm2<true, AMODE, EPI, 256, 256, 4, 4>(p, st)));
-        else CHK((launch_gemm2<false, AMODE, EPI, 256, 256, 4, 4>(p, st)));
+        if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 256, 256, 4, 4, 2, true>(p, st, h->device)));
+        else if (split) CHK((launch_gemm2<true, AMODE, EPI, 256, 256, 4, 4>(p, st, h->device)));
+        else STA_F16ONLY(CHK((launch_gemm2<false, AMODE, EPI, 256, 256, 4, 4>(p, st, h->device))));
     } else if (variant == 3) {
-        if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 192, 256, 3, 4, 2, true>(p, st)));
-        else if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 256, 3, 4>(p, st)));
-        else CHK((launch_gemm2<false, AMODE, EPI, 192, 256, 3, 4>(p, st)));
+        if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 192, 256, 3, 4, 2, true>(p, st, h->device)));
+        else if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 256, 3, 4>(p, st, h->device)));
+        else STA_F16ONLY(CHK((launch_gemm2<false, AMODE, EPI, 192, 256, 3, 4>(p, st, h->device))));
     } else if (variant == 5) {
-        if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4, 2, true>(p, st)));
-        else if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4>(p, st)));
-        else CHK((launch_gemm2<false, AMODE, EPI, 192, 128, 2, 4>(p, st)));
+        if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4, 2, true>(p, st, h->device)));
+        else if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4>(p, st, h->device)));
+        else STA_F16ONLY(CHK((launch_gemm2<false, AMODE, EPI, 192, 128, 2, 4>(p, st, h->device))));
     } else if (variant == 6) {
-        if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 2, 2, 3, true>(p, st)));
-        else if (split) CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 2, 2, 3>(p, st)));
-        else CHK((launch_gemm2<false, AMODE, EPI, 128, 64, 2, 2, 3>(p, st)));
+        if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 2, 2, 3, true>(p, st, h->device)));
+        else if (split) CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 2, 2, 3>(p, st, h->device)));
+        else STA_F16ONLY(CHK((launch_gemm2<false, AMODE, EPI, 128, 64, 2, 2, 3>(p, st, h->device))));
         if (EPI == EPI_QKV && p.ksplit > 1) {
             const int64_t nthr = (int64_t)p.M * (p.nq + p.nk) + (int64_t)((p.M + 3) / 4) * p.nv;
             const int blocks = (int)((nthr + 255) / 256);
@@ -620,14 +651,14 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
         int tm = (p.M + GEMM_BM - 1) / GEMM_BM, tn = (p.N + GEMM_BN - 1) / GEMM_BN;
         dim3 grid((unsigned)(tm * tn));
         if (split) {
-            static bool attr_done = false;
-            if (!attr_done) {
+            static unsigned attr_done = 0;
+            if (!(attr_done >> (h->device & 31) & 1u)) {
                 HIPCHK(hipFuncSetAttribute((const void*)gemm_kernel<true, AMODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_smem_bytes<true>()));
-                attr_done = true;
+                attr_done |= 1u << (h->device & 31);
             }
             hipLaunchKernelGGL((gemm_kernel<true, AMODE, EPI>), grid, dim3(256), gemm_smem_bytes<true>(), st, p);
         } else {
-            hipLaunchKernelGGL((gemm_kernel<false, AMODE, EPI>), grid, dim3(256), gemm_smem_bytes<false>(), st, p);
+            STA_F16ONLY(hipLaunchKernelGGL((gemm_kernel<false, AMODE, EPI>), grid, dim3(256), gemm_smem_bytes<false>(), st, p));
         }
     }
     HIPCHK(hipGetLastError());
@@ -655,7 +686,7 @@ static int gemm_f32(sta_handle* h, const Planes& A, const Lin& W, int M, float* 
     p.C32 = out; p.ldc = ldc; p.resid = resid; p.ldr = ldc;
     p.rows_in = rows_in; p.rows_out = rows_out; p.row_off = row_off;
     // throughput-scale in-place residual GEMMs (attn.proj, mlp.fc2, cross_attn.proj): specialised epilogue
-    if (resid == out && rows_in == 0 && M > 640 && (int64_t)((M + 191) / 192) * ((W.N + 127) / 128) >= 128)
+    if (resid == out && rows_in == 0 && !small_grid(M, W.N))
         return launch_gemm<A_DENSE, EPI_F32R>(h, p, st);
     return launch_gemm<A_DENSE, EPI_F32>(h, p, st);
 }
@@ -679,8 +710,7 @@ static int gemm_resid_ln(sta_handle* h, const Planes& A, const Lin& W, int M, fl
                          const LNp* lb, const Planes* ob, bool ln_mx, hipStream_t st) {
     static const LNp no_ln = {nullptr, nullptr};
     static const Planes no_planes;
-    const int64_t tiles_192 = (int64_t)((M + 191) / 192) * ((W.N + 127) / 128);
-    const bool small = (M <= 640 || tiles_192 < 128) && W.N % 64 == 0 && W.N <= 1024 && h->gemm_variant == 0 && ld == W.N;
+    const bool small = small_grid(M, W.N) && W.N % 64 == 0 && W.N <= 1024 && h->gemm_variant == 0 && ld == W.N;
     h->slab_ks = 0;
     if (small) {
         int slot = 0;
@@ -700,10 +730,12 @@ static int gemm_resid_ln(sta_handle* h, const Planes& A, const Lin& W, int M, fl
 }
 struct QKVOut { Planes q, k, vt; int npad; };
 static int gp_qkv(sta_handle* h, GemmParams& p, const Planes& A, const Lin& W, int M, int nq, int nk, int nv,
-                  const QKVOut& o, int ntok, int heads, int wp, int has_pose) {
+                  const QKVOut& o, int ntok, int heads, int wp, int has_pose, int pose_base = 0) {
     p = gp_dense(A, W.K, W, M, use_mx(h, W));
     p.Q_hi = o.q.hi; p.Q_lo = o.q.lo; p.K_hi = o.k.hi; p.K_lo = o.k.lo; p.Vt_hi = o.vt.hi; p.Vt_lo = o.vt.lo;
     p.nq = nq; p.nk = nk; p.nv = nv; p.ntok = ntok; p.npad = o.npad; p.heads = heads; p.wp = wp; p.has_pose_tok = has_pose;
+    p.pose_base = pose_base;
+    REQUIRE(!(pose_base > 0 && has_pose), "internal: pose_base and has_pose_tok are two layouts of the same thing");
     p.rope_tab = h->rope_tab;
     p.ntok_magic = ntok > 1 ? (unsigned)((1ull << 32) / (unsigned)ntok + 1) : 0u;
     p.wp_magic = wp > 1 ? (unsigned)((1ull << 32) / (unsigned)wp + 1) : 0u;
@@ -711,9 +743,9 @@ static int gp_qkv(sta_handle* h, GemmParams& p, const Planes& A, const Lin& W, i
     return 0;
 }
 static int gemm_qkv(sta_handle* h, const Planes& A, const Lin& W, int M, int nq, int nk, int nv,
-                    const QKVOut& o, int ntok, int heads, int wp, int has_pose, hipStream_t st) {
+                    const QKVOut& o, int ntok, int heads, int wp, int has_pose, hipStream_t st, int pose_base = 0) {
     GemmParams p;
-    CHK(gp_qkv(h, p, A, W, M, nq, nk, nv, o, ntok, heads, wp, has_pose));
+    CHK(gp_qkv(h, p, A, W, M, nq, nk, nv, o, ntok, heads, wp, has_pose, pose_base));
     return launch_gemm<A_DENSE, EPI_QKV>(h, p, st);
 }
 // Two QKV-epilogue GEMMs that do not depend on each other as ONE launch (gemm2_pair_kernel) when both run on the 192x128
@@ -721,7 +753,7 @@ static int gemm_qkv(sta_handle* h, const Planes& A, const Lin& W, int M, int nq,
 static int gemm_qkv_pair(sta_handle* h, const GemmParams& pa_in, const GemmParams& pb_in, hipStream_t st) {
     GemmParams pa = pa_in, pb = pb_in;
     const bool split = h->prec != STA_PREC_F16;
-    auto big = [](const GemmParams& p) { return p.M > 640 && p.N % 128 == 0 && (int64_t)((p.M + 191) / 192) * (p.N / 128) >= 128; };
+    auto big = [](const GemmParams& p) { return p.N % 128 == 0 && !small_grid(p.M, p.N); };
     if (h->dry) return 0;
     if (!split || pa.mx || pb.mx || !big(pa) || !big(pb) || pa.K != pb.K || pa.M != pb.M || h->gemm_variant != 0) {
         CHK((launch_gemm<A_DENSE, EPI_QKV>(h, pa, st)));
@@ -729,7 +761,11 @@ static int gemm_qkv_pair(sta_handle* h, const GemmParams& pa_in, const GemmParam
     }
     pa.zero_page = pb.zero_page = h->zero_page;
     pa.ksplit = pb.ksplit = 1;
-    const int ta = ((pa.M + 191) / 192) * (pa.N / 128), tb = ((pb.M + 191) / 192) * (pb.N / 128);
+    // pose-token rows as skinny tail blocks (GemmParams::m_tail), same rule as launch_gemm
+    pa.m_tail = pb.m_tail = (h->tail_hint > 0 && h->tail_hint <= 32 && pa.M > h->tail_hint && (pa.M - h->tail_hint) % 192 == 0 &&
+                             !small_grid(pa.M - h->tail_hint, pa.N) && !small_grid(pb.M - h->tail_hint, pb.N)) ? h->tail_hint : 0;
+    const int ta = ((pa.M - pa.m_tail + 191) / 192) * (pa.N / 128) + (pa.m_tail ? pa.N / 32 : 0);
+    const int tb = ((pb.M - pb.m_tail + 191) / 192) * (pb.N / 128) + (pb.m_tail ? pb.N / 32 : 0);
     const bool timed = h->ktime && (h->ktime_all || (h->kfilter[0] == EPI_QKV && h->kfilter[1] == A_DENSE && h->kfilter[2] == 7 && h->kfilter[3] == 0));
     if (timed) {      // one record: M x (Na + Nb) x K, tile family id 7 = gemm2_pair_kernel
         if ((int)h->kev.size() < 2 * (h->kn + 1)) {
@@ -745,10 +781,10 @@ static int gemm_qkv_pair(sta_handle* h, const GemmParams& pa_in, const GemmParam
         HIPCHK(hipEventRecord(h->kev[2 * h->kn], st));
         h->kn++;
     }
-    static bool attr_done = false;
+    static unsigned attr_done = 0;      // one bit per device
     constexpr int smem = gemm2_smem_bytes<true, 192, 128>(2);
     auto kern = gemm2_pair_kernel<true, A_DENSE, EPI_QKV, 192, 128, 2, 4>;
-    if (!attr_done) { HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr_done = true; }
+    if (!(attr_done >> (h->device & 31) & 1u)) { HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr_done |= 1u << (h->device & 31); }
     hipLaunchKernelGGL(kern, dim3((unsigned)(ta + tb)), dim3(512), smem, st, pa, pb, ta);
     HIPCHK(hipGetLastError());
     if (timed) { HIPCHK(hipEventRecord(h->kev[2 * (h->kn - 1) + 1], st)); if ((int)h->kvar.size() < h->kn) h->kvar.resize(h->kn); h->kvar[h->kn - 1] = 7; }
@@ -828,22 +864,26 @@ static int run_ln(sta_handle* h, const float* x, int M, int C, const LNp& a, con
     return 0;
 }
 
+// pose: token index nq (== nk) of the buffers is the pose token (decoder row order, see decode_impl / AttnParams::pose)
 static int run_attn(sta_handle* h, const QKVOut& qkv, const Planes& out, int ldo, int S, int heads,
-                    int nq, int nk, int kv_shift, hipStream_t st, bool o_mx = false) {
+                    int nq, int nk, int kv_shift, hipStream_t st, bool o_mx = false, bool pose = false) {
     if (h->dry) return 0;
+    REQUIRE(!pose || (nq == nk && nq + 1 <= qkv.npad), "internal: pose-token attention needs nq == nk < npad");
     AttnParams p; memset(&p, 0, sizeof p);
+    p.pose = pose ? 1 : 0;
     p.o_mx = o_mx ? 1 : 0;   // attention output feeds attn.proj / cross_attn.proj: their plane format
     p.Q_hi = qkv.q.hi; p.Q_lo = qkv.q.lo; p.K_hi = qkv.k.hi; p.K_lo = qkv.k.lo; p.Vt_hi = qkv.vt.hi; p.Vt_lo = qkv.vt.lo;
     p.O_hi = out.hi; p.O_lo = out.lo; p.ldo = ldo;
     p.S = S; p.heads = heads; p.nq = nq; p.nk = nk; p.npad = qkv.npad; p.kv_shift = kv_shift;
     p.scale_log2e = 0.125f * 1.44269504088896340736f;
-    dim3 grid((unsigned)(((nq + 127) / 128) * heads * S));
+    dim3 grid((unsigned)(((nq + 127) / 128) * heads * S + (pose ? (S * heads + 3) / 4 : 0)));
+    REQUIRE(!pose || (int64_t)4 * qkv.npad * 4 <= attn_smem_bytes<false>(), "internal: pose-query scratch exceeds the LDS allocation");
     if (h->prec != STA_PREC_F16) {
-        static bool attr_done = false;
-        if (!attr_done) { hipFuncSetAttribute((const void*)attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_smem_bytes<true>()); attr_done = true; }
+        static unsigned attr_done = 0;      // one bit per device
+        if (!(attr_done >> (h->device & 31) & 1u)) { hipFuncSetAttribute((const void*)attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_smem_bytes<true>()); attr_done |= 1u << (h->device & 31); }
         hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), attn_smem_bytes<true>(), st, p);
     } else {
-        hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), attn_smem_bytes<false>(), st, p);
+        STA_F16ONLY(hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), attn_smem_bytes<false>(), st, p));
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -937,14 +977,24 @@ static int encode_impl(sta_handle* h, Bump& ws, const void* const* imgs, bool u8
 }
 
 // ------------------------------------------------------------------------------------------ decoder
-// x: fp32 [2B, N+1, D] residual stream (workspace or caller).  hook(i, x) is called after layer i
-// (i = 0: decoder input) through the `want` table: want1[i]/want2[i] destination or NULL.
+// Row order of the decoder's residual stream x (fp32, [2B*N + 2B, D]) and of every plane buffer derived from it:
+//     rows [0, 2B*N)        patch tokens, sequence-major (sequence s = side * B + b, token t: row s*N + t)
+//     rows [2B*N, 2B*N+2B)  the pose tokens of the 2B sequences
+// (the reference prepends the pose token to every sequence, sta_model.py:206-213: M = 2B x (N + 1) interleaved rows.  Token
+// order is immaterial to every layer - linears and LayerNorm are row-wise, attention is permutation-equivariant - and with
+// the pose rows LAST the patch rows tile exactly: at 512x384, B = 8: 12288 = 64 x 192 rows + a 16-row tail that the GEMMs
+// serve with skinny tail blocks (GemmParams::m_tail) and the attention kernel with its pose path (AttnParams::pose),
+// instead of a 65th tile row, a 7th query block and a 13th key tile everywhere.)
+// Outputs through the `want` tables, after layer i (i = 0: decoder input):
+//   ref_layout:  want1[i] / want2[i] = [B, N+1, D] per side in the reference's token order (pose token first), or NULL
+//   otherwise:   want1[i] = the whole x in the row order above (internal consumers: sta_forward_pair, sta_regress_views)
+struct TailHint { sta_handle* h; TailHint(sta_handle* h_, int t) : h(h_) { h->tail_hint = t; } ~TailHint() { h->tail_hint = 0; } };
 static int decode_impl(sta_handle* h, Bump& ws, const float* feat1, const float* feat2, int B, int hp, int wp,
-                       float* x, float* const* want1, float* const* want2, hipStream_t st) {
+                       float* x, float* const* want1, float* const* want2, bool ref_layout, hipStream_t st) {
     const sta_config& c = h->cfg;
     const bool split = h->prec != STA_PREC_F16;
     const int E = c.enc_embed_dim, D = c.dec_embed_dim, Hh = c.dec_num_heads;
-    const int N = hp * wp, Np = N + 1, S = 2 * B, M = S * Np, npad = rup(Np, 64);
+    const int N = hp * wp, Np = N + 1, S = 2 * B, M = S * Np, Mp = S * N, npad = rup(Np, 64);
     Planes fp = ws.act((int64_t)S * N, E, split);
     Planes a1 = ws.act(M, D, split);
     Planes ay = ws.act(M, D, split);
@@ -965,16 +1015,27 @@ static int decode_impl(sta_handle* h, Bump& ws, const float* feat1, const float*
     Planes fp2 = slice_rows(fp, (int64_t)B * N);
     CHK(run_rows_to_planes(h, feat1, (int64_t)N * E, B, N, E, fp, st));
     CHK(run_rows_to_planes(h, feat2, (int64_t)N * E, B, N, E, fp2, st));
-    CHK(gemm_f32(h, fp, h->dec_embed, S * N, x, D, nullptr, st, N, Np, 1));
-    hipLaunchKernelGGL(fill_pose_token_kernel, dim3((S * D + 255) / 256), dim3(256), 0, st, x, S, Np, D, h->pose_tok);
+    CHK(gemm_f32(h, fp, h->dec_embed, Mp, x, D, nullptr, st));
+    float* xpose = x + (size_t)Mp * D;
+    hipLaunchKernelGGL(fill_pose_token_kernel, dim3((S * D + 255) / 256), dim3(256), 0, st, xpose, S, 1, D, h->pose_tok);
     HIPCHK(hipGetLastError());
-    const size_t half_bytes = (size_t)B * Np * D * 4;
-    auto emit = [&](int idx) -> int {
-        if (want1 && want1[idx]) HIPCHK(hipMemcpyAsync(want1[idx], x, half_bytes, hipMemcpyDeviceToDevice, st));
-        if (want2 && want2[idx]) HIPCHK(hipMemcpyAsync(want2[idx], x + (size_t)B * Np * D, half_bytes, hipMemcpyDeviceToDevice, st));
+    auto emit = [&](int idx, const float* src) -> int {
+        if (!ref_layout) {
+            if (want1 && want1[idx] && want1[idx] != src) HIPCHK(hipMemcpyAsync(want1[idx], src, (size_t)M * D * 4, hipMemcpyDeviceToDevice, st));
+            return 0;
+        }
+        for (int side = 0; side < 2; ++side) {
+            float* dst = side == 0 ? (want1 ? want1[idx] : nullptr) : (want2 ? want2[idx] : nullptr);
+            if (!dst) continue;
+            const int64_t total4 = (int64_t)B * Np * D / 4;
+            int blocks = (int)((total4 + 255) / 256); if (blocks > 8192) blocks = 8192;
+            hipLaunchKernelGGL(emit_tokens_kernel, dim3(blocks), dim3(256), 0, st, src, side * B, B, N, D, (int64_t)Mp, dst);
+            HIPCHK(hipGetLastError());
+        }
         return 0;
     };
-    CHK(emit(0));
+    CHK(emit(0, x));
+    TailHint tail(h, S);                 // every dense GEMM below: the last S rows are the pose-token rows
     // norm1(x) and norm_y(x) from one read: y of one side == x of the other (sta_model.py:231-235); qkv and projk|projv:
     // one class, one plane format.  Layer i+1's pair is issued with layer i's mlp.fc2 (gemm_resid_ln).
     if (c.dec_depth > 0) CHK(run_ln(h, x, M, D, h->dec[0].n1, a1, &h->dec[0].ny, &ay, nullptr, st, use_mx(h, h->dec[0].qkv)));
@@ -984,25 +1045,29 @@ static int decode_impl(sta_handle* h, Bump& ws, const float* feat1, const float*
         // (They write disjoint buffers: qkv / ckv_out.)
         {
             GemmParams pq, pkv;
-            CHK(gp_qkv(h, pq, a1, b.qkv, M, D, D, D, qkv, Np, Hh, wp, 1));
-            CHK(gp_qkv(h, pkv, ay, b.ckv, M, 0, D, D, cqkv, Np, Hh, wp, 1));
+            CHK(gp_qkv(h, pq, a1, b.qkv, M, D, D, D, qkv, N, Hh, wp, 0, Mp));
+            CHK(gp_qkv(h, pkv, ay, b.ckv, M, 0, D, D, cqkv, N, Hh, wp, 0, Mp));
             CHK(gemm_qkv_pair(h, pq, pkv, st));
         }
-        CHK(run_attn(h, qkv, ao, D, S, Hh, Np, Np, 0, st, use_mx(h, b.proj)));
+        CHK(run_attn(h, qkv, ao, D, S, Hh, N, N, 0, st, use_mx(h, b.proj), true));
         CHK(gemm_resid_ln(h, ao, b.proj, M, x, D, &b.n2, &a1, nullptr, nullptr, use_mx(h, b.cq), st));
-        CHK(gemm_qkv(h, a1, b.cq, M, D, 0, 0, cqkv, Np, Hh, wp, 1, st));
-        CHK(run_attn(h, cqkv, ao, D, S, Hh, Np, Np, B, st, use_mx(h, b.cproj)));
+        CHK(gemm_qkv(h, a1, b.cq, M, D, 0, 0, cqkv, N, Hh, wp, 0, st, Mp));
+        CHK(run_attn(h, cqkv, ao, D, S, Hh, N, N, B, st, use_mx(h, b.cproj), true));
         CHK(gemm_resid_ln(h, ao, b.cproj, M, x, D, &b.n3, &a1, nullptr, nullptr, use_mx(h, b.fc1), st));
         CHK(gemm_f16(h, a1, b.fc1, M, f1, ACT_GELU, st, use_mx(h, b.fc2)));
         if (i + 1 < c.dec_depth) {
             const DecBlk& nb = h->dec[i + 1];
             CHK(gemm_resid_ln(h, f1, b.fc2, M, x, D, &nb.n1, &a1, &nb.ny, &ay, use_mx(h, nb.qkv), st));
-            CHK(emit(i + 1));
+            CHK(emit(i + 1, x));
         } else {   // final_x[-1] = dec_norm(final_x[-1])  (sta_model.py:241-242)
             CHK(gemm_resid_ln(h, f1, b.fc2, M, x, D, nullptr, nullptr, nullptr, nullptr, false, st));
-            Planes none;
-            if (want1 && want1[i + 1]) CHK(run_ln(h, x, B * Np, D, h->dec_norm, none, nullptr, nullptr, want1[i + 1], st));
-            if (want2 && want2[i + 1]) CHK(run_ln(h, x + (size_t)B * Np * D, B * Np, D, h->dec_norm, none, nullptr, nullptr, want2[i + 1], st));
+            const bool wanted = (want1 && want1[i + 1]) || (ref_layout && want2 && want2[i + 1]);
+            if (wanted) {
+                Planes none;
+                float* dst = ref_layout ? x : want1[i + 1];          // x is dead after the last layer: normalise it in place
+                CHK(run_ln(h, x, M, D, h->dec_norm, none, nullptr, nullptr, dst, st));
+                CHK(emit(i + 1, dst));
+            }
         }
     }
     return 0;
@@ -1202,7 +1267,7 @@ extern "C" int sta_decode(sta_handle* h, const float* feat1, const float* feat2,
     const int64_t xbytes = (int64_t)2 * B * (N + 1) * D * 4;
     return plan_and_run(h, [&](Bump& ws) {
         float* x = (float*)ws.take(xbytes);
-        return decode_impl(h, ws, feat1, feat2, B, hp, wp, x, out1, out2, st);
+        return decode_impl(h, ws, feat1, feat2, B, hp, wp, x, out1, out2, true, st);
     });
 }
 
@@ -1258,17 +1323,19 @@ static int forward_pair_any(sta_handle* h, const void* img_a, const void* img_b,
         CHK(encode_impl(h, ws, imgs, u8hwc, 2, Bs, H, W, feat, st));
         if (rec) HIPCHK(hipEventRecord(h->ev[1], st));
         ws.rewind(mark);
-        std::vector<float*> w1(dd + 1, nullptr), w2(dd + 1, nullptr);
-        for (int k = 0; k < 3; ++k) { w1[hidx[k]] = hk[k]; w2[hidx[k]] = hk[k] + (size_t)Bs * Np * D; }
-        CHK(decode_impl(h, ws, feat, feat + (size_t)Bs * N * E, Bs, hp, wp, x, w1.data(), w2.data(), st));
+        // hooks in the decoder's own row order (decode_impl): [Ss*N patch rows | Ss pose rows]
+        std::vector<float*> w1(dd + 1, nullptr);
+        for (int k = 0; k < 3; ++k) w1[hidx[k]] = hk[k];
+        CHK(decode_impl(h, ws, feat, feat + (size_t)Bs * N * E, Bs, hp, wp, x, w1.data(), nullptr, false, st));
         if (rec) HIPCHK(hipEventRecord(h->ev[2], st));
-        // pose heads read token 0 of the dec_norm'ed last layer (sta_model.py:273,277)
+        // pose heads read the pose token of the dec_norm'ed last layer (sta_model.py:273,277)
         ws.rewind(mark);
-        CHK(pose_impl(h, ws, hk[2], Bs, (int64_t)Np * D, po[0], pc[0], st));
-        CHK(pose_impl(h, ws, hk[2] + (size_t)Bs * Np * D, Bs, (int64_t)Np * D, po[1], pc[1], st));
+        const float* ptok = hk[2] + (size_t)Ss * N * D;
+        CHK(pose_impl(h, ws, ptok, Bs, (int64_t)D, po[0], pc[0], st));
+        CHK(pose_impl(h, ws, ptok + (size_t)Bs * D, Bs, (int64_t)D, po[1], pc[1], st));
         if (rec) HIPCHK(hipEventRecord(h->ev[3], st));
         ws.rewind(mark);
-        CHK(dpt_impl(h, ws, feat, (int64_t)N * E, hk[0] + D, (int64_t)Np * D, hk[1] + D, (int64_t)Np * D, hk[2] + D, (int64_t)Np * D,
+        CHK(dpt_impl(h, ws, feat, (int64_t)N * E, hk[0], (int64_t)N * D, hk[1], (int64_t)N * D, hk[2], (int64_t)N * D,
                      Ss, H, W, p[0], cf[0], Bs, p[1], cf[1], st));
         if (rec) HIPCHK(hipEventRecord(h->ev[4], st));
         return 0;
