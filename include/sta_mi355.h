@@ -270,6 +270,11 @@ int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, int tile, int 
 /* Effective shader clock (GHz) observed inside the kernel of the last sta_bench_gemm call (s_memtime cycles per
  * 100 MHz s_memrealtime tick, sampled on every 64th workgroup): the chip clocks to its power budget (DVFS). */
 float sta_bench_gemm_last_ghz(void);
+/* The attention kernel alone on random operands (tools): ms per launch over `iters` back-to-back launches.  which: 0 = the
+ * automatic choice, 1 = the software-pipelined kernel (attention2.h), 2 = the small-grid kernel (attention.h); pose != 0: the
+ * decoder form (nq == nk patch tokens + the pose token). */
+int sta_bench_attention(sta_handle* h, int S, int heads, int nq, int nk, int pose, int iters, int which, float* ms_out, void* stream);
+
 
 const char* sta_last_error(void);
 const char* sta_version(void);

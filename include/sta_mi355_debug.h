@@ -14,8 +14,9 @@ extern "C" {
 #endif
 
 /* Force the GEMM tile family: 0 = automatic (product behaviour), 1 = 128x128 register-staged kernel,
- * 2 = 256-row direct-to-LDS kernels, 3 = 192-row ones (whenever N % 128 == 0).  Lets the tests cover the families on
- * small shapes. */
+ * 2 = 256-row direct-to-LDS kernels, 3 = 192-row ones (whenever N % 128 == 0), 4 = 192x128 everywhere, 8 = the halo-tiled
+ * 3x3 convolution kernel (conv3h.h) wherever it is legal (stride 1, Cout 128 / 256), 9 = automatic WITHOUT that kernel
+ * (same-box A/B).  Lets the tests cover the families on small shapes. */
 int sta_set_gemm_variant(sta_handle* h, int variant);
 
 /* Precision-policy experiments: choose which layer classes run in the f16mx arithmetic (f16 main product + one block-scaled
@@ -46,6 +47,11 @@ int sta_debug_attention(sta_handle* h, const float* q, const float* k, const flo
  * (patch rows sequence-major, then the S pose rows).  sta_blocks.py:129-148,201-205 on n + 1 tokens. */
 int sta_debug_attention_pose(sta_handle* h, const float* q, const float* k, const float* v, int S, int heads,
                              int n, int kv_shift, float* out, void* stream);
+
+/* Experiment switches of the tools (0 everywhere = product behaviour).  idx 0: conv3h configuration (bits 0-1: 0 = 16 waves /
+ * 2 weight stages, 1 = 16 waves / 3-stage weight ring, 2 = 8 waves with 64x64 wave tiles / ring; bit 3: Cout = 256 as two
+ * 128-column tiles). */
+int sta_debug_set_option(sta_handle* h, int idx, int value);
 
 /* Row-tail hint for the dense GEMMs (what the decoder sets to its 2B pose-token rows): the last `rows` (<= 32) rows of the
  * following sta_debug_gemm calls are computed by skinny tail blocks when the shape qualifies.  Sticky; 0 resets. */

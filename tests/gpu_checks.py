@@ -101,8 +101,10 @@ def check_qkv_rope(precision, S=2, hp=3, wp=4, pose_tok=1, K=128, Cdim=128, seed
             "vpad_abs": float(np.abs(pad).max()) if pad.size else 0.0}
 
 
-def check_attention(precision, S=2, heads=2, nq=197, nk=197, kv_shift=0, sharp=1.0, seed=2):
+def check_attention(precision, S=2, heads=2, nq=197, nk=197, kv_shift=0, sharp=1.0, seed=2, kernel=0):
+    """kernel: 0 = the library's choice, 1 = the software-pipelined throughput kernel (attention2.h), 2 = attention.h"""
     m, lib, h = kernel_handle(precision)
+    _lib.check(lib.sta_debug_set_option(h, 1, kernel))
     g = torch.Generator().manual_seed(seed)
     q = torch.randn(S, heads, nq, 64, generator=g) * sharp
     k = torch.randn(S, heads, nk, 64, generator=g)
@@ -112,9 +114,12 @@ def check_attention(precision, S=2, heads=2, nq=197, nk=197, kv_shift=0, sharp=1
     ref = (a.softmax(-1) @ v[idx].double()).permute(0, 2, 1, 3).reshape(S, nq, heads * 64)
     out = torch.empty(S, nq, heads * 64, device=DEV)
     qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
-    _lib.check(lib.sta_debug_attention(h, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), S, heads, nq, nk,
-                                       kv_shift, out.data_ptr(), st()))
-    torch.cuda.synchronize()
+    try:
+        _lib.check(lib.sta_debug_attention(h, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), S, heads, nq, nk,
+                                           kv_shift, out.data_ptr(), st()))
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(lib.sta_debug_set_option(h, 1, 0))
     o = out.cpu().numpy()
     return {"rel_l2": rel_l2(o, ref.numpy()), "max_rel": max_rel(o, ref.numpy()), "nan": float(np.isnan(o).sum())}
 
@@ -163,7 +168,7 @@ def check_qkv_rope_decoder_rows(precision, S=2, hp=3, wp=4, K=128, Cdim=128, see
             "vpad_abs": float(np.abs(pad).max()) if pad.size else 0.0}
 
 
-def check_attention_pose(precision, S=2, heads=2, n=196, kv_shift=0, sharp=1.0, seed=13):
+def check_attention_pose(precision, S=2, heads=2, n=196, kv_shift=0, sharp=1.0, seed=13, kernel=0):
     """Decoder form of the attention kernel: n patch tokens + the pose token (last): as a key it is folded into the initial
     softmax state, as a query it is served by the pose blocks."""
     m, lib, h = kernel_handle(precision)
@@ -178,8 +183,12 @@ def check_attention_pose(precision, S=2, heads=2, n=196, kv_shift=0, sharp=1.0, 
     ref = torch.cat([ref[:, :n].reshape(S * n, heads * 64), ref[:, n]], 0)       # decoder row order
     out = torch.empty(S * n + S, heads * 64, device=DEV)
     qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
-    _lib.check(lib.sta_debug_attention_pose(h, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), S, heads, n, kv_shift, out.data_ptr(), st()))
-    torch.cuda.synchronize()
+    _lib.check(lib.sta_debug_set_option(h, 1, kernel))
+    try:
+        _lib.check(lib.sta_debug_attention_pose(h, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), S, heads, n, kv_shift, out.data_ptr(), st()))
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(lib.sta_debug_set_option(h, 1, 0))
     o = out.cpu().numpy()
     return {"rel_l2": rel_l2(o, ref.numpy()), "rel_l2_pose": rel_l2(o[S * n:], ref.numpy()[S * n:]),
             "max_rel": max_rel(o, ref.numpy()), "nan": float(np.isnan(o).sum())}

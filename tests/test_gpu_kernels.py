@@ -92,6 +92,17 @@ def test_conv3x3(G, prec, kw):
 
 
 @pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("kw", [dict(Cin=32, Co=128, H=9, W_=40), dict(Cin=96, Co=256, H=19, W_=23, relu_in=1, act=2, resid=True),
+                                dict(Cin=64, Co=128, H=8, W_=32, n=3), dict(Cin=128, Co=256, H=17, W_=64, n=1, relu_in=1),
+                                dict(Cin=256, Co=128, H=3, W_=97, act=2), dict(Cin=32, Co=256, H=1, W_=1), dict(Cin=64, Co=128, H=30, W_=33, resid=True)])
+def test_conv3x3_halo_tiles(G, prec, kw):
+    """conv3h.h (forced with tile family 8): pixel tiles of 8 x 32 outputs, halo in LDS, image borders / ragged tiles /
+    several channel blocks (double-buffered halo) / ReLU on fragments / residual planes."""
+    r = G.check_conv3(prec, variant=8, **kw)
+    assert r["rel_l2"] < TOL[prec], r
+
+
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("kw", [dict(), dict(Cdim=192, k=2), dict(Cdim=192, k=2, variant=2), dict(Cdim=96, k=4, variant=2, H=9, W_=11)])
 def test_convt(G, prec, kw):
     r = G.check_convt(prec, **kw)
@@ -103,6 +114,26 @@ def test_convt(G, prec, kw):
 def test_up2(G, prec, kw):
     r = G.check_up2(prec, **kw)
     assert r["rel_l2"] < TOL[prec], r
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("kw", [dict(), dict(kv_shift=1), dict(nq=70, nk=130, sharp=6.0), dict(S=1, heads=1, nq=769, nk=769, sharp=3.0),
+                                dict(nq=1, nk=1), dict(nq=256, nk=64), dict(nq=300, nk=129, sharp=10.0), dict(nq=512, nk=192, S=3, kv_shift=2)])
+def test_attention_pipelined_kernel(G, prec, kw):
+    """attention2.h forced (the library picks it at throughput scale only): ragged query blocks, 1..13 key tiles incl. the
+    partly valid one, cross-attention shift, sharp softmax."""
+    r = G.check_attention(prec, kernel=1, **kw)
+    assert r["nan"] == 0, r
+    assert r["rel_l2"] < TOL[prec], r
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("kw", [dict(), dict(kv_shift=1), dict(n=768, S=2, heads=1, sharp=3.0), dict(n=12, sharp=6.0), dict(n=64), dict(n=128),
+                                dict(n=129, sharp=10.0, S=3, heads=1, kv_shift=2)])
+def test_attention_pose_token_pipelined_kernel(G, prec, kw):
+    r = G.check_attention_pose(prec, kernel=1, **kw)
+    assert r["nan"] == 0, r
+    assert r["rel_l2"] < TOL[prec] and r["rel_l2_pose"] < TOL[prec], r
 
 
 @pytest.mark.parametrize("prec", PRECS)

@@ -44,8 +44,9 @@ def test_stress_goldens_default_precision(G, case):
 @pytest.mark.parametrize("case", ["tiny_48x64_b2", "tiny_48x80_smooth_sharp"])
 def test_tiny_goldens_large_tile_kernel(G, case):
     """Same goldens with the large-tile GEMM families forced (2 = 256x256 / 16 waves, 3 = 192x256 / 12 waves: the
-    bench-scale kernels of mlp.fc1 / mlp.fc2 and the refinement convolutions, f16x3 and f16mx forms)."""
-    for variant in (2, 3):
+    bench-scale kernels of mlp.fc1 / mlp.fc2 and the refinement convolutions, f16x3 and f16mx forms; 8 = the halo-tiled
+    3x3 convolution kernel incl. the fused DPT tail, conv3h.h)."""
+    for variant in (2, 3, 8):
         r = G.run_golden_case(case, DEFAULT, variant=variant)
         bad = {k: v for k, v in r.items() if v > TOL}
         assert not bad, (variant, bad)

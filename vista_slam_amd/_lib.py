@@ -67,6 +67,7 @@ SIGNATURES = {
     "sta_kernel_clock_read": (_i, [_vp, C.POINTER(C.c_float)]),
     "sta_bench_gemm": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(_f), _vp]),
     "sta_bench_gemm_last_ghz": (C.c_float, []),
+    "sta_bench_attention": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_f), _vp]),
     "sta_last_error": (C.c_char_p, []),
     "sta_version": (C.c_char_p, []),
     # ---- debug / kernel-level test entry points
@@ -80,6 +81,7 @@ SIGNATURES = {
     "sta_debug_attention": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _vp]),
     "sta_debug_attention_pose": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _vp]),
     "sta_debug_set_tail_hint": (_i, [_vp, _i]),
+    "sta_debug_set_option": (_i, [_vp, _i, _i]),
     "sta_debug_conv3x3": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _fp, _fp, _vp]),
     "sta_debug_convt": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _vp]),
     "sta_debug_up2": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _i, _fp, _vp]),

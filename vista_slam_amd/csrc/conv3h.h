@@ -1,0 +1,291 @@
+// Halo-tiled 3x3 convolution (stride 1, pad 1) for gfx950: the throughput form of the DPT head's convolutions
+// (ResidualConvUnit_custom, layer_rn, head.0 / head.2: heads/dpt_block.py:20-77,121-142,316-324).
+//
+// The implicit-GEMM loader of gemm2.h (A_CONV3) DMA's every input pixel of a tile once per tap - nine times per output
+// tile - and the counters showed the re-reads reaching the fabric (3-6.6x the algorithmic bytes, round 2).  Here a
+// workgroup owns a 2-D pixel tile of TR x 32 outputs (TR = BM / 32: one 32-row MFMA tile = 32 pixels of ONE image row) and,
+// per 32-channel block, DMA's its (TR + 2) x 34 input HALO into LDS once; the nine taps are nine LDS offsets into it:
+//     K loop:  for channel block cb:  for tap (ky, kx):  acc += halo[(ty + ky, tx + kx), cb] . W[tap, cb]^T
+//  * A-operand DMA per output tile: (TR + 2) * 34 / (TR * 32) = 1.33x the input (256-pixel tile) instead of 9x; the
+//    global->LDS stream per K step drops from (A 32 KiB + B) to (A 4.8 KiB + B): what bounds these kernels.
+//  * LDS image of the halo: one 128-B row [hi32 | lo32] per halo pixel hp = hy * 34 + hx, 16-B chunk index XOR
+//    (hp >> 1) & 7 - the same involution as the GEMM tiles, keyed on the HALO pixel: a fragment read touches 32
+//    consecutive halo pixels of one halo row, i.e. 16 distinct hp mod 16 per ds_read_b128 lane group = all 64 banks once.
+//  * Two halo stages (channel block cb + 1 streams in, spread over the nine taps of cb) and two weight stages
+//    (tap t + 1 under tap t); one vmcnt(0) + barrier per K step; out-of-image halo pixels read the zero page.
+//  * 16 waves (4 x 4), one workgroup per CU: 256 x 128 tile (wave 64 x 32) for Cout = 128 - its epilogue can be the fused DPT
+//    tail (EPI_HEAD) - and 256 x 256 (wave 64 x 64) for Cout = 256.  f16 / f16x3 / f16mx arithmetic as in gemm2.h.
+//  * Epilogue: the ordinary plane epilogue per 32-pixel row segment (bias, ReLU, residual planes), bounded to the image.
+#pragma once
+#include "gemm2.h"
+
+#define C3H_PW 34     // halo width: 32 output columns + 2
+
+template <bool SPLIT, int BM>
+constexpr int conv3h_halo_bytes() { return ((BM / 32 + 2) * C3H_PW * (SPLIT ? 128 : 64) + 1023) / 1024 * 1024; }
+template <bool SPLIT, int BM, int BN>
+constexpr int conv3h_smem_bytes(int nstgb = 2) { return 2 * conv3h_halo_bytes<SPLIT, BM>() + nstgb * BN * (SPLIT ? 128 : 64); }
+
+// NSTGB: weight stages.  2 = tap t + 1 streams in under tap t (vmcnt(0) + barrier per K step).  3 = ring: the weights run TWO
+// taps ahead and stay in flight across the barrier (counted vmcnt): with one workgroup per CU nothing else covers a DMA
+// round trip, and a K step of the 256 x 128 tile is only 6 MFMAs per wave.
+template <bool SPLIT, int EPI, int BM, int BN, int WAVES_M, int WAVES_N, bool MX, int NSTGB = 2>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3h_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MT = WM / 32, NT = WN / 32, TR = BM / 32;
+    constexpr int RB = SPLIT ? 128 : 64, RPS = 1024 / RB, CPR = RB / 16;
+    constexpr int A_ES = SPLIT ? 64 : 32;
+    constexpr int HALO = conv3h_halo_bytes<SPLIT, BM>(), B_TILE = BN * RB;
+    constexpr int HPIX = (TR + 2) * C3H_PW;
+    constexpr int NHS = (HPIX + RPS - 1) / RPS;            // 1-KiB DMA slots of one halo
+    constexpr bool RING = NSTGB > 2;
+    constexpr int HTAPS = RING ? 8 : 9;                    // taps over which the next halo streams in (ring: done one step early)
+    constexpr int HPS = (NHS + HTAPS - 1) / HTAPS;         // halo slots issued per K step, one per wave
+    constexpr int NSB = BN / RPS, SB = (NSB + NW - 1) / NW;
+    static_assert(NSTGB == 2 || (NSTGB == 3 && NSB % NW == 0), "2 weight stages, or a 3-stage ring with the same DMA count in every wave");
+    static_assert((NW & (NW - 1)) == 0 && HPS <= NW && WM % 32 == 0 && WN % 32 == 0 && (!MX || SPLIT), "conv3h tile / wave mismatch");
+    static_assert(EPI == EPI_F16 || EPI == EPI_HEAD, "conv3h: plane epilogue or the fused DPT tail");
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    // ---- block id -> (pixel tile, N tile): XCD-contiguous ranges, bands of 4 pixel tiles x all N tiles (as gemm2.h)
+    const int tiles_x = (p.Wo + 31) >> 5, tiles_y = (p.Ho + TR - 1) / TR;
+    const int n_img = p.M / (p.Ho * p.Wo);
+    const int tiles_m = n_img * tiles_y * tiles_x, tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    int t;
+    {
+        const int bid = blockIdx.x, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    int bm, bn;
+    {
+        const int band = t / (4 * tiles_n);
+        const int hb = tiles_m - band * 4 < 4 ? tiles_m - band * 4 : 4;
+        const int local = t - band * 4 * tiles_n;
+        bm = band * 4 + local % hb;
+        bn = local / hb;
+    }
+    const int img = bm / (tiles_y * tiles_x);
+    const int trem = bm - img * (tiles_y * tiles_x);
+    const int y0 = (trem / tiles_x) * TR, x0 = (trem % tiles_x) * 32;
+    const int n0 = bn * BN;
+
+    // ---- DMA bookkeeping.  Lane l of a 1-KiB slot fills LDS row (l / CPR), chunk position (l % CPR) with the source chunk
+    // (l % CPR) ^ swizzle(row).
+    const int row_in = lane / CPR, c_lds = lane % CPR;
+    unsigned b_src[SB];
+#pragma unroll
+    for (int s = 0; s < SB; ++s) {
+        const int row = RPS * (wave + NW * s) + row_in;
+        const int sw = SPLIT ? (row >> 1) & 7 : (row >> 2) & 3;
+        const int gn = n0 + row;
+        const int gnc = gn < p.N ? gn : p.N - 1;
+        b_src[s] = ((unsigned)gnc * 64 + (c_lds ^ sw) * 8) * 2u;              // weights are always [hi32|lo32]
+    }
+    const size_t b_kstride = (size_t)p.N * 64;
+    const int cblocks = p.Cin >> 5;
+    const int nkt = 9 * cblocks;
+    char* const sH = smem;
+    char* const sB = smem + 2 * HALO;
+
+    auto issue_b = [&](int cb, int tap, int stage) {           // weight K tile (tap, cb): K order of the packed weights is (ky, kx, ci)
+        const f16* base = p.B_hi + (size_t)(tap * cblocks + cb) * b_kstride;
+#pragma unroll
+        for (int s = 0; s < SB; ++s) {
+            if (NSB % NW != 0 && wave + NW * s >= NSB) continue;
+            unsigned o = b_src[s];
+            asm volatile("" : "+v"(o));
+            glds16(reinterpret_cast<const char*>(base) + o, sB + stage * B_TILE + (wave + NW * s) * 1024);
+        }
+    };
+    auto issue_halo = [&](int j, int cb, int stage) {          // halo slot j (RPS halo pixels) of channel block cb
+        const int hp = j * RPS + row_in;
+        const int sw = SPLIT ? (hp >> 1) & 7 : (hp >> 2) & 3;
+        const int hy = hp / C3H_PW, hx = hp - hy * C3H_PW;
+        const int yi = y0 - 1 + hy, xi = x0 - 1 + hx;
+        const bool ok = hp < HPIX && yi >= 0 && yi < p.Hi && xi >= 0 && xi < p.Wi;
+        const size_t pix = (size_t)(img * p.Hi + yi) * p.Wi + xi;
+        glds16(ok ? p.A_hi + ((size_t)cb * p.a_rp + pix) * A_ES + (c_lds ^ sw) * 8 : p.zero_page, sH + stage * HALO + j * 1024);
+    };
+
+    floatx16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int j = wave; j < NHS; j += NW) issue_halo(j, 0, 0);
+    issue_b(0, 0, 0);
+    if (RING) {
+        if (nkt > 1) issue_b(0, 1, 1);
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    int cb = 0, tap = 0;
+    bool h_prev = false;                                       // ring: did this wave issue a halo slot in the previous K step
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = RING ? kt % NSTGB : (kt & 1), hs = cb & 1;
+        int ncb = cb, ntap = tap + 1;
+        if (ntap == 9) { ntap = 0; ncb = cb + 1; }
+        bool h_cur = false;
+        if (RING) {
+            // this wave's DMA queue, oldest first: ... | step kt-2: halo?, W(kt) | step kt-1: halo?, W(kt+1).  W(kt) and every halo
+            // slot up to step kt-2 have landed once at most the instructions of step kt-1 are outstanding.
+            if (kt + 1 >= nkt) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (h_prev) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(SB + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(SB) : "memory");
+            // the barrier also says every wave finished step kt-1: its weight stage is free for W(kt+2)
+            if (cb + 1 < cblocks && tap < HTAPS) {
+                const int q = (wave - tap * HPS) & (NW - 1);
+                const int j = tap * HPS + q;
+                if (q < HPS && j < NHS) { issue_halo(j, cb + 1, hs ^ 1); h_cur = true; }
+            }
+            if (kt + 2 < nkt) {
+                int c2 = ncb, t2 = ntap + 1;
+                if (t2 == 9) { t2 = 0; c2 = ncb + 1; }
+                issue_b(c2, t2, (kt + 2) % NSTGB);
+            }
+        } else {
+            if (kt + 1 < nkt) issue_b(ncb, ntap, cur ^ 1);
+            if (cb + 1 < cblocks) {                            // halo of the next channel block: HPS slots per tap, one per wave
+                const int q = (wave - tap * HPS) & (NW - 1);
+                const int j = tap * HPS + q;
+                if (q < HPS && j < NHS) issue_halo(j, cb + 1, hs ^ 1);
+            }
+        }
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const char* hA = sH + hs * HALO;
+        const char* bB = sB + cur * B_TILE;
+        int hp[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) hp[i] = (wm * MT + i + ky) * C3H_PW + l31 + kx;
+        if constexpr (MX) {
+            typedef int int4v __attribute__((ext_vector_type(4)));
+            typedef int int8v __attribute__((ext_vector_type(8)));
+            half8 ah[MT], bh[NT];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int chunk = ks * 2 + lhi;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    ah[i] = *reinterpret_cast<const half8*>(hA + lds2_off<true>(hp[i], chunk));
+                    if (p.relu_in) {
+                        union { half8 h; unsigned u[4]; } tt; tt.h = ah[i];
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) { const unsigned sgn = (tt.u[w] >> 15) & 0x00010001u; tt.u[w] &= ~((sgn << 16) - sgn); }
+                        ah[i] = tt.h;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bh[j] = *reinterpret_cast<const half8*>(bB + lds2_off<true>(wn * WN + j * 32 + l31, chunk));
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+            union U8 { struct { int4v x, y; } q; int8v v; };
+            U8 a8[MT], b8[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                a8[i].q.x = *reinterpret_cast<const int4v*>(hA + lds2_off<true>(hp[i], 4 + 2 * lhi));
+                a8[i].q.y = *reinterpret_cast<const int4v*>(hA + lds2_off<true>(hp[i], 5 + 2 * lhi));
+                if (p.relu_in) {
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) { const unsigned u = (unsigned)a8[i].v[w]; const unsigned sgn = (u >> 7) & 0x00010001u; a8[i].v[w] = (int)(u & ~((sgn << 16) - sgn)); }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int rb = wn * WN + j * 32 + l31;
+                b8[j].q.x = *reinterpret_cast<const int4v*>(bB + lds2_off<true>(rb, 4 + 2 * lhi));
+                b8[j].q.y = *reinterpret_cast<const int4v*>(bB + lds2_off<true>(rb, 5 + 2 * lhi));
+            }
+            constexpr int sc_a = 127 - STA_MX_A_SLO, sc_b = 127 - STA_MX_W_SHI;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i].v, b8[j].v, acc[i][j], 0, 0, 0, sc_a, 0, sc_b);
+        } else {
+            half8 a_hi[MT], a_lo[MT], b_hi[NT], b_lo[NT];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int chunk = ks * 2 + lhi;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    a_hi[i] = *reinterpret_cast<const half8*>(hA + lds2_off<SPLIT>(hp[i], chunk));
+                    if (SPLIT) a_lo[i] = *reinterpret_cast<const half8*>(hA + lds2_off<SPLIT>(hp[i], 4 + chunk));
+                    if (p.relu_in) {         // relu(hi + lo): the sign of hi decides (packed-half integer form, gemm2.h)
+                        union { half8 h; unsigned u[4]; } ah, al;
+                        ah.h = a_hi[i]; al.h = a_lo[i];
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const unsigned sgn = (ah.u[w] >> 15) & 0x00010001u;
+                            const unsigned m = (sgn << 16) - sgn;
+                            ah.u[w] &= ~m;
+                            if (SPLIT) al.u[w] &= ~m;
+                        }
+                        a_hi[i] = ah.h; if (SPLIT) a_lo[i] = al.h;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int rb = wn * WN + j * 32 + l31;
+                    b_hi[j] = *reinterpret_cast<const half8*>(bB + lds2_off<SPLIT>(rb, chunk));
+                    if (SPLIT) b_lo[j] = *reinterpret_cast<const half8*>(bB + lds2_off<SPLIT>(rb, 4 + chunk));
+                }
+                if (SPLIT) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (!RING) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        h_prev = h_cur;
+        tap = ntap; cb = ncb;
+    }
+
+    // ---- epilogue: MFMA tile (i, j) of this wave = the 32 pixels (y0 + wm*MT + i, x0 .. x0 + 31) x 32 channels
+    const int cols_valid = p.Wo - x0 < 32 ? p.Wo - x0 : 32;
+    if constexpr (EPI == EPI_HEAD) {
+        if constexpr (BN == 128) {
+            const int rows_valid = p.Ho - y0 < TR ? p.Ho - y0 : TR;
+            head_epilogue<BM, MT, NT, WM, WAVES_N>(p, acc, (int64_t)(img * p.Ho + y0) * p.Wo + x0, p.Wo, rows_valid, cols_valid, wm, wn, tid, smem);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int yy = y0 + wm * MT + i;
+                const int row0 = (img * p.Ho + yy) * p.Wo + x0;
+                epilogue_tile<SPLIT, EPI>(p, acc[i][j], row0, n0 + wn * WN + j * 32 + l31, lane, 0, yy < p.Ho ? row0 + cols_valid : row0);
+            }
+    }
+}

@@ -193,10 +193,13 @@ __device__ __forceinline__ void epilogue_qkv_tile(const GemmParams& p, const flo
 // column `col` (= tile col + lane&31) and rows row0 + (r&3) + 8*(r>>2) + 4*(lane>>5), r = 0..15.
 // The tile column origin is a multiple of 32 and (for EPI_QKV) segment/head boundaries are multiples
 // of 64, so segment, head and the RoPE half (y for d<32, x for d>=32) are wave-uniform.
+// mlim >= 0: rows >= mlim are not stored (halo-tiled convolutions: a 32-row MFMA tile = 32 pixels of ONE image row, the rest
+// of the tile lies beyond the row's end); default: the GEMM's M.
 template <bool SPLIT, int EPI>
 __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx16& acc, int row0, int col, int lane,
-                                              int kslice = 0) {
+                                              int kslice = 0, int mlim = -1) {
     const bool first_slice = kslice == 0;
+    const int M_ = mlim >= 0 ? mlim : p.M;
     if (EPI == EPI_QKV && p.ksplit <= 1) { epilogue_qkv_tile<SPLIT>(p, acc, row0, col, lane); return; }
     const int lhi = lane >> 5;
     const bool col_ok = col < p.N;
@@ -209,7 +212,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
         return;
     }
     const float bv = (p.bias != nullptr && col_ok && first_slice) ? p.bias[col] : 0.f;
-    if ((EPI == EPI_F32R || EPI == EPI_GELU) && row0 + 32 <= p.M && __all(col_ok)) {
+    if ((EPI == EPI_F32R || EPI == EPI_GELU) && row0 + 32 <= M_ && __all(col_ok)) {
         // interior tile of a hot epilogue (every tile when M, N are tile multiples, as at bench scale): no per-element
         // bounds predicate -> no exec-mask save / branch per element
 #pragma unroll
@@ -232,7 +235,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        const bool ok = col_ok && row < p.M;
+        const bool ok = col_ok && row < M_;
         float v = acc[r] + bv;
         if (EPI == EPI_F32R) {
             if (ok) {

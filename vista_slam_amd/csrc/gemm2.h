@@ -47,24 +47,34 @@ __device__ __forceinline__ int lds2_off(int row, int chunk) {
 // for MT x 32 pixels).  Per 32x32 accumulator tile: v = relu(acc + bias), the four head.4 partial dot products of the lane's
 // channel, then a halving butterfly over the 32 channel lanes (62 shuffles for 64 (pixel, output) sums instead of 320);
 // the four waves of a pixel row meet in LDS, and BM threads apply the activations and store pts / conf.
-template <int BM, int MT, int WM, int WAVES_N>
-__device__ __forceinline__ void head_epilogue(const GemmParams& p, const floatx16 (&acc)[MT][1], int m0, int wm, int wn, int tid, char* smem) {
+// Tile row r -> pixel pix_base + (r >> 5) * rstride + (r & 31), stored when (r >> 5) < rows_valid, (r & 31) < cols_valid and
+// the pixel index is < p.M (linear tiles: rstride 32; halo tiles: rstride = image width, conv3h.h).
+// NT accumulator tiles per wave along the channels (a lane then owns NT channels: their products are summed before the butterfly).
+template <int BM, int MT, int NT, int WM, int WAVES_N>
+__device__ __forceinline__ void head_epilogue(const GemmParams& p, const floatx16 (&acc)[MT][NT], int64_t pix_base, int rstride, int rows_valid,
+                                              int cols_valid, int wm, int wn, int tid, char* smem) {
     float* red = reinterpret_cast<float*>(smem);                 // [WAVES_N][BM][4]
     const int lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
-    const int col = wn * 32 + l31;
-    const float bv = p.bias ? p.bias[col] : 0.f;
-    float w4[4];
+    float bv[NT], w4[NT][4];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) w4[o] = p.hw4[o * 128 + col];
+    for (int j = 0; j < NT; ++j) {
+        const int col = (wn * NT + j) * 32 + l31;
+        bv[j] = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) w4[j][o] = p.hw4[o * 128 + col];
+    }
     __syncthreads();                                             // every wave has left the operand stages
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         float part[64];                                          // [r][o]
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float v = fmaxf(acc[i][0][r] + bv, 0.f);
 #pragma unroll
-            for (int o = 0; o < 4; ++o) part[r * 4 + o] = v * w4[o];
+            for (int j = 0; j < NT; ++j) {
+                const float v = fmaxf(acc[i][j][r] + bv[j], 0.f);
+#pragma unroll
+                for (int o = 0; o < 4; ++o) part[r * 4 + o] = j == 0 ? v * w4[j][o] : __builtin_fmaf(v, w4[j][o], part[r * 4 + o]);
+            }
         }
 #pragma unroll
         for (int m = 16, n = 64; m >= 1; m >>= 1, n >>= 1) {     // after the step a lane keeps n/2 sums: the upper half if its bit is set
@@ -84,8 +94,8 @@ __device__ __forceinline__ void head_epilogue(const GemmParams& p, const floatx1
     }
     __syncthreads();
     if (tid < BM) {
-        const int64_t pix = (int64_t)m0 + tid;
-        if (pix < p.M) {
+        const int64_t pix = pix_base + (int64_t)(tid >> 5) * rstride + (tid & 31);
+        if (pix < p.M && (tid >> 5) < rows_valid && (tid & 31) < cols_valid) {
             float4 a = *reinterpret_cast<const float4*>(red + (size_t)tid * 4);
 #pragma unroll
             for (int w = 1; w < WAVES_N; ++w) {
@@ -483,7 +493,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
     }
 
     if constexpr (EPI == EPI_HEAD) {
-        if constexpr (NT == 1 && BN == 128 && WAVES_N == 4) head_epilogue<BM, MT, WM, WAVES_N>(p, acc, m0, wm, wn, tid, smem);
+        if constexpr (BN == 128) head_epilogue<BM, MT, NT, WM, WAVES_N>(p, acc, m0, 32, BM / 32, 32, wm, wn, tid, smem);
     } else {
 #pragma unroll
         for (int j = 0; j < NT; ++j)

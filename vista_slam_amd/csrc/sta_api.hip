@@ -4,7 +4,9 @@
 #include "../../include/sta_mi355.h"
 #include "gemm.h"
 #include "gemm2.h"
+#include "conv3h.h"
 #include "attention.h"
+#include "attention2.h"
 #include "elementwise.h"
 
 #include <cmath>
@@ -105,8 +107,9 @@ struct sta_handle {
     float* skbuf = nullptr;   // fp32 partial sums of split-K GEMMs with the plane epilogue (SKBUF_SLOTS x SKBUF_ELEMS floats)
     float* slab = nullptr;    // slab split-K of the small-M in-place residual GEMMs (GemmParams::slab), same slots and size as skbuf
     int slab_ks = 0;          // set by launch_gemm: K slices the last slab GEMM wrote (0: it did not take the slab path)
+    int opt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // experiment switches (sta_debug_set_option; 0 = product behaviour)
     int tail_hint = 0;      // decode_impl: the last tail_hint rows of every dense GEMM are pose-token rows (GemmParams::m_tail)
-    int gemm_variant = 0;   // 0 auto, 1 force 128x128 kernel, 2 force 256-row kernel (tests/bench only)
+    int gemm_variant = 0;   // tests / tools: 0 auto, 1..4 forced GEMM families, 8 = conv3h wherever legal, 9 = auto WITHOUT conv3h (A/B)
     // rope table
     float* rope_tab = nullptr; int rope_P = 0;
     // timing
@@ -348,6 +351,10 @@ extern "C" int sta_create(const sta_config* cfg, int device, sta_handle** out) {
     REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, "this library is built for gfx950 only, device reports %s", prop.gcnArchName);
     sta_handle* h = new sta_handle();
     h->cfg = *cfg; h->device = device; h->prec = cfg->precision; h->mx_mask = mask_of_precision(cfg->precision);
+    for (int i = 0; i < 8; ++i) {            // experiment switches may also come from the environment (tools): STA_OPT0 .. STA_OPT7
+        char nm[16]; snprintf(nm, sizeof nm, "STA_OPT%d", i);
+        if (const char* v = getenv(nm)) h->opt[i] = atoi(v);
+    }
     if (build_schema(h) != 0) { sta_destroy(h); return -1; }
     h->stage_elems = (int64_t)cfg->mlp_ratio * cfg->enc_embed_dim * cfg->enc_embed_dim;
     int64_t big = (int64_t)768 * 768 * 9;
@@ -407,7 +414,7 @@ extern "C" int sta_set_concurrency(sta_handle* h, int n_slices) {
     return 0;
 }
 extern "C" int sta_set_gemm_variant(sta_handle* h, int variant) {
-    REQUIRE(h && variant >= 0 && variant <= 4, "bad gemm variant");
+    REQUIRE(h && ((variant >= 0 && variant <= 4) || variant == 8 || variant == 9), "bad gemm variant");
     h->gemm_variant = variant;
     return 0;
 }
@@ -480,6 +487,24 @@ static int launch_gemm2(const GemmParams& p, hipStream_t st, int dev = 0) {
     hipLaunchKernelGGL((gemm2_kernel<SPLIT, AMODE, EPI, BM, BN, WMS, WNS, 0, NSTG, MX>), dim3((unsigned)(tm * tn * ks + ntail)), dim3(WMS * WNS * 64), smem, st, p);
     return 0;
 }
+
+template <bool SPLIT, int EPI, int BM, int BN, bool MX, int WMS = 4, int WNS = 4, int NSTGB = 2>
+static int launch_conv3h(const GemmParams& p, hipStream_t st, int dev) {
+    static unsigned attr_done = 0;        // one bit per device
+    constexpr int smem = conv3h_smem_bytes<SPLIT, BM, BN>(NSTGB);
+    static_assert(smem <= 160 * 1024, "conv3h: LDS budget");
+    auto kern = conv3h_kernel<SPLIT, EPI, BM, BN, WMS, WNS, MX, NSTGB>;
+    if (!(attr_done >> (dev & 31) & 1u)) {
+        HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_done |= 1u << (dev & 31);
+    }
+    const int n_img = p.M / (p.Ho * p.Wo);
+    const int tiles = n_img * ((p.Ho + BM / 32 - 1) / (BM / 32)) * ((p.Wo + 31) / 32) * ((p.N + BN - 1) / BN);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(WMS * WNS * 64), smem, st, p);
+    return 0;
+}
+
+static inline bool auto_family(const sta_handle* h) { return h->gemm_variant == 0 || h->gemm_variant == 9; }
 
 // The ONE small-grid predicate (SLAM scale: 224x224, batch 1..6 -> M = 196..2400 rows): below it the 128x64 split-K family
 // runs (launch_gemm), in-place residual GEMMs hand their K slices to resid_ln_kernel (gemm_resid_ln), and the specialised
@@ -582,6 +607,9 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
         variant = (p.N % 256 == 0 && EPI != EPI_QKV) ? h->gemm_variant : 5;
     if (h->gemm_variant == 4 && variant != 6 && p.N % 128 == 0) variant = 5;
     if (h->gemm_variant == 1) variant = 1;
+    // 8: halo-tiled 3x3 convolution (conv3h.h): stride 1, Cout 128 / 256, at throughput scale (or forced: tests)
+    if (AMODE == A_CONV3 && (EPI == EPI_F16 || EPI == EPI_HEAD) && p.cstride == 1 && (p.N == 128 || p.N == 256) &&
+        ((h->gemm_variant == 0 && p.M >= 32768 && p.Wo >= 32 && variant != 6) || h->gemm_variant == 8)) variant = 8;
     if (variant != 6) { p.ksplit = 1; h->slab_ks = 0; }
     if (h->slab_ks == 0) p.slab = nullptr;
     p.M = M_all;
@@ -611,6 +639,30 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
         h->kn++;
     }
     if (timed && variant == 5) p.clk_dbg = h->clk_buf;   // effective-clock probe (bench only)
+    if constexpr (AMODE == A_CONV3 && (EPI == EPI_F16 || EPI == EPI_HEAD)) {
+        if (variant == 8) {
+            REQUIRE((int64_t)p.Ho * p.Wo > 0 && p.M % (p.Ho * p.Wo) == 0, "internal: conv3h needs whole images");
+            const int cfg = h->opt[0];      // experiments (sta_debug_set_option 0): conv3h configuration of the Cout = 128 tile
+            if (p.N == 128 || (cfg & 8)) {  // (cfg & 8: Cout = 256 as two 128-column tiles as well)
+                if ((cfg & 3) == 1 && split) {
+                    if (p.mx) CHK((launch_conv3h<true, EPI, 256, 128, true, 4, 4, 3>(p, st, h->device)));
+                    else CHK((launch_conv3h<true, EPI, 256, 128, false, 4, 4, 3>(p, st, h->device)));
+                } else if ((cfg & 3) == 2 && split) {
+                    if (p.mx) CHK((launch_conv3h<true, EPI, 256, 128, true, 4, 2, 3>(p, st, h->device)));
+                    else CHK((launch_conv3h<true, EPI, 256, 128, false, 4, 2, 3>(p, st, h->device)));
+                } else
+                if (p.mx) CHK((launch_conv3h<true, EPI, 256, 128, true>(p, st, h->device)));
+                else if (split) CHK((launch_conv3h<true, EPI, 256, 128, false>(p, st, h->device)));
+                else STA_F16ONLY(CHK((launch_conv3h<false, EPI, 256, 128, false>(p, st, h->device))));
+            } else if constexpr (EPI == EPI_F16) {
+                if (p.mx) CHK((launch_conv3h<true, EPI, 256, 256, true>(p, st, h->device)));
+                else if (split) CHK((launch_conv3h<true, EPI, 256, 256, false>(p, st, h->device)));
+                else STA_F16ONLY(CHK((launch_conv3h<false, EPI, 256, 256, false>(p, st, h->device))));
+            }
+        }
+    }
+    if (variant == 8) {
+    } else
     if constexpr (EPI == EPI_HEAD) {      // exists for the 192x128 family only (conv3_head checks the shape)
         REQUIRE(variant == 5 && p.N == 128, "internal: fused head epilogue on a tile family without it");
         if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4, 2, true>(p, st, h->device)));
@@ -710,7 +762,7 @@ static int gemm_resid_ln(sta_handle* h, const Planes& A, const Lin& W, int M, fl
                          const LNp* lb, const Planes* ob, bool ln_mx, hipStream_t st) {
     static const LNp no_ln = {nullptr, nullptr};
     static const Planes no_planes;
-    const bool small = small_grid(M, W.N) && W.N % 64 == 0 && W.N <= 1024 && h->gemm_variant == 0 && ld == W.N;
+    const bool small = small_grid(M, W.N) && W.N % 64 == 0 && W.N <= 1024 && auto_family(h) && ld == W.N;
     h->slab_ks = 0;
     if (small) {
         int slot = 0;
@@ -755,7 +807,7 @@ static int gemm_qkv_pair(sta_handle* h, const GemmParams& pa_in, const GemmParam
     const bool split = h->prec != STA_PREC_F16;
     auto big = [](const GemmParams& p) { return p.N % 128 == 0 && !small_grid(p.M, p.N); };
     if (h->dry) return 0;
-    if (!split || pa.mx || pb.mx || !big(pa) || !big(pb) || pa.K != pb.K || pa.M != pb.M || h->gemm_variant != 0) {
+    if (!split || pa.mx || pb.mx || !big(pa) || !big(pb) || pa.K != pb.K || pa.M != pb.M || !auto_family(h)) {
         CHK((launch_gemm<A_DENSE, EPI_QKV>(h, pa, st)));
         return launch_gemm<A_DENSE, EPI_QKV>(h, pb, st);
     }
@@ -820,7 +872,7 @@ static int conv3(sta_handle* h, const Planes& in, int nimg, int Hi, int Wi, int 
 // head.2 (3x3 conv 128 -> 128) + ReLU + head.4 (1x1 conv 128 -> 4) + point-map / confidence activations as ONE kernel
 // (EPI_HEAD): true when it was launched; false = the caller runs conv3 + head_final_kernel (small grids, forced tile families).
 static bool conv3_head_ok(sta_handle* h, const Lin& W, int64_t M) {
-    return W.N == 128 && h->gemm_variant == 0 && (M + 191) / 192 >= 128;
+    return W.N == 128 && ((auto_family(h) && (M + 191) / 192 >= 128) || h->gemm_variant == 8);
 }
 static int conv3_head(sta_handle* h, const Planes& in, int nimg, int Hi, int Wi, int Cin, const Lin& W, const F32Lin& W4,
                       float* ptsA, float* confA, int nA, float* ptsB, float* confB, hipStream_t st) {
@@ -876,11 +928,52 @@ static int run_attn(sta_handle* h, const QKVOut& qkv, const Planes& out, int ldo
     p.O_hi = out.hi; p.O_lo = out.lo; p.ldo = ldo;
     p.S = S; p.heads = heads; p.nq = nq; p.nk = nk; p.npad = qkv.npad; p.kv_shift = kv_shift;
     p.scale_log2e = 0.125f * 1.44269504088896340736f;
-    dim3 grid((unsigned)(((nq + 127) / 128) * heads * S + (pose ? (S * heads + 3) / 4 : 0)));
+    const int npose = pose ? (S * heads + 3) / 4 : 0;
     REQUIRE(!pose || (int64_t)4 * qkv.npad * 4 <= attn_smem_bytes<false>(), "internal: pose-query scratch exceeds the LDS allocation");
+    // throughput scale: the software-pipelined kernel (attention2.h: 256 queries per workgroup, one workgroup per CU) once
+    // its grid fills the chip; experiment switch 1 forces either kernel (tests)
+    const int blocks2 = ((nq + 255) / 256) * heads * S;
+    const bool use2 = h->prec != STA_PREC_F16 && (h->opt[1] == 1 || (h->opt[1] == 0 && blocks2 >= 256 && nq >= 192));
+    if (use2) {
+        dim3 grid((unsigned)(blocks2 + (pose ? (S * heads + 7) / 8 : 0)));
+        REQUIRE(!pose || (int64_t)8 * qkv.npad * 4 <= attn2_smem_bytes<false>(), "internal: pose-query scratch exceeds the LDS allocation");
+        {
+            static unsigned attr_done = 0;      // one bit per device
+            if (!(attr_done >> (h->device & 31) & 1u)) { HIPCHK(hipFuncSetAttribute((const void*)attn2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, attn2_smem_bytes<true>())); attr_done |= 1u << (h->device & 31); }
+#ifdef STA_BENCH_EXPERIMENTS      // component ablations of the tile body (tools/attn_bench.py ablate): opt[2] = ABL bits
+            auto abl = [&](auto a_c) {
+                constexpr int A = decltype(a_c)::value;
+                hipFuncSetAttribute((const void*)attn2_kernel<true, A>, hipFuncAttributeMaxDynamicSharedMemorySize, attn2_smem_bytes<true>());
+                hipLaunchKernelGGL((attn2_kernel<true, A>), grid, dim3(512), attn2_smem_bytes<true>(), st, p);
+            };
+            using std::integral_constant;
+            switch (h->opt[2]) {
+                case 1: abl(integral_constant<int, 1>{}); break;
+                case 2: abl(integral_constant<int, 2>{}); break;
+                case 3: abl(integral_constant<int, 3>{}); break;
+                case 4: abl(integral_constant<int, 4>{}); break;
+                case 7: abl(integral_constant<int, 7>{}); break;
+                case 8: abl(integral_constant<int, 8>{}); break;
+                case 14: abl(integral_constant<int, 14>{}); break;
+                case 15: abl(integral_constant<int, 15>{}); break;
+                default: hipLaunchKernelGGL(attn2_kernel<true>, grid, dim3(512), attn2_smem_bytes<true>(), st, p);
+            }
+#else
+            hipLaunchKernelGGL(attn2_kernel<true>, grid, dim3(512), attn2_smem_bytes<true>(), st, p);
+#endif
+        }
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    dim3 grid((unsigned)(((nq + 127) / 128) * heads * S + npose));
     if (h->prec != STA_PREC_F16) {
         static unsigned attr_done = 0;      // one bit per device
         if (!(attr_done >> (h->device & 31) & 1u)) { hipFuncSetAttribute((const void*)attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_smem_bytes<true>()); attr_done |= 1u << (h->device & 31); }
+        if (h->opt[3] == 1) {       // experiment: fp16-rounded probabilities in numerator and denominator (attention.h PMODE)
+            static bool attr1 = false;
+            if (!attr1) { hipFuncSetAttribute((const void*)attn_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_smem_bytes<true>()); attr1 = true; }
+            hipLaunchKernelGGL((attn_kernel<true, 1>), grid, dim3(256), attn_smem_bytes<true>(), st, p);
+        } else
         hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), attn_smem_bytes<true>(), st, p);
     } else {
         STA_F16ONLY(hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), attn_smem_bytes<false>(), st, p));
