@@ -101,6 +101,18 @@ int sta_set_deterministic(sta_handle* h, int on);
  * identical per pair (no cross-pair arithmetic).  No reference counterpart (torch runs one stream). */
 int sta_set_concurrency(sta_handle* h, int n_slices);
 
+/* Range report.  Activations travel between kernels as fp16 planes (hi + residual), the f16mx arithmetic adds e4m3 copies:
+ * values beyond +-65504 (or NaN) SATURATE when they are written to a plane, e4m3 correction bytes saturate at +-448 (the result
+ * then degrades towards single-fp16 accuracy for those elements).  Neither can be seen in the outputs, so the writers of every
+ * tensor that is NOT a function of a LayerNorm output count them - the input and hook conversions, every plane of the DPT head
+ * (which has no normalisation layers: convolutions, transposed convolutions, bilinear), the split-K finishers - and the
+ * LayerNorm kernels count non-finite rows of the residual streams: counts[0] = fp16-range events, counts[1] = e4m3
+ * saturations on this handle's device since the last reset (events = (lane, tile) pairs with at least one such value;
+ * device-wide: all handles on one GPU share the counters; the call synchronises the device).  QKV / attention / mlp.fc1 outputs
+ * are bounded by their LayerNorm inputs and are not counted (0.7 % of the step if they were).  A non-zero counts[0] means the
+ * forward left the range the parity goldens cover - the reference (fp32) has no such limit.  reset != 0 clears them. */
+int sta_range_report(sta_handle* h, unsigned long long counts[2], int reset);
+
 /* Number of state_dict entries the handle expects / has received so far. */
 int sta_num_expected_tensors(const sta_handle* h);
 int sta_num_loaded_tensors(const sta_handle* h);
@@ -270,9 +282,8 @@ int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, int tile, int 
 /* Effective shader clock (GHz) observed inside the kernel of the last sta_bench_gemm call (s_memtime cycles per
  * 100 MHz s_memrealtime tick, sampled on every 64th workgroup): the chip clocks to its power budget (DVFS). */
 float sta_bench_gemm_last_ghz(void);
-/* The attention kernel alone on random operands (tools): ms per launch over `iters` back-to-back launches.  which: 0 = the
- * automatic choice, 1 = the software-pipelined kernel (attention2.h), 2 = the small-grid kernel (attention.h); pose != 0: the
- * decoder form (nq == nk patch tokens + the pose token). */
+/* The attention kernel alone on random operands (tools): ms per launch over `iters` back-to-back launches.  pose != 0: the
+ * decoder form (nq == nk patch tokens + the pose token).  which: reserved for kernel variants under test, pass 0. */
 int sta_bench_attention(sta_handle* h, int S, int heads, int nq, int nk, int pose, int iters, int which, float* ms_out, void* stream);
 
 

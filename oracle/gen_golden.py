@@ -35,9 +35,9 @@ def _views(img_a, img_b, H, W_):
             "neighbor_views": [{"img": img_b, "true_shape": ts}], "loop_views": []}
 
 
-def run_case(name, cfg, H, W_, B, qk_gain=1.0, taps=False, sub=1, smooth=False, seed=43):
+def run_case(name, cfg, H, W_, B, qk_gain=1.0, taps=False, sub=1, smooth=False, seed=43, outlier=0):
     t0 = time.time()
-    sd = W.state_dict(cfg, seed=seed, qk_gain=qk_gain)
+    sd = W.state_dict(cfg, seed=seed, qk_gain=qk_gain, outlier=outlier)
     model = load_reference_model(cfg, sd)
     gen = W.smooth_images if smooth else W.synth_images
     imgs = gen(2 * B, H, W_, seed=seed, tag=0)
@@ -100,8 +100,17 @@ def run_case(name, cfg, H, W_, B, qk_gain=1.0, taps=False, sub=1, smooth=False, 
             # follows sta_model.py:257-277: enc(main), enc(supp), dec..., head(supp), head(main))
             for i, t in enumerate(store[:2]):
                 res[f"tap_{key}_{i}"] = t.numpy()
-    meta = dict(H=H, W=W_, B=B, qk_gain=qk_gain, sub=sub, smooth=int(smooth), seed=seed,
+    meta = dict(H=H, W=W_, B=B, qk_gain=qk_gain, sub=sub, smooth=int(smooth), seed=seed, outlier=outlier,
                 **{f"cfg_{k}": v for k, v in cfg.as_dict().items() if not isinstance(v, tuple)})
+    if outlier:         # how far the statistics actually went (the fp32 reference's own tensors): residual-stream / DPT ranges
+        res["range_enc_feat_absmax"] = np.float32(fa.abs().max())
+        res["range_dec_hook_absmax"] = np.float32(max(float(t.abs().max()) for t in d1))
+        dpt = model.downstream_head_pts.dpt
+        with torch.no_grad():
+            feats = [fa] + [d1[h - 1][:, 1:] for h in cfg.hooks[1:]]
+            n_h, n_w = H // cfg.patch_size, W_ // cfg.patch_size
+            lay = [dpt.act_postprocess[k](f.transpose(1, 2).reshape(f.shape[0], -1, n_h, n_w)) for k, f in enumerate(feats)]
+            res["range_dpt_layers_absmax"] = np.array([float(x.abs().max()) for x in lay], np.float32)
     res["meta_keys"] = np.array(list(meta.keys()))
     res["meta_vals"] = np.array([float(v) for v in meta.values()], dtype=np.float64)
     os.makedirs(OUT, exist_ok=True)
@@ -352,6 +361,15 @@ CASES = {
     "portrait": [
         dict(name="tiny_80x48_b2_portrait", cfg=W.TINY, H=80, W_=48, B=2, taps="light"),
         dict(name="full_512x384_b1_portrait", cfg=W.FULL, H=512, W_=384, B=1, sub=16),
+    ],
+    # trained-checkpoint-like RANGE statistics (weights.py `_outlier`): heavy-tailed LayerNorm gains, massive activation
+    # channels in both residual streams, DPT feature maps 300x larger (past the e4m3 correction range of the f16mx
+    # arithmetic); `overflow`: DPT feature maps past the fp16 range - the library must REPORT it (sta_range_report)
+    "outlier": [
+        dict(name="tiny_48x64_b2_outlier", cfg=W.TINY, H=48, W_=64, B=2, taps="light", outlier=1),
+        dict(name="tiny_48x80_outlier_sharp", cfg=W.TINY, H=48, W_=80, B=1, qk_gain=4.0, smooth=True, outlier=1, seed=45),
+        dict(name="full_224_b1_outlier", cfg=W.FULL, H=224, W_=224, B=1, sub=8, outlier=1),
+        dict(name="tiny_48x64_b1_overflow", cfg=W.TINY, H=48, W_=64, B=1, outlier=2),
     ],
     "full224": [
         dict(name="full_224_b1", cfg=W.FULL, H=224, W_=224, B=1, sub=8),

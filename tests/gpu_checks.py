@@ -14,6 +14,7 @@ from vista_slam_amd.sta_frontend import STAFrontend, rope2d_inplace
 
 DEV = "cuda:0"
 _models = {}
+last_range = (0, 0)      # (fp16 saturations, e4m3 saturations) counted during the last run_golden_case (sta_range_report)
 
 
 def dev(a):
@@ -24,13 +25,13 @@ def st():
     return torch.cuda.current_stream().cuda_stream
 
 
-def model(cfg_name="tiny", qk_gain=1.0, precision="f16x3", seed=43):
-    """Cached frontends (weights are procedural, so (cfg, gain, seed) identifies them)."""
-    key = (cfg_name, qk_gain, seed)
+def model(cfg_name="tiny", qk_gain=1.0, precision="f16x3", seed=43, outlier=0):
+    """Cached frontends (weights are procedural, so (cfg, gain, seed, outlier level) identifies them)."""
+    key = (cfg_name, qk_gain, seed, outlier)
     if key not in _models:
         cfg = W.TINY if cfg_name == "tiny" else W.FULL
         m = STAFrontend(cfg, DEV, precision=precision)
-        m.load_procedural(seed=seed, qk_gain=qk_gain)
+        m.load_procedural(seed=seed, qk_gain=qk_gain, outlier=outlier)
         _models[key] = m
     m = _models[key]
     m.set_precision(precision)
@@ -101,10 +102,8 @@ def check_qkv_rope(precision, S=2, hp=3, wp=4, pose_tok=1, K=128, Cdim=128, seed
             "vpad_abs": float(np.abs(pad).max()) if pad.size else 0.0}
 
 
-def check_attention(precision, S=2, heads=2, nq=197, nk=197, kv_shift=0, sharp=1.0, seed=2, kernel=0):
-    """kernel: 0 = the library's choice, 1 = the software-pipelined throughput kernel (attention2.h), 2 = attention.h"""
+def check_attention(precision, S=2, heads=2, nq=197, nk=197, kv_shift=0, sharp=1.0, seed=2):
     m, lib, h = kernel_handle(precision)
-    _lib.check(lib.sta_debug_set_option(h, 1, kernel))
     g = torch.Generator().manual_seed(seed)
     q = torch.randn(S, heads, nq, 64, generator=g) * sharp
     k = torch.randn(S, heads, nk, 64, generator=g)
@@ -114,12 +113,9 @@ def check_attention(precision, S=2, heads=2, nq=197, nk=197, kv_shift=0, sharp=1
     ref = (a.softmax(-1) @ v[idx].double()).permute(0, 2, 1, 3).reshape(S, nq, heads * 64)
     out = torch.empty(S, nq, heads * 64, device=DEV)
     qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
-    try:
-        _lib.check(lib.sta_debug_attention(h, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), S, heads, nq, nk,
-                                           kv_shift, out.data_ptr(), st()))
-        torch.cuda.synchronize()
-    finally:
-        _lib.check(lib.sta_debug_set_option(h, 1, 0))
+    _lib.check(lib.sta_debug_attention(h, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), S, heads, nq, nk,
+                                       kv_shift, out.data_ptr(), st()))
+    torch.cuda.synchronize()
     o = out.cpu().numpy()
     return {"rel_l2": rel_l2(o, ref.numpy()), "max_rel": max_rel(o, ref.numpy()), "nan": float(np.isnan(o).sum())}
 
@@ -168,7 +164,7 @@ def check_qkv_rope_decoder_rows(precision, S=2, hp=3, wp=4, K=128, Cdim=128, see
             "vpad_abs": float(np.abs(pad).max()) if pad.size else 0.0}
 
 
-def check_attention_pose(precision, S=2, heads=2, n=196, kv_shift=0, sharp=1.0, seed=13, kernel=0):
+def check_attention_pose(precision, S=2, heads=2, n=196, kv_shift=0, sharp=1.0, seed=13):
     """Decoder form of the attention kernel: n patch tokens + the pose token (last): as a key it is folded into the initial
     softmax state, as a query it is served by the pose blocks."""
     m, lib, h = kernel_handle(precision)
@@ -183,12 +179,8 @@ def check_attention_pose(precision, S=2, heads=2, n=196, kv_shift=0, sharp=1.0, 
     ref = torch.cat([ref[:, :n].reshape(S * n, heads * 64), ref[:, n]], 0)       # decoder row order
     out = torch.empty(S * n + S, heads * 64, device=DEV)
     qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
-    _lib.check(lib.sta_debug_set_option(h, 1, kernel))
-    try:
-        _lib.check(lib.sta_debug_attention_pose(h, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), S, heads, n, kv_shift, out.data_ptr(), st()))
-        torch.cuda.synchronize()
-    finally:
-        _lib.check(lib.sta_debug_set_option(h, 1, 0))
+    _lib.check(lib.sta_debug_attention_pose(h, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), S, heads, n, kv_shift, out.data_ptr(), st()))
+    torch.cuda.synchronize()
     o = out.cpu().numpy()
     return {"rel_l2": rel_l2(o, ref.numpy()), "rel_l2_pose": rel_l2(o[S * n:], ref.numpy()[S * n:]),
             "max_rel": max_rel(o, ref.numpy()), "nan": float(np.isnan(o).sum())}
@@ -319,9 +311,10 @@ def run_golden_case(name, precision, taps=True, variant=0):
     """HIP forward on the procedural inputs of a golden case; returns {key: rel-L2 error}."""
     g, meta = load_golden(name)
     cfg_name = "tiny" if int(meta["cfg_enc_embed_dim"]) == W.TINY.enc_embed_dim else "full"
-    m = model(cfg_name, float(meta["qk_gain"]), precision, int(meta["seed"]))
+    m = model(cfg_name, float(meta["qk_gain"]), precision, int(meta["seed"]), int(meta.get("outlier", 0)))
     set_variant(m, variant)
     cfg = m.cfg
+    m.range_report(reset=True)
     H, W_, B, sub = int(meta["H"]), int(meta["W"]), int(meta["B"]), int(meta["sub"])
     gen = W.smooth_images if int(meta["smooth"]) else W.synth_images
     imgs = gen(2 * B, H, W_, seed=int(meta["seed"]), tag=0)
@@ -356,6 +349,6 @@ def run_golden_case(name, precision, taps=True, variant=0):
     res["split_pts_vs_golden"] = rel_l2(hp["pts3d"].cpu().numpy()[:, ::sub, ::sub], g["main_pts3d"])
     if taps and "dec1_in" in g:
         res["dec1_in"] = rel_l2(d1[0].cpu().numpy(), g["dec1_in"])
-        if "tap_enc_block0_0" in g:
-            pass
+    global last_range
+    last_range = m.range_report(reset=True)
     return res

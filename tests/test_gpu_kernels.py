@@ -117,26 +117,6 @@ def test_up2(G, prec, kw):
 
 
 @pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("kw", [dict(), dict(kv_shift=1), dict(nq=70, nk=130, sharp=6.0), dict(S=1, heads=1, nq=769, nk=769, sharp=3.0),
-                                dict(nq=1, nk=1), dict(nq=256, nk=64), dict(nq=300, nk=129, sharp=10.0), dict(nq=512, nk=192, S=3, kv_shift=2)])
-def test_attention_pipelined_kernel(G, prec, kw):
-    """attention2.h forced (the library picks it at throughput scale only): ragged query blocks, 1..13 key tiles incl. the
-    partly valid one, cross-attention shift, sharp softmax."""
-    r = G.check_attention(prec, kernel=1, **kw)
-    assert r["nan"] == 0, r
-    assert r["rel_l2"] < TOL[prec], r
-
-
-@pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("kw", [dict(), dict(kv_shift=1), dict(n=768, S=2, heads=1, sharp=3.0), dict(n=12, sharp=6.0), dict(n=64), dict(n=128),
-                                dict(n=129, sharp=10.0, S=3, heads=1, kv_shift=2)])
-def test_attention_pose_token_pipelined_kernel(G, prec, kw):
-    r = G.check_attention_pose(prec, kernel=1, **kw)
-    assert r["nan"] == 0, r
-    assert r["rel_l2"] < TOL[prec] and r["rel_l2_pose"] < TOL[prec], r
-
-
-@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("C", [128, 768, 1024])
 def test_layernorm(G, prec, C):
     r = G.check_layernorm(prec, Cdim=C)

@@ -29,6 +29,38 @@ def test_tiny_goldens_default_precision(G, case, prec):
     r = G.run_golden_case(case, prec)
     bad = {k: v for k, v in r.items() if v > TOL}
     assert not bad, bad
+    assert G.last_range == (0, 0), f"a plane writer saturated on an ordinary golden: {G.last_range} (sta_range_report)"
+
+
+OUTLIER = ["tiny_48x64_b2_outlier", "tiny_48x80_outlier_sharp", "full_224_b1_outlier"]
+
+
+@pytest.mark.parametrize("prec", [DEFAULT, "f16x3"])
+@pytest.mark.parametrize("case", OUTLIER)
+def test_outlier_statistics_goldens(G, case, prec):
+    """Trained-checkpoint-like RANGE statistics from the imported reference (weights.py `_outlier`):
+    LayerNorm gains with a 3..10x tail, three massive-activation channels (+80 / -60 / +50) in both residual streams, DPT
+    feature maps 300x larger (up to 6.5e3: past the +-448 of the e4m3 correction bytes of the head's f16mx arithmetic, inside
+    the fp16 range).  The shipped policy must hold the 1e-3 bar, nothing may leave the fp16 range, and the e4m3 saturation
+    (f16x3h only) is counted, not silent."""
+    if case.startswith("full"):
+        G.drop_models()
+    r = G.run_golden_case(case, prec)
+    bad = {k: v for k, v in r.items() if v > TOL}
+    assert not bad, (bad, G.last_range)
+    assert G.last_range[0] == 0, f"fp16 saturation inside the range the reference golden covers: {G.last_range}"
+    if prec == "f16x3":
+        assert G.last_range[1] == 0, "f16x3 has no e4m3 bytes"
+
+
+@pytest.mark.parametrize("prec", [DEFAULT, "f16x3"])
+def test_range_overflow_is_reported_not_silent(G, prec):
+    """DPT feature maps 3e4x larger (up to 5e5: past the fp16 planes' +-65504; the fp32 reference is unaffected): the planes
+    saturate, so the result is NOT expected to match - but the library must say so (sta_range_report counts[0] > 0)."""
+    G.run_golden_case("tiny_48x64_b1_overflow", prec)
+    assert G.last_range[0] > 0, G.last_range
+    m = G.model("tiny", 1.0, prec, 43, 2)
+    assert m.range_report() == (0, 0), "the report resets"
 
 
 @pytest.mark.parametrize("case", STRESS)
@@ -39,6 +71,7 @@ def test_stress_goldens_default_precision(G, case):
     r = G.run_golden_case(case, DEFAULT)
     bad = {k: v for k, v in r.items() if v > TOL}
     assert not bad, bad
+    assert G.last_range == (0, 0), G.last_range
 
 
 @pytest.mark.parametrize("case", ["tiny_48x64_b2", "tiny_48x80_smooth_sharp"])
@@ -65,6 +98,7 @@ def test_full_goldens_default_precision(G, case):
     r = G.run_golden_case(case, DEFAULT)
     bad = {k: v for k, v in r.items() if v > TOL}
     assert not bad, bad
+    assert G.last_range == (0, 0), G.last_range
 
 
 @pytest.mark.parametrize("case", ["tiny_80x48_b2_portrait", "full_512x384_b1_portrait"])
@@ -283,12 +317,13 @@ def np_concat(x, y):
     return np.ascontiguousarray(np.concatenate([x, y], 0))
 
 
-def test_u8_hwc_input_matches_normalised_fp32(G):
+@pytest.mark.parametrize("prec", [DEFAULT, "f16x3"])
+def test_u8_hwc_input_matches_normalised_fp32(G, prec):
     """f3 (input step): uint8 HWC frames with the reference ImgNorm fused into the patch gather give
     exactly the encoder features / outputs of the fp32 NCHW path."""
     import torch
     from vista_slam_amd import weights as W
-    m = G.model("tiny", 1.0, "f16x3")
+    m = G.model("tiny", 1.0, prec)
     G.set_variant(m, 0)
     f32 = torch.from_numpy(W.synth_images(4, 48, 64, seed=43, tag=5)).cuda()
     u8 = torch.from_numpy(W.synth_images_u8(4, 48, 64, seed=43, tag=5)).cuda()
@@ -306,14 +341,15 @@ def test_u8_hwc_input_matches_normalised_fp32(G):
         assert rel_l2(m2[k].cpu().numpy(), m1[k].cpu().numpy()) < 1e-5 and rel_l2(s2[k].cpu().numpy(), s1[k].cpu().numpy()) < 1e-5
 
 
-def test_two_slice_concurrency_matches_single_stream(G):
+@pytest.mark.parametrize("prec", [DEFAULT, "f16x3"])
+def test_two_slice_concurrency_matches_single_stream(G, prec):
     """sta_set_concurrency(2): two batch slices on internal streams, forked/joined on the caller's stream,
     give the single-stream outputs (odd batch -> uneven slices; full-config weights at 224x224)."""
     import torch
     from helpers import rel_l2
     from vista_slam_amd import weights as W
     for cfg, B, H, Wd in (("tiny", 5, 48, 64), ("full", 3, 224, 224)):
-        m = G.model(cfg, 1.0, "f16x3")
+        m = G.model(cfg, 1.0, prec)
         G.set_variant(m, 0)
         imgs = torch.from_numpy(W.synth_images(2 * B, H, Wd, seed=43, tag=9)).cuda()
         m.set_concurrency(1)
@@ -359,7 +395,8 @@ def test_input_step_f3_bit_exact_to_pillow_goldens(G, path):
     assert abs(float(out["rgb"].double().sum()) - float(g["rgb_sum"])) < 1e-6 * out["rgb"].numel()
 
 
-def test_input_step_f3_vs_oracle_random_geometries_and_encoder_handoff(G):
+@pytest.mark.parametrize("prec", [DEFAULT, "f16x3"])
+def test_input_step_f3_vs_oracle_random_geometries_and_encoder_handoff(G, prec):
     """Random source sizes / edges / targets against the oracle (bit-exact), the cached-table switch between
     geometries, error cases, and the hand-off: encode_u8hwc(u8) == _encode_image(rgb)."""
     import numpy as np
@@ -368,7 +405,7 @@ def test_input_step_f3_vs_oracle_random_geometries_and_encoder_handoff(G):
     from oracle import preprocess_oracle as P
     from vista_slam_amd import weights as W
     from vista_slam_amd.preprocess import process_image
-    m = G.model("tiny", 1.0, "f16x3")
+    m = G.model("tiny", 1.0, prec)
     rng = np.random.default_rng(7)
     for it in range(8):
         Hs = int(rng.integers(120, 700)); Ws = int(Hs * rng.uniform(1.15, 2.2))
@@ -404,14 +441,15 @@ def test_input_step_f3_vs_oracle_random_geometries_and_encoder_handoff(G):
         process_image(m, src, (48, 64))
 
 
-def test_output_step_f4_pointcloud_and_files(G, tmp_path):
+@pytest.mark.parametrize("prec", [DEFAULT, "f16x3"])
+def test_output_step_f4_pointcloud_and_files(G, tmp_path, prec):
     """f4: world point cloud vs the reference golden (compute_local_pointclouds + bmm + mask order), PLY records,
     the save_data_all file set re-read the way eval_recon.load_data does, and mat -> SE3."""
     import numpy as np
     import torch
     from helpers import load_golden, max_rel
     from vista_slam_amd import formats as F
-    m = G.model("tiny", 1.0, "f16x3")
+    m = G.model("tiny", 1.0, prec)
     g = load_golden("fmt")[0]
     pts, col, rec = F.world_pointcloud(m, g["depths"], g["scales"], g["intrinsics"], g["poses"], g["confs"], g["imgs"],
                                        float(g["thres"]), want_records=True)
@@ -467,7 +505,8 @@ def _sequential_regress(m, feats, pos, i, j, thres, H, Wd):
 
 
 @pytest.mark.parametrize("cfg,H,Wd,nview", [("tiny", 48, 64, 6), ("full", 224, 224, 4)])
-def test_keyframe_scheduler_f2_matches_sequential_edges(G, cfg, H, Wd, nview):
+@pytest.mark.parametrize("prec", [DEFAULT, "f16x3"])
+def test_keyframe_scheduler_f2_matches_sequential_edges(G, cfg, H, Wd, nview, prec):
     """f2: one batched sta_regress_views call == the reference's per-edge regress_two_views sequence, incl. the
     early reject (threshold set between the observed confidences so both branches are exercised) and the
     adjacent-edge exemption."""
@@ -475,7 +514,7 @@ def test_keyframe_scheduler_f2_matches_sequential_edges(G, cfg, H, Wd, nview):
     from helpers import rel_l2
     from vista_slam_amd import weights as W
     from vista_slam_amd.slam_scheduler import regress_views
-    m = G.model(cfg, 1.0, "f16x3")
+    m = G.model(cfg, 1.0, prec)
     G.set_variant(m, 0)
     imgs = torch.from_numpy(W.synth_images(nview, H, Wd, seed=43, tag=21)).cuda()
     feats, pos = [], None
@@ -498,15 +537,19 @@ def test_keyframe_scheduler_f2_matches_sequential_edges(G, cfg, H, Wd, nview):
             n_rej += 1
             assert r.confs is None and r.intri is None and r.depths is None
             continue
-        assert rel_l2(r.confs.cpu().numpy(), confs.cpu().numpy()) < 2e-5
-        assert rel_l2(r.depths.cpu().numpy(), depths.cpu().numpy()) < 2e-5
-        assert rel_l2(r.intri.cpu().numpy(), intri.cpu().numpy()) < 2e-5
+        # (the batched call picks other tile families / split-K forms than the B = 1 calls: same arithmetic, other summation
+        # orders; in the default policy the DPT head's fp8 correction term makes that a 1e-5-class difference)
+        ctol = 2e-5 if prec == "f16x3" else 6e-5
+        assert rel_l2(r.confs.cpu().numpy(), confs.cpu().numpy()) < ctol
+        assert rel_l2(r.depths.cpu().numpy(), depths.cpu().numpy()) < ctol
+        assert rel_l2(r.intri.cpu().numpy(), intri.cpu().numpy()) < ctol
     assert res[-1].accepted                      # the adjacent edge is never rejected (slam.py:169)
     assert 0 < n_rej < len(js)
 
 
 @pytest.mark.parametrize("name,cfg", [("f2_tiny_48x64", "tiny"), ("f2_tiny_80x48_portrait", "tiny"), ("f2_full_224", "full")])
-def test_keyframe_scheduler_f2_vs_reference_golden(G, name, cfg):
+@pytest.mark.parametrize("prec", [DEFAULT, "f16x3"])
+def test_keyframe_scheduler_f2_vs_reference_golden(G, name, cfg, prec):
     """f2 pinned by the reference: sta_regress_views (one batched call for all edges of the keyframe) and the per-edge
     split calls vs tests/golden/f2_*.npz = regress_two_views (slam.py:153-189) replayed on the reference model with the
     reference's estimate_intrinsic_from_pts3d (oracle/gen_golden.py gen_f2): accepted / rejected edges and the
@@ -521,7 +564,7 @@ def test_keyframe_scheduler_f2_vs_reference_golden(G, name, cfg):
         G.drop_models()
     g, meta = load_golden(name)
     H, Wd, nview, sub = int(meta["H"]), int(meta["W"]), int(meta["nview"]), int(meta["sub"])
-    m = G.model(cfg, 1.0, "f16x3")
+    m = G.model(cfg, 1.0, prec)
     G.set_variant(m, 0)
     imgs = torch.from_numpy(W.synth_images(nview, H, Wd, seed=int(meta["seed"]), tag=int(meta["tag"]))).cuda()
     feats = [m._encode_image(imgs[v:v + 1], None, normalize=False)[0] for v in range(nview)]
@@ -553,13 +596,14 @@ def test_keyframe_scheduler_f2_vs_reference_golden(G, name, cfg):
         G.drop_models()
 
 
-def test_forward_encodes_main_view_once_and_matches_forward_pair(G):
+@pytest.mark.parametrize("prec", [DEFAULT, "f16x3"])
+def test_forward_encodes_main_view_once_and_matches_forward_pair(G, prec):
     """forward(views) (sta_model.py:247-291) with two support views == forward_pair per support view (the main view is
     encoded once, sta_model.py:257)."""
     import torch
     from helpers import rel_l2
     from vista_slam_amd import weights as W
-    m = G.model("tiny", 1.0, "f16x3")
+    m = G.model("tiny", 1.0, prec)
     imgs = torch.from_numpy(W.synth_images(3, 48, 64, seed=43, tag=31)).cuda()
     views = {"main_view": {"img": imgs[0:1]}, "neighbor_views": [{"img": imgs[1:2]}], "loop_views": [{"img": imgs[2:3]}]}
     calls = []
@@ -590,12 +634,13 @@ def test_keyframe_scheduler_f2_all_rejected_and_errors(G):
         regress_views(m, feats[2], [feats[0][:, :5]], [False], 0.5, 48, 64)
 
 
-def test_post_sta_reductions_f1(G):
+@pytest.mark.parametrize("prec", [DEFAULT, "f16x3"])
+def test_post_sta_reductions_f1(G, prec):
     """f1: fused intrinsics / depth / mean-confidence pass and the scale estimate vs reference goldens."""
     import torch
     from helpers import load_golden, max_rel
     from vista_slam_amd import post
-    m = G.model("tiny", 1.0, "f16x3")
+    m = G.model("tiny", 1.0, prec)
     g = load_golden("post")[0]
     pts, conf = torch.from_numpy(g["pts"]).cuda(), torch.from_numpy(g["conf"]).cuda()
     K, depth, cmean = post.pair_reductions(m, pts, conf, shared_intrinsic=True)
@@ -609,7 +654,8 @@ def test_post_sta_reductions_f1(G):
     assert abs(float(s) - float(g["scale"])) < 1e-5 * abs(float(g["scale"]))
 
 
-def test_multi_gpu_layer_on_real_outputs_nccl_world1(G):
+@pytest.mark.parametrize("prec", [DEFAULT, "f16x3"])
+def test_multi_gpu_layer_on_real_outputs_nccl_world1(G, prec):
     """SURVEY 8(e) on the GPU: pack_compact -> gather_compact (RCCL all_gather_into_tensor) -> unpack_compact on REAL
     forward_pair outputs and pack_edges -> gather_edges on REAL regress_views results, in an `nccl` process group of
     world size 1 (one GPU per box; the world-2 paths run under gloo in tests/test_dist_cpu.py)."""
@@ -620,7 +666,7 @@ def test_multi_gpu_layer_on_real_outputs_nccl_world1(G):
     from vista_slam_amd import parallel as P
     from vista_slam_amd import weights as W
     from vista_slam_amd.slam_scheduler import regress_views
-    m = G.model("tiny", 1.0, "f16x3")
+    m = G.model("tiny", 1.0, prec)
     H, Wd, B = 48, 64, 3
     imgs = torch.from_numpy(W.synth_images(2 * B, H, Wd, seed=43, tag=41)).cuda()
     main_o, supp_o = m.forward_pair(imgs[:B], imgs[B:])

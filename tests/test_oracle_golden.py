@@ -57,11 +57,14 @@ def test_postprocess(ops):
 
 @pytest.mark.parametrize("case", ["tiny_32x32_b1", "tiny_48x64_b2", "tiny_48x64_b2_sharp", "tiny_48x80_smooth_sharp",
                                   "tiny_48x80_sharp_s44_smooth", "tiny_48x80_sharp_s45", "tiny_48x80_sharp_s46_smooth", "tiny_48x80_sharp_s47",
-                                  "tiny_80x48_b2_portrait"])
+                                  "tiny_80x48_b2_portrait",
+                                  # trained-checkpoint-like range statistics (weights.py _outlier): heavy-tailed LayerNorm gains,
+                                  # massive activation channels, DPT feature maps 300x / 3e4x larger
+                                  "tiny_48x64_b2_outlier", "tiny_48x80_outlier_sharp", "tiny_48x64_b1_overflow"])
 def test_forward_vs_reference_golden(case):
     g, meta = load_golden(case)
     H, W_, B = int(meta["H"]), int(meta["W"]), int(meta["B"])
-    sd = W.state_dict(W.TINY, seed=int(meta["seed"]), qk_gain=float(meta["qk_gain"]))
+    sd = W.state_dict(W.TINY, seed=int(meta["seed"]), qk_gain=float(meta["qk_gain"]), outlier=int(meta.get("outlier", 0)))
     gen = W.smooth_images if int(meta["smooth"]) else W.synth_images
     imgs = gen(2 * B, H, W_, seed=int(meta["seed"]), tag=0)
     r = O.forward_pair(W.TINY, sd, imgs[:B], imgs[B:])

@@ -67,6 +67,7 @@ SIGNATURES = {
     "sta_kernel_clock_read": (_i, [_vp, C.POINTER(C.c_float)]),
     "sta_bench_gemm": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(_f), _vp]),
     "sta_bench_gemm_last_ghz": (C.c_float, []),
+    "sta_range_report": (_i, [_vp, C.POINTER(C.c_ulonglong), _i]),
     "sta_bench_attention": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_f), _vp]),
     "sta_last_error": (C.c_char_p, []),
     "sta_version": (C.c_char_p, []),

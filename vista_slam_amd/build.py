@@ -11,7 +11,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libsta_mi355.so")
 SOURCES = ["sta_api.hip"]
-DEPS = ["sta_api.hip", "sta_debug.inc", "sta_rows.inc", "sta_bench.inc", "gemm.h", "gemm2.h", "conv3h.h", "attention.h", "attention2.h", "elementwise.h", "sta_common.h",
+DEPS = ["sta_api.hip", "sta_debug.inc", "sta_rows.inc", "sta_bench.inc", "gemm.h", "gemm2.h", "conv3h.h", "attention.h", "elementwise.h", "sta_common.h",
         os.path.join("..", "..", "include", "sta_mi355.h"), os.path.join("..", "..", "include", "sta_mi355_debug.h")]
 
 

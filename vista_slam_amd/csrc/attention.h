@@ -50,7 +50,7 @@ template <bool SPLIT>
 __device__ __forceinline__ void attn_pose_query(const AttnParams& p, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nsh = p.S * p.heads;
-    int sh = blockIdx.x * (blockDim.x >> 6) + wave;            // 4 waves per block (attn_kernel) or 8 (attn2_kernel)
+    int sh = blockIdx.x * (blockDim.x >> 6) + wave;
     const bool live = sh < nsh;
     if (!live) sh = nsh - 1;                                  // duplicate work, no store: every wave reaches the barriers
     const int s = sh / p.heads, h = sh - s * p.heads;
@@ -115,9 +115,7 @@ __device__ __forceinline__ void attn_pose_query(const AttnParams& p, char* smem)
     else p.O_hi[oo] = to_f16_sat(o);
 }
 
-// PMODE (experiment, f16x3 only): 1 = the probabilities are rounded to fp16 ONCE and that rounded value is used in both the
-// numerator (P V: two products, V hi + V lo) and the denominator (row sum): no fp16 residual of P, 40 instead of 48 MFMAs per tile.
-template <bool SPLIT, int PMODE = 0>
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NPL = SPLIT ? 2 : 1;
@@ -285,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
             for (int r = 0; r < 16; ++r) {
                 const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[t][r], p.scale_log2e, neg_m));
                 sacc[t][r] = pv;
-                psum += PMODE == 1 ? (float)(f16)pv : pv;
+                psum += pv;
             }
         l_run = l_run * alpha + psum;
         m_run = m_new;
@@ -310,14 +308,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
                     const float pv = sacc[t][8 * w + j];
                     const f16 hh = (f16)pv;
                     ph.h[j] = hh;
-                    if (SPLIT && PMODE == 0) pl.h[j] = (f16)(pv - (float)hh);
+                    if (SPLIT) pl.h[j] = (f16)(pv - (float)hh);
                 }
                 // u[0..1] = X (registers 8w..8w+3), u[2..3] = Y (8w+4..8w+7): swap X.high-lanes <-> Y.low-lanes
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     auto r1 = __builtin_amdgcn_permlane32_swap(ph.u[e], ph.u[2 + e], false, false);
                     ph.u[e] = r1[0]; ph.u[2 + e] = r1[1];
-                    if (SPLIT && PMODE == 0) {
+                    if (SPLIT) {
                         auto r2 = __builtin_amdgcn_permlane32_swap(pl.u[e], pl.u[2 + e], false, false);
                         pl.u[e] = r2[0]; pl.u[2 + e] = r2[1];
                     }
@@ -331,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
                     if (SPLIT) {
                         half8 vl = *reinterpret_cast<const half8*>(sV + ATT_TILE_BYTES + d * 4096 + foff_l[c2]);
                         oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph.h, oacc[d], 0, 0, 0);
-                        if (PMODE == 0) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pl.h, oacc[d], 0, 0, 0);
+                        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pl.h, oacc[d], 0, 0, 0);
                     }
                     oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, ph.h, oacc[d], 0, 0, 0);
                 }
@@ -371,6 +369,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     const float inv = 1.0f / l_tot;
     const int q = q0 + l31;
     if (q < p.nq) {
+        RangeAcc ra;        // never flushed (dead code): a convex combination of V rows stays inside V's range
         const int64_t orow = (int64_t)s * p.nq + q, orows = (int64_t)p.S * p.nq + (p.pose ? p.S : 0);
 #pragma unroll
         for (int d = 0; d < 2; ++d)
@@ -380,14 +379,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
                 const size_t o = blk_off<SPLIT>(orow, h * 64 + dcol, orows);    // blocked planes [ldo/32][S*nq][hi32|lo32]
                 if (SPLIT && p.o_mx) {
                     const float y[4] = {oacc[d][g * 4] * inv, oacc[d][g * 4 + 1] * inv, oacc[d][g * 4 + 2] * inv, oacc[d][g * 4 + 3] * inv};
-                    store_mx4(p.O_hi, o, split_mx4<false>(y));
+                    store_mx4(p.O_hi, o, split_mx4<false>(y, ra));
                     continue;
                 }
                 H4 oh, ol;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = oacc[d][g * 4 + e] * inv;
-                    if (SPLIT) split_f16(v, oh.e[e], ol.e[e]); else oh.e[e] = to_f16_sat(v);
+                    if (SPLIT) split_f16(v, oh.e[e], ol.e[e], ra); else oh.e[e] = to_f16_sat(v, ra);
                 }
                 *reinterpret_cast<uint2*>(p.O_hi + o) = oh.u;
                 if (SPLIT) *reinterpret_cast<uint2*>(p.O_hi + o + 32) = ol.u;

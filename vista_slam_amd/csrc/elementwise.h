@@ -23,6 +23,8 @@ struct LnParams {
 // normalised values n[4] of columns idx..idx+3 of `row` -> affine set 1 (fp32 copy and / or planes) and optional set 2
 template <bool SPLIT>
 __device__ __forceinline__ void ln_store4(const LnParams& p, int row, int idx, const float n[4]) {
+    RangeAcc ra;       // never flushed (dead code): a normalised row times the gains cannot leave the fp16 range; what can go wrong is a
+                       // non-finite ROW (inf / NaN in the residual stream), which ln_kernel / resid_ln_kernel count from the row statistics
     {
         float4 g = *reinterpret_cast<const float4*>(p.g1 + idx);
         float4 b = *reinterpret_cast<const float4*>(p.b1 + idx);
@@ -31,11 +33,11 @@ __device__ __forceinline__ void ln_store4(const LnParams& p, int row, int idx, c
         if (p.o1_hi) {
             const size_t o = blk_off<SPLIT>(row, idx, p.M);
             if (SPLIT && p.mx) {
-                store_mx4(p.o1_hi, o, split_mx4<false>(y));
+                store_mx4(p.o1_hi, o, split_mx4<false>(y, ra));
             } else {
                 H4 h, l;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e]); else h.e[e] = to_f16_sat(y[e]); }
+                for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e], ra); else h.e[e] = to_f16_sat(y[e], ra); }
                 *reinterpret_cast<uint2*>(p.o1_hi + o) = h.u;
                 if (SPLIT) *reinterpret_cast<uint2*>(p.o1_hi + o + 32) = l.u;
             }
@@ -47,11 +49,11 @@ __device__ __forceinline__ void ln_store4(const LnParams& p, int row, int idx, c
         float y[4] = {n[0] * g.x + b.x, n[1] * g.y + b.y, n[2] * g.z + b.z, n[3] * g.w + b.w};
         const size_t o = blk_off<SPLIT>(row, idx, p.M);
         if (SPLIT && p.mx) {
-            store_mx4(p.o2_hi, o, split_mx4<false>(y));
+            store_mx4(p.o2_hi, o, split_mx4<false>(y, ra));
         } else {
             H4 h, l;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e]); else h.e[e] = to_f16_sat(y[e]); }
+            for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e], ra); else h.e[e] = to_f16_sat(y[e], ra); }
             *reinterpret_cast<uint2*>(p.o2_hi + o) = h.u;
             if (SPLIT) *reinterpret_cast<uint2*>(p.o2_hi + o + 32) = l.u;
         }
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)p.C + p.eps);
+    if (lane == 0 && !(fabsf(mean) <= 3.0e38f && rstd <= 3.0e38f)) atomicAdd(&g_sta_range[0], 1ull);   // non-finite row (range report)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int idx = (i * 64 + lane) * 4;
@@ -124,6 +127,7 @@ __global__ __launch_bounds__(256) void resid_ln_kernel(const LnParams p) {
     if (lane == 0) red[1][wave] = sq;
     __syncthreads();
     const float rstd = 1.0f / sqrtf(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)p.C + p.eps);
+    if (threadIdx.x == 0 && !(fabsf(mean) <= 3.0e38f && rstd <= 3.0e38f)) atomicAdd(&g_sta_range[0], 1ull);   // non-finite row (range report)
     if (on) {
         float n[4] = {(v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd};
         ln_store4<SPLIT>(p, row, idx, n);
@@ -311,6 +315,7 @@ __global__ __launch_bounds__(256) void bilinear_up2_kernel(const f16* i_hi, cons
         if (SPLIT) { al.u = ldg16(i_hi + o00 + 32); bl.u = ldg16(i_hi + o01 + 32); cl.u = ldg16(i_hi + o10 + 32); dl.u = ldg16(i_hi + o11 + 32); }
         H8 oh, ol;
         float vout[8];
+        RangeAcc ra;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float v00 = (float)a.e[e], v01 = (float)b_.e[e], v10 = (float)c_.e[e], v11 = (float)d.e[e];
@@ -327,13 +332,16 @@ __global__ __launch_bounds__(256) void bilinear_up2_kernel(const f16* i_hi, cons
             float bot = (1.f - fx) * v10 + fx * v11;
             float v = (1.f - fy) * top + fy * bot;
             vout[e] = v;
-            if (SPLIT) split_f16(v, oh.e[e], ol.e[e]); else oh.e[e] = to_f16_sat(v);
+            if (SPLIT && mx) continue;
+            if (SPLIT) split_f16(v, oh.e[e], ol.e[e], ra); else oh.e[e] = to_f16_sat(v, ra);
         }
         const size_t o = blk_off<SPLIT>(orow + x, c, orows);
         if (SPLIT && mx) {
-            store_mx4(o_hi, o, split_mx4<false>(vout)); store_mx4(o_hi, o + 4, split_mx4<false>(vout + 4));
+            store_mx4(o_hi, o, split_mx4<false>(vout, ra)); store_mx4(o_hi, o + 4, split_mx4<false>(vout + 4, ra));
+            ra.flush();
             continue;
         }
+        ra.flush();
         *reinterpret_cast<uint4*>(o_hi + o) = oh.u;
         if (SPLIT) *reinterpret_cast<uint4*>(o_hi + o + 32) = ol.u;
     }

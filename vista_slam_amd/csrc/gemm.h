@@ -126,6 +126,8 @@ template <bool SPLIT>
 __device__ __forceinline__ void epilogue_qkv_tile(const GemmParams& p, const floatx16& acc, int row0, int col, int lane) {
     const int lhi = lane >> 5;
     const bool col_ok = col < p.N;
+    RangeAcc ra;                      // never flushed: q / k / v are linear maps of LayerNorm outputs (bounded by sqrt(C) x the gains x
+                                      // the weights), the range report (sta_common.h) covers the unnormalised tensors instead
     const float bv = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
     const int cbase = (col - (lane & 31)) & ~63;
     int seg = 0, cc = cbase;
@@ -143,7 +145,7 @@ __device__ __forceinline__ void epilogue_qkv_tile(const GemmParams& p, const flo
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float v = acc[g * 4 + e] + bv;
-                if (SPLIT) split_f16(v, hh[e], ll[e]); else { hh[e] = to_f16_sat(v); ll[e] = (f16)0; }
+                if (SPLIT) split_f16(v, hh[e], ll[e], ra); else { hh[e] = to_f16_sat(v, ra); ll[e] = (f16)0; }
             }
             const size_t o = ((size_t)(s * p.heads + head) * 64 + dcol) * p.npad + t;
             if (col_ok && rowg + 3 < p.M && t + 3 < p.ntok) {      // 4 tokens of one sequence: one run
@@ -183,8 +185,8 @@ __device__ __forceinline__ void epilogue_qkv_tile(const GemmParams& p, const flo
         v = (lane & 16) ? (v * cs.x + other * cs.y) : (v * cs.x - other * cs.y);
         if (col_ok && row < p.M) {
             const size_t o = ((size_t)(s * p.heads + head) * p.npad + t) * 64 + dcol;
-            if (SPLIT) { f16 h, l; split_f16(v, h, l); dh[o] = h; dl[o] = l; }
-            else dh[o] = to_f16_sat(v);
+            if (SPLIT) { f16 h, l; split_f16(v, h, l, ra); dh[o] = h; dl[o] = l; }
+            else dh[o] = to_f16_sat(v, ra);
         }
     }
 }
@@ -200,6 +202,9 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
                                               int kslice = 0, int mlim = -1) {
     const bool first_slice = kslice == 0;
     const int M_ = mlim >= 0 ? mlim : p.M;
+    RangeAcc ra;                      // range report (sta_common.h): one flush per tile - for the plane epilogues of the DPT head
+                                      // (no normalisation layers) and the generic EPI_F16; mlp.fc1's GELU tile (EPI_GELU) is a
+                                      // function of a LayerNorm output and stays uncounted (its compares are dead code)
     if (EPI == EPI_QKV && p.ksplit <= 1) { epilogue_qkv_tile<SPLIT>(p, acc, row0, col, lane); return; }
     const int lhi = lane >> 5;
     const bool col_ok = col < p.N;
@@ -225,9 +230,9 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
             } else {
                 v = gelu_erf(v);
                 const size_t o = blk_off<SPLIT>(row, col, p.c_rp);
-                if (SPLIT && p.c_mx) store_mx1<false>(p.C_hi, o, v);
-                else if (SPLIT) { f16 h, l; split_f16(v, h, l); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
-                else p.C_hi[o] = to_f16_sat(v);
+                if (SPLIT && p.c_mx) store_mx1<false>(p.C_hi, o, v, ra);
+                else if (SPLIT) { f16 h, l; split_f16(v, h, l, ra); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
+                else p.C_hi[o] = to_f16_sat(v, ra);
             }
         }
         return;
@@ -259,9 +264,9 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
             if (ok) {
                 v = gelu_erf(v);
                 const size_t o = blk_off<SPLIT>(row, col, p.c_rp);
-                if (SPLIT && p.c_mx) store_mx1<false>(p.C_hi, o, v);
-                else if (SPLIT) { f16 h, l; split_f16(v, h, l); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
-                else p.C_hi[o] = to_f16_sat(v);
+                if (SPLIT && p.c_mx) store_mx1<false>(p.C_hi, o, v, ra);
+                else if (SPLIT) { f16 h, l; split_f16(v, h, l, ra); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
+                else p.C_hi[o] = to_f16_sat(v, ra);
             }
         } else if (EPI == EPI_F16) {
             if (ok && p.ksplit > 1) {
@@ -277,9 +282,9 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
                     if (p.R1_hi) { v += (float)p.R1_hi[o]; if (SPLIT) v += (float)p.R1_hi[o + 32]; }
                     if (p.R2_hi) { v += (float)p.R2_hi[o]; if (SPLIT) v += (float)p.R2_hi[o + 32]; }
                 }
-                if (SPLIT && p.c_mx) store_mx1<false>(p.C_hi, o, v);
-                else if (SPLIT) { f16 h, l; split_f16(v, h, l); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
-                else p.C_hi[o] = to_f16_sat(v);
+                if (SPLIT && p.c_mx) store_mx1<false>(p.C_hi, o, v, ra);
+                else if (SPLIT) { f16 h, l; split_f16(v, h, l, ra); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
+                else p.C_hi[o] = to_f16_sat(v, ra);
             }
         } else {  // EPI_CONVT
             if (ok) {
@@ -290,12 +295,13 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
                 int y = rem / p.ct_w, x = rem - y * p.ct_w;
                 const size_t opix = ((size_t)img * (p.ct_h * p.ct_k) + (y * p.ct_k + dy)) * (p.ct_w * p.ct_k) + (x * p.ct_k + dx);
                 const size_t o = blk_off<SPLIT>(opix, co, p.c_rp);
-                if (SPLIT && p.c_mx) store_mx1<false>(p.C_hi, o, v);
-                else if (SPLIT) { f16 h, l; split_f16(v, h, l); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
-                else p.C_hi[o] = to_f16_sat(v);
+                if (SPLIT && p.c_mx) store_mx1<false>(p.C_hi, o, v, ra);
+                else if (SPLIT) { f16 h, l; split_f16(v, h, l, ra); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
+                else p.C_hi[o] = to_f16_sat(v, ra);
             }
         }
     }
+    if (EPI != EPI_GELU) ra.flush();
 }
 
 // Second half of a split-K GEMM with the QKV epilogue (small-M regime): sums the K-slice slabs skbuf[s][M,N], adds the

@@ -6,7 +6,6 @@
 #include "gemm2.h"
 #include "conv3h.h"
 #include "attention.h"
-#include "attention2.h"
 #include "elementwise.h"
 
 #include <cmath>
@@ -416,6 +415,17 @@ extern "C" int sta_set_concurrency(sta_handle* h, int n_slices) {
 extern "C" int sta_set_gemm_variant(sta_handle* h, int variant) {
     REQUIRE(h && ((variant >= 0 && variant <= 4) || variant == 8 || variant == 9), "bad gemm variant");
     h->gemm_variant = variant;
+    return 0;
+}
+extern "C" int sta_range_report(sta_handle* h, unsigned long long counts[2], int reset) {
+    REQUIRE(h && counts, "null argument");
+    DEV_SCOPE(h->device);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(counts, HIP_SYMBOL(g_sta_range), 16, 0, hipMemcpyDeviceToHost));
+    if (reset) {
+        const unsigned long long z[2] = {0, 0};
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_sta_range), z, 16, 0, hipMemcpyHostToDevice));
+    }
     return 0;
 }
 extern "C" int sta_num_expected_tensors(const sta_handle* h) { return h ? (int)h->slots.size() : -1; }
@@ -930,50 +940,10 @@ static int run_attn(sta_handle* h, const QKVOut& qkv, const Planes& out, int ldo
     p.scale_log2e = 0.125f * 1.44269504088896340736f;
     const int npose = pose ? (S * heads + 3) / 4 : 0;
     REQUIRE(!pose || (int64_t)4 * qkv.npad * 4 <= attn_smem_bytes<false>(), "internal: pose-query scratch exceeds the LDS allocation");
-    // throughput scale: the software-pipelined kernel (attention2.h: 256 queries per workgroup, one workgroup per CU) once
-    // its grid fills the chip; experiment switch 1 forces either kernel (tests)
-    const int blocks2 = ((nq + 255) / 256) * heads * S;
-    const bool use2 = h->prec != STA_PREC_F16 && (h->opt[1] == 1 || (h->opt[1] == 0 && blocks2 >= 256 && nq >= 192));
-    if (use2) {
-        dim3 grid((unsigned)(blocks2 + (pose ? (S * heads + 7) / 8 : 0)));
-        REQUIRE(!pose || (int64_t)8 * qkv.npad * 4 <= attn2_smem_bytes<false>(), "internal: pose-query scratch exceeds the LDS allocation");
-        {
-            static unsigned attr_done = 0;      // one bit per device
-            if (!(attr_done >> (h->device & 31) & 1u)) { HIPCHK(hipFuncSetAttribute((const void*)attn2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, attn2_smem_bytes<true>())); attr_done |= 1u << (h->device & 31); }
-#ifdef STA_BENCH_EXPERIMENTS      // component ablations of the tile body (tools/attn_bench.py ablate): opt[2] = ABL bits
-            auto abl = [&](auto a_c) {
-                constexpr int A = decltype(a_c)::value;
-                hipFuncSetAttribute((const void*)attn2_kernel<true, A>, hipFuncAttributeMaxDynamicSharedMemorySize, attn2_smem_bytes<true>());
-                hipLaunchKernelGGL((attn2_kernel<true, A>), grid, dim3(512), attn2_smem_bytes<true>(), st, p);
-            };
-            using std::integral_constant;
-            switch (h->opt[2]) {
-                case 1: abl(integral_constant<int, 1>{}); break;
-                case 2: abl(integral_constant<int, 2>{}); break;
-                case 3: abl(integral_constant<int, 3>{}); break;
-                case 4: abl(integral_constant<int, 4>{}); break;
-                case 7: abl(integral_constant<int, 7>{}); break;
-                case 8: abl(integral_constant<int, 8>{}); break;
-                case 14: abl(integral_constant<int, 14>{}); break;
-                case 15: abl(integral_constant<int, 15>{}); break;
-                default: hipLaunchKernelGGL(attn2_kernel<true>, grid, dim3(512), attn2_smem_bytes<true>(), st, p);
-            }
-#else
-            hipLaunchKernelGGL(attn2_kernel<true>, grid, dim3(512), attn2_smem_bytes<true>(), st, p);
-#endif
-        }
-        HIPCHK(hipGetLastError());
-        return 0;
-    }
     dim3 grid((unsigned)(((nq + 127) / 128) * heads * S + npose));
     if (h->prec != STA_PREC_F16) {
         static unsigned attr_done = 0;      // one bit per device
         if (!(attr_done >> (h->device & 31) & 1u)) { hipFuncSetAttribute((const void*)attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_smem_bytes<true>()); attr_done |= 1u << (h->device & 31); }
-        if (h->opt[3] == 1) {       // experiment: fp16-rounded probabilities in numerator and denominator (attention.h PMODE)
-            static bool attr1 = false;
-            if (!attr1) { hipFuncSetAttribute((const void*)attn_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_smem_bytes<true>()); attr1 = true; }
-            hipLaunchKernelGGL((attn_kernel<true, 1>), grid, dim3(256), attn_smem_bytes<true>(), st, p);
-        } else
         hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), attn_smem_bytes<true>(), st, p);
     } else {
         STA_F16ONLY(hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), attn_smem_bytes<false>(), st, p));

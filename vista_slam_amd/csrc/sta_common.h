@@ -12,10 +12,32 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 #define STA_F16_MAX 65504.0f
 
+// Range report (sta_range_report): how many values did not fit the fp16 planes (|x| > 65504, or NaN) and how many fp8
+// correction bytes of the f16mx arithmetic saturated at +-448, since the last reset.  The planes SATURATE instead of
+// producing inf; a non-zero count says the result is no longer backed by the parity goldens.  Rare path: one compare per value.
+// A writer tracks the largest magnitude it stored in a RangeAcc (ONE v_max_f32 per value, no compare, no branch) and
+// flushes once per tile / row / call: the counters count (lane, flush) events with at least one out-of-range value, not values.
+// (NaNs are dropped by the max; a non-finite row of a residual stream is counted by the LayerNorm kernels.)
+__device__ unsigned long long g_sta_range[2];
+struct RangeAcc {
+    float amax = 0.f;       // largest |x| written as an fp16 (hi, residual) pair
+    float amax8 = 0.f;      // largest |x| whose e4m3 copy was written (f16mx activation rows: saturates beyond 448)
+    bool w8 = false;        // a WEIGHT e4m3 byte saturated (packing at load time: exact check)
+    __device__ __forceinline__ void flush() {
+        if (__builtin_expect(amax > STA_F16_MAX, 0)) atomicAdd(&g_sta_range[0], 1ull);
+        if (__builtin_expect(amax8 > 448.f || w8, 0)) atomicAdd(&g_sta_range[1], 1ull);
+        amax = amax8 = 0.f; w8 = false;
+    }
+};
+__device__ __forceinline__ float sat_f16_range(float x, RangeAcc& a) {
+    a.amax = fmaxf(a.amax, fabsf(x));
+    return fminf(fmaxf(x, -STA_F16_MAX), STA_F16_MAX);
+}
+
 // 2-term fp16 split: x ~= hi + lo with |lo| <= ulp(hi)/2  (~21 significant bits while lo is a
 // normal fp16, absolute floor 2^-25 below that).  Saturates instead of producing inf.
-__device__ __forceinline__ void split_f16(float x, f16& hi, f16& lo) {
-    x = fminf(fmaxf(x, -STA_F16_MAX), STA_F16_MAX);
+__device__ __forceinline__ void split_f16(float x, f16& hi, f16& lo, RangeAcc& ra) {
+    x = sat_f16_range(x, ra);
     hi = (f16)x;
     lo = (f16)(x - (float)hi);
 #ifdef STA_EMU_LO_MANT
@@ -30,9 +52,9 @@ __device__ __forceinline__ void split_f16(float x, f16& hi, f16& lo) {
     }
 #endif
 }
-__device__ __forceinline__ f16 to_f16_sat(float x) {
-    return (f16)fminf(fmaxf(x, -STA_F16_MAX), STA_F16_MAX);
-}
+__device__ __forceinline__ void split_f16(float x, f16& hi, f16& lo) { RangeAcc ra; split_f16(x, hi, lo, ra); ra.flush(); }
+__device__ __forceinline__ f16 to_f16_sat(float x, RangeAcc& ra) { return (f16)sat_f16_range(x, ra); }
+__device__ __forceinline__ f16 to_f16_sat(float x) { RangeAcc ra; const f16 r = to_f16_sat(x, ra); ra.flush(); return r; }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -88,25 +110,30 @@ __device__ __forceinline__ int cvt2_e4m3(float first, float second, int old, boo
 }
 struct MX4 { uint2 hi; uint2 pairs; };
 template <bool WEIGHT>
-__device__ __forceinline__ MX4 split_mx4(const float y[4]) {
+__device__ __forceinline__ MX4 split_mx4(const float y[4], RangeAcc& ra) {
     constexpr float KHI = WEIGHT ? (float)(1 << STA_MX_W_SHI) : (float)(1 << STA_MX_A_SHI);
     constexpr float KLO = WEIGHT ? (float)(1 << STA_MX_W_SLO) : (float)(1 << STA_MX_A_SLO);
     union { uint2 u; f16 e[4]; } h;
     float a[4], b[4];            // first / second byte of every pair
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float x = fminf(fmaxf(y[e], -STA_F16_MAX), STA_F16_MAX);
+        const float x = sat_f16_range(y[e], ra);
         h.e[e] = (f16)x;
         const float hf = (float)h.e[e], lf = x - hf;
         a[e] = WEIGHT ? lf * KLO : hf * KHI;
         b[e] = WEIGHT ? hf * KHI : lf * KLO;
+        // activations: |lo * 2^11| <= |hi|, so the pair saturates iff |hi| > 448; weights (load time): exact check
+        if (WEIGHT) ra.w8 |= fabsf(a[e]) > 448.f || fabsf(b[e]) > 448.f;
     }
+    if (!WEIGHT) ra.amax8 = ra.amax;      // (this accumulator only ever sees f16mx rows)
     MX4 r; r.hi = h.u;
     int w0 = cvt2_e4m3(a[0], b[0], 0, false); w0 = cvt2_e4m3(a[1], b[1], w0, true);
     int w1 = cvt2_e4m3(a[2], b[2], 0, false); w1 = cvt2_e4m3(a[3], b[3], w1, true);
     r.pairs = make_uint2((unsigned)w0, (unsigned)w1);
     return r;
 }
+template <bool WEIGHT>
+__device__ __forceinline__ MX4 split_mx4(const float y[4]) { RangeAcc ra; const MX4 r = split_mx4<WEIGHT>(y, ra); ra.flush(); return r; }
 // o = blk_off<true>(row, col, rows) with col % 4 == 0: hi at base + o, the byte pairs in the second half of the row block
 __device__ __forceinline__ void store_mx4(f16* base, size_t o, const MX4& v) {
     *reinterpret_cast<uint2*>(base + o) = v.hi;
@@ -118,15 +145,18 @@ __device__ __forceinline__ float load_mx_act(const f16* base, size_t o) {
     return (float)base[o] + __builtin_amdgcn_cvt_f32_fp8(pair, 1) * (1.0f / (float)(1 << STA_MX_A_SLO));
 }
 template <bool WEIGHT>
-__device__ __forceinline__ void store_mx1(f16* base, size_t o, float x) {     // scalar variant (column-per-lane epilogues)
+__device__ __forceinline__ void store_mx1(f16* base, size_t o, float x, RangeAcc& ra) {     // scalar variant (column-per-lane epilogues)
     constexpr float KHI = WEIGHT ? (float)(1 << STA_MX_W_SHI) : (float)(1 << STA_MX_A_SHI);
     constexpr float KLO = WEIGHT ? (float)(1 << STA_MX_W_SLO) : (float)(1 << STA_MX_A_SLO);
-    x = fminf(fmaxf(x, -STA_F16_MAX), STA_F16_MAX);
+    x = sat_f16_range(x, ra);
     const f16 h = (f16)x; const float hf = (float)h, lf = x - hf;
+    if (WEIGHT) ra.w8 |= fabsf(lf * KLO) > 448.f || fabsf(hf * KHI) > 448.f; else ra.amax8 = ra.amax;
     const int b = WEIGHT ? cvt2_e4m3(lf * KLO, hf * KHI, 0, false) : cvt2_e4m3(hf * KHI, lf * KLO, 0, false);
     base[o] = h;
     reinterpret_cast<unsigned short*>(base)[o + 32] = (unsigned short)(b & 0xFFFF);
 }
+template <bool WEIGHT>
+__device__ __forceinline__ void store_mx1(f16* base, size_t o, float x) { RangeAcc ra; store_mx1<WEIGHT>(base, o, x, ra); ra.flush(); }
 
 union H8 { uint4 u; half8 h; f16 e[8]; };
 union H4 { uint2 u; half4 h; f16 e[4]; };

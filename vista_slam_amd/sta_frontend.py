@@ -102,6 +102,13 @@ class STAFrontend:
         _lib.check(self.lib.sta_set_precision(self._h, _lib.PRECISIONS[precision]))
         self.precision = precision
 
+    def range_report(self, reset: bool = True):
+        """(fp16 saturations, e4m3 saturations) counted by the plane writers on this GPU since the last reset
+        (sta_range_report): non-zero fp16 saturations = the forward left the range the fp16 planes can carry."""
+        c = (C.c_ulonglong * 2)()
+        _lib.check(self.lib.sta_range_report(self._h, c, int(reset)))
+        return int(c[0]), int(c[1])
+
     def set_deterministic(self, on: bool = True):
         """Bit-reproducible results (no split-K fp32 atomics at SLAM scale; include/sta_mi355.h)."""
         _lib.check(self.lib.sta_set_deterministic(self._h, int(on)))
@@ -127,9 +134,9 @@ class STAFrontend:
         shape = (C.c_int64 * a.ndim)(*a.shape)
         _lib.check(self.lib.sta_load_tensor(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim, 0))
 
-    def load_procedural(self, seed: int = 43, qk_gain: float = 1.0):
+    def load_procedural(self, seed: int = 43, qk_gain: float = 1.0, outlier: int = 0):
         """Stream the deterministic procedural weights (vista_slam_amd.weights) into the library."""
-        for name, a in W.generate(self.cfg, seed=seed, qk_gain=qk_gain, reuse_buffer=True):
+        for name, a in W.generate(self.cfg, seed=seed, qk_gain=qk_gain, reuse_buffer=True, outlier=outlier):
             self._load_one(name, a)
         _lib.check(self.lib.sta_finalize_weights(self._h))
         self._finalized = True

@@ -180,8 +180,41 @@ def _name_seed(seed: int, name: str) -> int:
     return (zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0xFFFFFFFF
 
 
+OUTLIER_DPT_SCALE = {1: 300.0, 2: 3.0e4}     # outlier level -> scale of the DPT head's feature maps (undone by head.4)
+OUTLIER_MASSIVE = (80.0, -60.0, 50.0)         # "massive activation" channels added to the residual streams
+
+
+def _outlier(cfg: STAConfig, seed: int, level: int, src: str, kind: str, a: np.ndarray) -> None:
+    """Trained-checkpoint statistics the plain U(+-1/sqrt(fan_in)) weights do not have, in place:
+    * LayerNorm gains with a heavy tail: ~3 % of the channels of every norm scaled by 3..10;
+    * massive activations: three channels of the encoder / decoder residual streams carry +80 / -60 / +50 from the second
+      block on (bias of mlp.fc2), i.e. 50-100x the other channels - every later LayerNorm, GEMM operand split and the DPT
+      hooks see them;
+    * DPT head (no normalisation layers, dpt_block.py:264-324, use_bn=False): the four act_postprocess 1x1 convolutions are
+      scaled by OUTLIER_DPT_SCALE[level] and head.4 by its inverse, so every feature map of the head is 300x larger
+      (level 1: past the +-448 of the e4m3 correction bytes of the f16mx arithmetic) or 3e4x larger (level 2: past the
+      +-65504 of the fp16 planes) while the fp32 reference's outputs keep their scale."""
+    if kind == "ln_w":
+        n = a.size
+        u = hash_uniform(_name_seed(seed, src + "/outlier"), 2 * n)
+        pick = u[:n] > np.float32(0.94)                 # u in [-1, 1): 3 % of the channels
+        a[pick] *= (np.float32(6.5) + np.float32(3.5) * u[n:][pick])
+        return
+    E, D = cfg.enc_embed_dim, cfg.dec_embed_dim
+    for blk, C in ((f"enc_blocks.{min(1, cfg.enc_depth - 1)}.mlp.fc2.bias", E), (f"dec_block.{min(1, cfg.dec_depth - 1)}.mlp.fc2.bias", D)):
+        if src == blk:
+            for ch, v in zip((7 % C, C // 3, (2 * C) // 3 + 5), OUTLIER_MASSIVE):
+                a[ch] += np.float32(v)
+            return
+    dp = "downstream_head_pts.dpt."
+    if src.startswith(dp + "act_postprocess.") and src.split(".")[-2] == "0" and src.split(".")[-3] in "0123":
+        a *= np.float32(OUTLIER_DPT_SCALE[level])
+    elif src == dp + "head.4.weight":
+        a *= np.float32(1.0 / OUTLIER_DPT_SCALE[level])
+
+
 def generate(cfg: STAConfig = FULL, seed: int = 43, qk_gain: float = 1.0,
-             reuse_buffer: bool = False) -> Iterator[Tuple[str, np.ndarray]]:
+             reuse_buffer: bool = False, outlier: int = 0) -> Iterator[Tuple[str, np.ndarray]]:
     """Yield (name, float32 array) in reference state_dict order.
 
     reuse_buffer=True yields views of ONE scratch buffer (valid only until the next
@@ -190,6 +223,9 @@ def generate(cfg: STAConfig = FULL, seed: int = 43, qk_gain: float = 1.0,
     qk_gain > 1 multiplies every Q/K projection (weights and biases) so attention becomes
     peaky ("sharp" set): with default-scale weights a wrong RoPE/softmax
     hides under the 1e-3 bar.
+
+    outlier > 0 adds trained-checkpoint-like range statistics (`_outlier`): 1 = heavy-tailed LayerNorm gains, massive
+    activation channels, DPT feature maps past +-448; 2 = DPT feature maps past the fp16 range as well.
     """
     E, D = cfg.enc_embed_dim, cfg.dec_embed_dim
     sch = schema(cfg)
@@ -217,11 +253,13 @@ def generate(cfg: STAConfig = FULL, seed: int = 43, qk_gain: float = 1.0,
                 a[: 2 * C] *= g
             elif ".cross_attn.projq." in src or ".cross_attn.projk." in src:
                 a *= g
+        if outlier:
+            _outlier(cfg, seed, outlier, src, kind, a.reshape(-1) if kind in ("ln_w", "b") else a)
         yield name, a
 
 
-def state_dict(cfg: STAConfig = FULL, seed: int = 43, qk_gain: float = 1.0) -> Dict[str, np.ndarray]:
-    return dict(generate(cfg, seed, qk_gain))
+def state_dict(cfg: STAConfig = FULL, seed: int = 43, qk_gain: float = 1.0, outlier: int = 0) -> Dict[str, np.ndarray]:
+    return dict(generate(cfg, seed, qk_gain, outlier=outlier))
 
 
 def synth_images(n: int, H: int, W: int, seed: int = 43, tag: int = 0) -> np.ndarray:
