@@ -19,11 +19,6 @@ extern "C" {
  * (same-box A/B).  Lets the tests cover the families on small shapes. */
 int sta_set_gemm_variant(sta_handle* h, int variant);
 
-/* Precision-policy experiments: choose which layer classes run in the f16mx arithmetic (f16 main product + one block-scaled
- * fp8 correction MFMA).  Bits: 1 = qkv / projq / projk|projv, 2 = attn.proj / cross_attn.proj, 4 = mlp.fc1, 8 = mlp.fc2,
- * 16 = DPT head convolutions.  sta_set_precision resets it (f16x3: 0, f16x3h: 16, f16mx: 31). */
-int sta_set_mx_mask(sta_handle* h, int mask);
-
 /* nn.Linear (+GELU/ReLU, +residual): out[M,N] = act(A[M,K] W[N,K]^T + bias) (+resid).
  * act: 0 none, 1 erf-GELU, 2 ReLU.  via_f16 != 0 uses the fp16-plane epilogue (sta_blocks.py:73-79). */
 int sta_debug_gemm(sta_handle* h, const float* A, const float* W, const float* bias, int M, int N, int K,
@@ -50,7 +45,8 @@ int sta_debug_attention_pose(sta_handle* h, const float* q, const float* k, cons
 
 /* Experiment switches of the tools (0 everywhere = product behaviour).  idx 0: conv3h configuration (bits 0-1: 0 = 16 waves /
  * 2 weight stages, 1 = 16 waves / 3-stage weight ring, 2 = 8 waves with 64x64 wave tiles / ring; bit 3: Cout = 256 as two
- * 128-column tiles). */
+ * 128-column tiles).  idx 4 = 1: sta_debug_gemm (plane epilogue) / conv3x3 / convt / up2 run in the DPT head's f16mx arithmetic
+ * (f16mx rows in and out, f16mx weights) when the handle's precision is f16x3h - the kernels that precision uses inside the head. */
 int sta_debug_set_option(sta_handle* h, int idx, int value);
 
 /* Row-tail hint for the dense GEMMs (what the decoder sets to its 2B pose-token rows): the last `rows` (<= 32) rows of the

@@ -363,8 +363,8 @@ CASES = {
         dict(name="full_512x384_b1_portrait", cfg=W.FULL, H=512, W_=384, B=1, sub=16),
     ],
     # trained-checkpoint-like RANGE statistics (weights.py `_outlier`): heavy-tailed LayerNorm gains, massive activation
-    # channels in both residual streams, DPT feature maps 300x larger (past the e4m3 correction range of the f16mx
-    # arithmetic); `overflow`: DPT feature maps past the fp16 range - the library must REPORT it (sta_range_report)
+    # channels in both residual streams, DPT feature maps 300x larger (up to 6.5e3: past what e4m3 correction bytes could carry,
+    # the reason the f16mx arithmetic keeps activation bytes in e5m2); `overflow`: DPT feature maps past the fp16 range - the library must REPORT it (sta_range_report)
     "outlier": [
         dict(name="tiny_48x64_b2_outlier", cfg=W.TINY, H=48, W_=64, B=2, taps="light", outlier=1),
         dict(name="tiny_48x80_outlier_sharp", cfg=W.TINY, H=48, W_=80, B=1, qk_gain=4.0, smooth=True, outlier=1, seed=45),

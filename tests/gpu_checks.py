@@ -14,7 +14,7 @@ from vista_slam_amd.sta_frontend import STAFrontend, rope2d_inplace
 
 DEV = "cuda:0"
 _models = {}
-last_range = (0, 0)      # (fp16 saturations, e4m3 saturations) counted during the last run_golden_case (sta_range_report)
+last_range = (0, 0)      # (fp16 saturations, fp8 correction-byte saturations) counted during the last run_golden_case (sta_range_report)
 
 
 def dev(a):
@@ -44,8 +44,11 @@ def drop_models():
 
 
 def kernel_handle(precision, variant=0):
-    m = model("tiny", 1.0, precision)
+    """precision "head_mx": the DPT head's arithmetic of the default policy (f16 main product + one block-scaled fp8 correction
+    MFMA on f16mx rows) in the kernels that have it: the debug GEMM (plane epilogue), conv3x3, ConvT, bilinear."""
+    m = model("tiny", 1.0, "f16x3h" if precision == "head_mx" else precision)
     _lib.check(m.lib.sta_set_gemm_variant(m._h, variant))
+    _lib.check(m.lib.sta_debug_set_option(m._h, 4, 1 if precision == "head_mx" else 0))
     return m, m.lib, m._h
 
 
@@ -270,6 +273,12 @@ def check_ops_golden(precision):
     # inverse rotation (fwd = -1) restores the input (curope backward, curope2d.py:24-29)
     rope2d_inplace(tok, rpos, 100.0, -1.0)
     res["rope2d_roundtrip"] = max_rel(tok.permute(0, 2, 1, 3).cpu().numpy(), g["rope_tok"])
+    # the other token dtypes curope dispatches on (kernels.cu:101): fp32 rotation of the stored value, result stored in that dtype
+    for dt, name in ((torch.float16, "f16"), (torch.float64, "f64")):
+        t0 = dev(g["rope_tok"]).permute(0, 2, 1, 3).contiguous().to(dt)
+        want = torch.from_numpy(rope2d_ref(t0.float().permute(0, 2, 1, 3).cpu().numpy(), g["rope_pos"])).to(dt)
+        rope2d_inplace(t0, rpos, 100.0, 1.0)
+        res["rope2d_" + name] = max_rel(t0.permute(0, 2, 1, 3).cpu().double().numpy(), want.double().numpy())
     # LayerNorm eps 1e-6
     M, Cd = g["ln_x"].shape
     o32 = torch.empty(M, Cd, device=DEV); op = torch.empty(M, Cd, device=DEV)

@@ -36,7 +36,7 @@ def main():
     import gpu_checks as G
     sel = sys.argv[1:] or ["kernels", "tiny", "full"]
     out("==== diag", time.ctime(), torch.cuda.get_device_name(0), sel)
-    for prec in ("f16x3", "f16", "f16mx"):
+    for prec in ("f16x3", "f16", "f16x3h"):
         if "kernels" in sel:
             run(f"gemm f32-epi {prec}", G.check_gemm, prec)
             run(f"gemm f32-epi resid {prec}", G.check_gemm, prec, resid=True)
@@ -67,10 +67,10 @@ def main():
     if "full" in sel:
         G.drop_models()
         for case in ("full_224_b1", "full_384x512_b1"):
-            for prec in ("f16x3", "f16", "f16mx"):
+            for prec in ("f16x3", "f16", "f16x3h"):
                 run(f"{case} {prec}", G.run_golden_case, case, prec)
         G.drop_models()
-        for prec in ("f16x3", "f16", "f16mx"):
+        for prec in ("f16x3", "f16", "f16x3h"):
             run(f"full_224_b1_sharp {prec}", G.run_golden_case, "full_224_b1_sharp", prec)
     out("==== done")
 

@@ -20,6 +20,14 @@ def G():
 
 
 DEFAULT = "f16x3h"      # the shipped precision policy: f16x3 transformer + pose head, f16mx arithmetic in the DPT head
+
+
+def ctol(prec):
+    """Self-consistency bound between two valid schedules of the same forward (different tiles / split-K / streams).  f16x3
+    differs by summation order only; in f16x3h a head conv that lands on a split-K slab or on the register-staged tile runs
+    full f16x3 instead of f16mx, so two schedules also differ by the f16mx correction error (2^-14-class per element with the
+    e5m2 activation bytes; kernel-level bound in test_gpu_kernels.TOL["head_mx"])."""
+    return 2e-5 if prec == "f16x3" else 6e-5
 STRESS = [f"tiny_48x80_sharp_s{sd}{sm}" for sd in (44, 45, 46, 47) for sm in ("_smooth", "")]
 
 
@@ -40,17 +48,16 @@ OUTLIER = ["tiny_48x64_b2_outlier", "tiny_48x80_outlier_sharp", "full_224_b1_out
 def test_outlier_statistics_goldens(G, case, prec):
     """Trained-checkpoint-like RANGE statistics from the imported reference (weights.py `_outlier`):
     LayerNorm gains with a 3..10x tail, three massive-activation channels (+80 / -60 / +50) in both residual streams, DPT
-    feature maps 300x larger (up to 6.5e3: past the +-448 of the e4m3 correction bytes of the head's f16mx arithmetic, inside
-    the fp16 range).  The shipped policy must hold the 1e-3 bar, nothing may leave the fp16 range, and the e4m3 saturation
-    (f16x3h only) is counted, not silent."""
+    feature maps 300x larger (up to 6.5e3: inside the fp16 range, and inside the +-57344 of the e5m2 correction bytes the
+    head's f16mx arithmetic keeps for ACTIVATIONS - with e4m3 bytes (+-448) these cases sat at 2.3e-4..3.3e-4 with 3e5..1.4e6
+    saturated bytes; with e5m2 they are 3e-5..6e-5 with none).  The shipped policy must hold the 1e-3 bar and nothing may
+    leave either range."""
     if case.startswith("full"):
         G.drop_models()
     r = G.run_golden_case(case, prec)
     bad = {k: v for k, v in r.items() if v > TOL}
     assert not bad, (bad, G.last_range)
-    assert G.last_range[0] == 0, f"fp16 saturation inside the range the reference golden covers: {G.last_range}"
-    if prec == "f16x3":
-        assert G.last_range[1] == 0, "f16x3 has no e4m3 bytes"
+    assert G.last_range == (0, 0), f"saturation inside the range the reference golden covers: {G.last_range}"
 
 
 @pytest.mark.parametrize("prec", [DEFAULT, "f16x3"])
@@ -135,24 +142,6 @@ def test_full_sharp_attention_golden(G):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("case,tol", [("tiny_32x32_b1", 1e-4), ("tiny_48x64_b2", 1e-4), ("full_224_b1", 1e-4), ("full_384x512_b1", 1e-4),
-                                      ("full_224_b1_sharp", 3e-4),
-                                      # the two sharpened tiny-config stress sets amplify every rounding error ~100x (f16x3: 2e-4 there):
-                                      # beyond what this opt-in mode promises, bounded here so a regression still shows
-                                      ("tiny_48x64_b2_sharp", 5e-3), ("tiny_48x80_smooth_sharp", 2e-2)])
-def test_goldens_f16mx_experimental_precision(G, case, tol):
-    """Experimental precision f16mx (EVERY linear / convolution: f16 main product + one block-scaled fp8 correction MFMA).
-    NOT parity-qualified: it holds the reference-architecture goldens at <= 1e-4 but EXCEEDS the 1e-3 bar on the sharpened
-    tiny-config stress sets (1.2e-3 / 6e-3 on the two below, up to 2e-3 on the other eight).  The loosened bounds only keep a
-    regression of the mode visible; the shipped policy (f16x3h) uses this arithmetic in the DPT head alone and is held to
-    1e-3 on every golden by the tests above."""
-    if case.startswith("full"):
-        G.drop_models()
-    r = G.run_golden_case(case, "f16mx")
-    bad = {k: v for k, v in r.items() if v > tol}
-    assert not bad, bad
-
-
 def test_random_shapes_and_batches_vs_oracle(G):
     """Beyond the fixed golden shapes: random (H, W, B) - odd token grids, ragged last tiles, square, wide and portrait
     frames, a single 16x16 token - against the oracle (itself pinned to the reference goldens) on the tiny configuration, default and opt-in precision."""
@@ -169,7 +158,7 @@ def test_random_shapes_and_batches_vs_oracle(G):
         H, Wd = 16 * hp, 16 * wp
         imgs = (W.smooth_images if it % 2 else W.synth_images)(2 * B, H, Wd, seed=43, tag=30 + it)
         want = O.forward_pair(W.TINY, sd, imgs[:B], imgs[B:])
-        for prec, tol in (("f16x3", 2e-5), (DEFAULT, 5e-5), ("f16mx", 2e-4)):
+        for prec, tol in (("f16x3", 2e-5), (DEFAULT, 5e-5)):
             m = G.model("tiny", 1.0, prec)
             G.set_variant(m, 0)
             main, supp = m.forward_pair(torch.from_numpy(imgs[:B]).cuda(), torch.from_numpy(imgs[B:]).cuda())
@@ -245,9 +234,9 @@ def test_full_size_batch_rows_are_independent(full_b8):
     for i in (0, 5):
         m1, s1 = m.forward_pair(a[i:i + 1], b[i:i + 1])
         torch.cuda.synchronize()
-        assert rel_l2(m1["pts3d_pred"].cpu().numpy(), main["pts3d_pred"][i:i + 1].cpu().numpy()) < 2e-5
-        assert rel_l2(s1["conf"].cpu().numpy(), supp["conf"][i:i + 1].cpu().numpy()) < 2e-5
-        assert rel_l2(m1["relative_pose"].cpu().numpy(), main["relative_pose"][i:i + 1].cpu().numpy()) < 2e-5
+        assert rel_l2(m1["pts3d_pred"].cpu().numpy(), main["pts3d_pred"][i:i + 1].cpu().numpy()) < ctol(DEFAULT)
+        assert rel_l2(s1["conf"].cpu().numpy(), supp["conf"][i:i + 1].cpu().numpy()) < ctol(DEFAULT)
+        assert rel_l2(m1["relative_pose"].cpu().numpy(), main["relative_pose"][i:i + 1].cpu().numpy()) < ctol(DEFAULT)
 
 
 def test_full_size_view_swap_symmetry(full_b8):
@@ -258,9 +247,9 @@ def test_full_size_view_swap_symmetry(full_b8):
     m, a, b, main, supp = full_b8
     main2, supp2 = m.forward_pair(b[:2], a[:2])
     torch.cuda.synchronize()
-    assert rel_l2(main2["pts3d_pred"].cpu().numpy(), supp["pts3d_pred"][:2].cpu().numpy()) < 2e-5
-    assert rel_l2(supp2["relative_pose"].cpu().numpy(), main["relative_pose"][:2].cpu().numpy()) < 2e-5
-    assert rel_l2(supp2["conf"].cpu().numpy(), main["conf"][:2].cpu().numpy()) < 2e-5
+    assert rel_l2(main2["pts3d_pred"].cpu().numpy(), supp["pts3d_pred"][:2].cpu().numpy()) < ctol(DEFAULT)
+    assert rel_l2(supp2["relative_pose"].cpu().numpy(), main["relative_pose"][:2].cpu().numpy()) < ctol(DEFAULT)
+    assert rel_l2(supp2["conf"].cpu().numpy(), main["conf"][:2].cpu().numpy()) < ctol(DEFAULT)
 
 
 def test_full_size_pair0_matches_reference_golden(full_b8):
@@ -361,8 +350,8 @@ def test_two_slice_concurrency_matches_single_stream(G, prec):
             b1, b2 = m.forward_pair(imgs[:B], imgs[B:])
             torch.cuda.synchronize()
             for k, (r1, r2) in ref.items():
-                assert rel_l2(b1[k].cpu().numpy(), r1.cpu().numpy()) < 2e-5, (cfg, k)
-                assert rel_l2(b2[k].cpu().numpy(), r2.cpu().numpy()) < 2e-5, (cfg, k)
+                assert rel_l2(b1[k].cpu().numpy(), r1.cpu().numpy()) < ctol(prec), (cfg, k)
+                assert rel_l2(b2[k].cpu().numpy(), r2.cpu().numpy()) < ctol(prec), (cfg, k)
         finally:
             m.set_concurrency(1)
 
@@ -539,10 +528,9 @@ def test_keyframe_scheduler_f2_matches_sequential_edges(G, cfg, H, Wd, nview, pr
             continue
         # (the batched call picks other tile families / split-K forms than the B = 1 calls: same arithmetic, other summation
         # orders; in the default policy the DPT head's fp8 correction term makes that a 1e-5-class difference)
-        ctol = 2e-5 if prec == "f16x3" else 6e-5
-        assert rel_l2(r.confs.cpu().numpy(), confs.cpu().numpy()) < ctol
-        assert rel_l2(r.depths.cpu().numpy(), depths.cpu().numpy()) < ctol
-        assert rel_l2(r.intri.cpu().numpy(), intri.cpu().numpy()) < ctol
+        assert rel_l2(r.confs.cpu().numpy(), confs.cpu().numpy()) < ctol(prec)
+        assert rel_l2(r.depths.cpu().numpy(), depths.cpu().numpy()) < ctol(prec)
+        assert rel_l2(r.intri.cpu().numpy(), intri.cpu().numpy()) < ctol(prec)
     assert res[-1].accepted                      # the adjacent edge is never rejected (slam.py:169)
     assert 0 < n_rej < len(js)
 

@@ -16,11 +16,7 @@ for rep in range(2):
         m.set_concurrency(int(envv[1:]) if envv[:1] == "S" and envv[1:].isdigit() else 1)
         if envv and not (envv[:1] == "S" and envv[1:].isdigit()):
             os.environ["STA_EXPERIMENT_" + envv] = "1"
-        if prec.startswith("mask"):          # f16x3 with the given layer classes in the f16mx arithmetic (sta_set_mx_mask)
-            m.set_precision("f16x3")
-            _lib.check(m.lib.sta_set_mx_mask(m._h, int(prec[4:])))
-        else:
-            m.set_precision(prec)
+        m.set_precision(prec)
         _lib.check(m.lib.sta_set_gemm_variant(m._h, v))
         for _ in range(2):
             m.forward_pair(imgs[:B], imgs[B:])

@@ -11,9 +11,8 @@ LIB_PATH = os.path.join(PKG, "libsta_mi355.so")
 
 STA_PREC_F16 = 1
 STA_PREC_F16X3 = 3
-STA_PREC_F16MX = 4
 STA_PREC_F16X3H = 5
-PRECISIONS = {"f16": STA_PREC_F16, "f16x3": STA_PREC_F16X3, "f16mx": STA_PREC_F16MX, "f16x3h": STA_PREC_F16X3H}
+PRECISIONS = {"f16": STA_PREC_F16, "f16x3": STA_PREC_F16X3, "f16x3h": STA_PREC_F16X3H}
 
 
 class StaConfig(C.Structure):
@@ -57,6 +56,7 @@ SIGNATURES = {
     "sta_regress_views": (_i, [_vp, _fp, C.POINTER(_vp), _i, C.c_char_p, _f, _i, _i, _fp, C.POINTER(C.c_float),
                                C.POINTER(_i), C.POINTER(_i), _fp, _fp, _fp, _fp, _vp]),
     "sta_rope2d_inplace": (_i, [_fp, _i64, _i64, _vp, _i, _i, _i, _i, _f, _f, _vp]),
+    "sta_rope2d_inplace_dtype": (_i, [_vp, _i, _i64, _i64, _vp, _i, _i, _i, _i, _f, _f, _vp]),
     "sta_flops_per_pair": (C.c_double, [_vp, _i, _i]),
     "sta_workspace_bytes": (_i64, [_vp]),
     "sta_weight_bytes": (_i64, [_vp]),
@@ -74,7 +74,6 @@ SIGNATURES = {
     # ---- debug / kernel-level test entry points
     "sta_set_gemm_variant": (_i, [_vp, _i]),
     "sta_kernel_timing_dump": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(_i), C.POINTER(_i)]),
-    "sta_set_mx_mask": (_i, [_vp, _i]),
     "sta_kernel_timing_filter": (_i, [_vp, _i, _i, _i, _i]),
     "sta_kernel_timing_dump_shapes": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(C.c_float), C.POINTER(_i), C.POINTER(_i)]),
     "sta_debug_gemm": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _vp]),

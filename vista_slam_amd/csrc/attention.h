@@ -31,7 +31,6 @@ struct AttnParams {
     int S, heads, nq, nk, npad;
     int kv_shift;            // K/V come from sequence (s + kv_shift) % S
     float scale_log2e;       // head_dim^-0.5 * log2(e)
-    int o_mx;                // write the output planes in the f16mx row format (the consumer is an f16mx GEMM)
     int pose;                // decoder: token index nk (== nq) of Q / K / V^T is the pose token.  As a KEY it is folded into the
                              // initial online-softmax state of every query (no 13th key tile for one key); as a QUERY it is served by
                              // the pose blocks (one wave per (sequence, head), plain fp32 dot products); its output row is S*nq + s
@@ -110,8 +109,7 @@ __device__ __forceinline__ void attn_pose_query(const AttnParams& p, char* smem)
     o /= sum;
     const int64_t orow = (int64_t)p.S * p.nq + s, orows = (int64_t)p.S * p.nq + p.S;
     const size_t oo = blk_off<SPLIT>(orow, h * 64 + lane, orows);
-    if (SPLIT && p.o_mx) store_mx1<false>(p.O_hi, oo, o);
-    else if (SPLIT) { f16 hh, ll; split_f16(o, hh, ll); p.O_hi[oo] = hh; p.O_hi[oo + 32] = ll; }
+    if (SPLIT) { f16 hh, ll; split_f16(o, hh, ll); p.O_hi[oo] = hh; p.O_hi[oo + 32] = ll; }
     else p.O_hi[oo] = to_f16_sat(o);
 }
 
@@ -377,11 +375,6 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
             for (int g = 0; g < 4; ++g) {
                 const int dcol = d * 32 + 8 * g + 4 * lhi;
                 const size_t o = blk_off<SPLIT>(orow, h * 64 + dcol, orows);    // blocked planes [ldo/32][S*nq][hi32|lo32]
-                if (SPLIT && p.o_mx) {
-                    const float y[4] = {oacc[d][g * 4] * inv, oacc[d][g * 4 + 1] * inv, oacc[d][g * 4 + 2] * inv, oacc[d][g * 4 + 3] * inv};
-                    store_mx4(p.O_hi, o, split_mx4<false>(y, ra));
-                    continue;
-                }
                 H4 oh, ol;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3h_kernel(const Gem
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i].v, b8[j].v, acc[i][j], 0, 0, 0, sc_a, 0, sc_b);
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i].v, b8[j].v, acc[i][j], 1 /* A: e5m2 */, 0 /* B: e4m3 */, 0, sc_a, 0, sc_b);
         } else {
             half8 a_hi[MT], a_lo[MT], b_hi[NT], b_lo[NT];
 #pragma unroll

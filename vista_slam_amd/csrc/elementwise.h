@@ -14,7 +14,6 @@ struct LnParams {
     const float* g1; const float* b1; f16* o1_hi; f16* o1_lo;
     const float* g2; const float* b2; f16* o2_hi; f16* o2_lo;   // optional (g2 == nullptr)
     float* o32; int ldo32;                                       // optional fp32 output with set 1
-    int mx;                                                      // planes in the f16mx row format (sta_common.h)
     // optional first half of a slab split-K residual GEMM (GemmParams::slab): x[row] += sum_s slab[s][row]; x is rewritten,
     // then normalised as usual (g1 == nullptr: only the add)
     const float* slab; int nslab; float* xw;
@@ -32,15 +31,11 @@ __device__ __forceinline__ void ln_store4(const LnParams& p, int row, int idx, c
         if (p.o32) *reinterpret_cast<float4*>(p.o32 + (size_t)row * p.ldo32 + idx) = make_float4(y[0], y[1], y[2], y[3]);
         if (p.o1_hi) {
             const size_t o = blk_off<SPLIT>(row, idx, p.M);
-            if (SPLIT && p.mx) {
-                store_mx4(p.o1_hi, o, split_mx4<false>(y, ra));
-            } else {
-                H4 h, l;
+            H4 h, l;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e], ra); else h.e[e] = to_f16_sat(y[e], ra); }
-                *reinterpret_cast<uint2*>(p.o1_hi + o) = h.u;
-                if (SPLIT) *reinterpret_cast<uint2*>(p.o1_hi + o + 32) = l.u;
-            }
+            for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e], ra); else h.e[e] = to_f16_sat(y[e], ra); }
+            *reinterpret_cast<uint2*>(p.o1_hi + o) = h.u;
+            if (SPLIT) *reinterpret_cast<uint2*>(p.o1_hi + o + 32) = l.u;
         }
     }
     if (p.g2) {
@@ -48,15 +43,11 @@ __device__ __forceinline__ void ln_store4(const LnParams& p, int row, int idx, c
         float4 b = *reinterpret_cast<const float4*>(p.b2 + idx);
         float y[4] = {n[0] * g.x + b.x, n[1] * g.y + b.y, n[2] * g.z + b.z, n[3] * g.w + b.w};
         const size_t o = blk_off<SPLIT>(row, idx, p.M);
-        if (SPLIT && p.mx) {
-            store_mx4(p.o2_hi, o, split_mx4<false>(y, ra));
-        } else {
-            H4 h, l;
+        H4 h, l;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e], ra); else h.e[e] = to_f16_sat(y[e], ra); }
-            *reinterpret_cast<uint2*>(p.o2_hi + o) = h.u;
-            if (SPLIT) *reinterpret_cast<uint2*>(p.o2_hi + o + 32) = l.u;
-        }
+        for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e], ra); else h.e[e] = to_f16_sat(y[e], ra); }
+        *reinterpret_cast<uint2*>(p.o2_hi + o) = h.u;
+        if (SPLIT) *reinterpret_cast<uint2*>(p.o2_hi + o + 32) = l.u;
     }
 }
 
@@ -168,7 +159,8 @@ __global__ void rows_to_planes_kernel(const float* x, int64_t bstride, int rows,
 
 // planes [nb, rows(+pad), C] -> fp32 [nb, rows, C]  (test/debug taps only)
 __global__ void planes_to_f32_kernel(const f16* hi, const f16* lo, int64_t ibstride_rows, int rows, int C,
-                                     int64_t total, float* out, int64_t irows /* blocked planes with irows rows; 0 = row-major */) {
+                                     int64_t total, float* out, int64_t irows /* blocked planes with irows rows; 0 = row-major */,
+                                     int mx = 0 /* blocked f16mx rows: value = hi + lo8 * 2^-11 */) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
     for (; i < total; i += step) {
@@ -176,7 +168,8 @@ __global__ void planes_to_f32_kernel(const f16* hi, const f16* lo, int64_t ibstr
         int64_t b = r / rows; int rr = (int)(r - b * rows);
         const int64_t srow = ibstride_rows ? b * ibstride_rows + rr : r;
         const size_t src = irows ? (lo ? blk_off<true>(srow, c, irows) : blk_off<false>(srow, c, irows)) : (size_t)(srow * C + c);
-        float v = (float)hi[src]; if (lo) v += (float)lo[src];
+        float v = (float)hi[src];
+        if (mx && lo) v = load_mx_act(hi, src); else if (lo) v += (float)lo[src];
         out[i] = v;
     }
 }
@@ -321,10 +314,10 @@ __global__ __launch_bounds__(256) void bilinear_up2_kernel(const f16* i_hi, cons
             float v00 = (float)a.e[e], v01 = (float)b_.e[e], v10 = (float)c_.e[e], v11 = (float)d.e[e];
             if (SPLIT && mx) {       // the second field holds (hi8, lo8) byte pairs: value = hi + lo8 * 2^-11
                 constexpr float KL = 1.0f / (float)(1 << STA_MX_A_SLO);
-                v00 += __builtin_amdgcn_cvt_f32_fp8(reinterpret_cast<const unsigned short*>(&al)[e], 1) * KL;
-                v01 += __builtin_amdgcn_cvt_f32_fp8(reinterpret_cast<const unsigned short*>(&bl)[e], 1) * KL;
-                v10 += __builtin_amdgcn_cvt_f32_fp8(reinterpret_cast<const unsigned short*>(&cl)[e], 1) * KL;
-                v11 += __builtin_amdgcn_cvt_f32_fp8(reinterpret_cast<const unsigned short*>(&dl)[e], 1) * KL;
+                v00 += __builtin_amdgcn_cvt_f32_bf8(reinterpret_cast<const unsigned short*>(&al)[e], 1) * KL;
+                v01 += __builtin_amdgcn_cvt_f32_bf8(reinterpret_cast<const unsigned short*>(&bl)[e], 1) * KL;
+                v10 += __builtin_amdgcn_cvt_f32_bf8(reinterpret_cast<const unsigned short*>(&cl)[e], 1) * KL;
+                v11 += __builtin_amdgcn_cvt_f32_bf8(reinterpret_cast<const unsigned short*>(&dl)[e], 1) * KL;
             } else
             if (SPLIT) { v00 += (float)al.e[e]; v01 += (float)bl.e[e]; v10 += (float)cl.e[e]; v11 += (float)dl.e[e]; }
             // same association as ATen upsample_bilinear2d: h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)
@@ -376,7 +369,7 @@ __global__ __launch_bounds__(256) void head_final_kernel(const f16* i_hi, const 
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float v = (float)a.e[e];
-                if (SPLIT && mx) v += __builtin_amdgcn_cvt_f32_fp8(reinterpret_cast<const unsigned short*>(&al)[e], 1) * (1.0f / (float)(1 << STA_MX_A_SLO));
+                if (SPLIT && mx) v += __builtin_amdgcn_cvt_f32_bf8(reinterpret_cast<const unsigned short*>(&al)[e], 1) * (1.0f / (float)(1 << STA_MX_A_SLO));
                 else if (SPLIT) v += (float)al.e[e];
 #pragma unroll
                 for (int o = 0; o < 4; ++o) acc[o] += v * wv[o][e];
@@ -601,9 +594,11 @@ __global__ __launch_bounds__(1024) void scale_estimate_kernel(const float* Di, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// curope-compatible in-place 2-D RoPE on fp32 tokens (B,N,Hh,D) (kernels.cu:17-82): one thread per
-// (token, head, pair); accurate sinf/cosf/powf (the reference CUDA build uses fast-math variants).
-__global__ void rope2d_inplace_kernel(float* tok, int64_t sb, int64_t sn, const int64_t* pos,
+// curope-compatible in-place 2-D RoPE on tokens (B,N,Hh,D) of type T = f16 / float / double (kernels.cu:17-82,101): one
+// thread per (token, head, pair); the rotation is evaluated in fp32 for every T, like the reference kernel (its shared
+// memory and cos / sin are float); accurate sinf/cosf/powf (the reference CUDA build uses fast-math variants).
+template <class T>
+__global__ void rope2d_inplace_kernel(T* tok, int64_t sb, int64_t sn, const int64_t* pos,
                                       int B, int N, int Hh, int D, float base, float fwd) {
     const int Q = D / 4;
     const int64_t total = (int64_t)B * N * Hh * 2 * Q;
@@ -613,13 +608,13 @@ __global__ void rope2d_inplace_kernel(float* tok, int64_t sb, int64_t sn, const 
     int xy = (int)(t % 2); t /= 2;
     int h = (int)(t % Hh); t /= Hh;
     int n = (int)(t % N); int b = (int)(t / N);
-    float* base_p = tok + b * sb + n * sn + (int64_t)h * D + xy * 2 * Q;
+    T* base_p = tok + b * sb + n * sn + (int64_t)h * D + xy * 2 * Q;
     const float pp = (float)pos[((int64_t)b * N + n) * 2 + xy];
     const float ang = fwd * pp / powf(base, (float)d / (float)Q);
     const float c = cosf(ang), s = sinf(ang);
-    const float u = base_p[d], v = base_p[d + Q];
-    base_p[d] = u * c - v * s;
-    base_p[d + Q] = v * c + u * s;
+    const float u = (float)base_p[d], v = (float)base_p[d + Q];
+    base_p[d] = (T)(u * c - v * s);
+    base_p[d + Q] = (T)(v * c + u * s);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -230,8 +230,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
             } else {
                 v = gelu_erf(v);
                 const size_t o = blk_off<SPLIT>(row, col, p.c_rp);
-                if (SPLIT && p.c_mx) store_mx1<false>(p.C_hi, o, v, ra);
-                else if (SPLIT) { f16 h, l; split_f16(v, h, l, ra); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
+                if (SPLIT) { f16 h, l; split_f16(v, h, l, ra); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
                 else p.C_hi[o] = to_f16_sat(v, ra);
             }
         }
@@ -264,8 +263,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
             if (ok) {
                 v = gelu_erf(v);
                 const size_t o = blk_off<SPLIT>(row, col, p.c_rp);
-                if (SPLIT && p.c_mx) store_mx1<false>(p.C_hi, o, v, ra);
-                else if (SPLIT) { f16 h, l; split_f16(v, h, l, ra); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
+                if (SPLIT) { f16 h, l; split_f16(v, h, l, ra); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
                 else p.C_hi[o] = to_f16_sat(v, ra);
             }
         } else if (EPI == EPI_F16) {

@@ -399,7 +399,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i].v, b8[j].v, acc[i][j], 0, 0, 0, sc_a, 0, sc_b);
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i].v, b8[j].v, acc[i][j], 1 /* A: e5m2 */, 0 /* B: e4m3 */, 0, sc_a, 0, sc_b);
             if (!RING) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();

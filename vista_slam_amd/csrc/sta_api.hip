@@ -55,10 +55,11 @@ static inline Planes slice_rows(const Planes& p, int64_t r0) {
     q.hi = p.hi + r0 * es; if (p.lo) q.lo = q.hi + 32;
     return q;
 }
-// layer classes of the precision policy (mx_mask): which linears run "f16 main product + block-scaled fp8 corrections"
-enum { CLS_NONE = 0, CLS_QKV = 1 /* qkv, projq, projk|projv */, CLS_PROJ = 2 /* attn.proj, cross_attn.proj */,
-       CLS_FC1 = 4, CLS_FC2 = 8, CLS_HEAD = 16 /* DPT head convolutions */, CLS_ALL = 31 };
-struct Lin { Planes w; Planes wmx; float* bias = nullptr; int N = 0, K = 0; int cls = CLS_NONE; };   // wmx: second packed copy in the f16mx row format
+// layer classes of the precision policy: the DPT head's convolutions may run "f16 main product + one block-scaled fp8 correction
+// MFMA" (the f16mx arithmetic, sta_common.h; precision f16x3h); the transformer and the pose head never do (round 3: the
+// all-layers form failed the stress goldens and was retired)
+enum { CLS_NONE = 0, CLS_HEAD = 16 /* DPT head convolutions */ };
+struct Lin { Planes w; Planes wmx; float* bias = nullptr; int N = 0, K = 0; int cls = CLS_NONE; };   // wmx: second packed copy in the f16mx row format (head only)
 struct LNp { float* g = nullptr; float* b = nullptr; };
 struct EncBlk { LNp n1, n2; Lin qkv, proj, fc1, fc2; };
 struct DecBlk { LNp n1, n2, n3, ny; Lin qkv, proj, cq, ckv, cproj, fc1, fc2; };
@@ -86,7 +87,7 @@ struct sta_handle {
     int device = 0;
     int prec = STA_PREC_F16X3;
     bool deterministic = false;   // sta_set_deterministic: no ATOMIC split-K (the slab forms have a fixed summation order anyway)
-    int mx_mask = 0;          // CLS_* bits of the layer classes that run in the f16mx arithmetic (set by the precision mode)
+    int mx_mask = 0;          // CLS_HEAD when the DPT head runs in the f16mx arithmetic (precision f16x3h), else 0
     bool finalized = false;
     std::unordered_map<std::string, Slot> slots;
     int n_loaded = 0;
@@ -244,11 +245,11 @@ static int build_schema(sta_handle* h) {
         EncBlk& b = h->enc[i];
         snprintf(nm, sizeof nm, "enc_blocks.%d.", i); std::string p(nm);
         CHK(reg_ln(h, p + "norm1", b.n1, E));
-        CHK(reg_linear(h, p + "attn.qkv", b.qkv, 3 * E, E, true, CLS_QKV));
-        CHK(reg_linear(h, p + "attn.proj", b.proj, E, E, true, CLS_PROJ));
+        CHK(reg_linear(h, p + "attn.qkv", b.qkv, 3 * E, E));
+        CHK(reg_linear(h, p + "attn.proj", b.proj, E, E));
         CHK(reg_ln(h, p + "norm2", b.n2, E));
-        CHK(reg_linear(h, p + "mlp.fc1", b.fc1, R * E, E, true, CLS_FC1));
-        CHK(reg_linear(h, p + "mlp.fc2", b.fc2, E, R * E, true, CLS_FC2));
+        CHK(reg_linear(h, p + "mlp.fc1", b.fc1, R * E, E));
+        CHK(reg_linear(h, p + "mlp.fc2", b.fc2, E, R * E));
     }
     CHK(reg_ln(h, "enc_norm", h->enc_norm, E));   // only applied by _encode_image(normalize=True) (sta_model.py:172-173); the forward / SLAM paths pass False
     CHK(reg_linear(h, "decoder_embed", h->dec_embed, D, E));
@@ -257,20 +258,20 @@ static int build_schema(sta_handle* h) {
         DecBlk& b = h->dec[i];
         snprintf(nm, sizeof nm, "dec_block.%d.", i); std::string p(nm);
         CHK(reg_ln(h, p + "norm1", b.n1, D));
-        CHK(reg_linear(h, p + "attn.qkv", b.qkv, 3 * D, D, true, CLS_QKV));
-        CHK(reg_linear(h, p + "attn.proj", b.proj, D, D, true, CLS_PROJ));
-        CHK(reg_linear(h, p + "cross_attn.projq", b.cq, D, D, true, CLS_QKV));
+        CHK(reg_linear(h, p + "attn.qkv", b.qkv, 3 * D, D));
+        CHK(reg_linear(h, p + "attn.proj", b.proj, D, D));
+        CHK(reg_linear(h, p + "cross_attn.projq", b.cq, D, D));
         // projk + projv packed as one [2D, D] GEMM
-        CHK(make_lin(h, b.ckv, 2 * D, D, true, true)); b.ckv.cls = CLS_QKV;
+        CHK(make_lin(h, b.ckv, 2 * D, D));
         slot_w(h, p + "cross_attn.projk.weight", {D, D}, SK_W_ID, b.ckv, 0);
         slot_f32(h, p + "cross_attn.projk.bias", {D}, b.ckv.bias);
         slot_w(h, p + "cross_attn.projv.weight", {D, D}, SK_W_ID, b.ckv, D);
         slot_f32(h, p + "cross_attn.projv.bias", {D}, b.ckv.bias + D);
-        CHK(reg_linear(h, p + "cross_attn.proj", b.cproj, D, D, true, CLS_PROJ));
+        CHK(reg_linear(h, p + "cross_attn.proj", b.cproj, D, D));
         CHK(reg_ln(h, p + "norm2", b.n2, D));
         CHK(reg_ln(h, p + "norm3", b.n3, D));
-        CHK(reg_linear(h, p + "mlp.fc1", b.fc1, R * D, D, true, CLS_FC1));
-        CHK(reg_linear(h, p + "mlp.fc2", b.fc2, D, R * D, true, CLS_FC2));
+        CHK(reg_linear(h, p + "mlp.fc1", b.fc1, R * D, D));
+        CHK(reg_linear(h, p + "mlp.fc2", b.fc2, D, R * D));
         CHK(reg_ln(h, p + "norm_y", b.ny, D));
     }
     CHK(reg_ln(h, "dec_norm", h->dec_norm, D));
@@ -320,7 +321,7 @@ static int build_schema(sta_handle* h) {
 
 // ------------------------------------------------------------------------------------------ API: lifecycle
 static int mask_of_precision(int prec) {
-    return prec == STA_PREC_F16MX ? CLS_ALL : (prec == STA_PREC_F16X3H ? CLS_HEAD : 0);
+    return prec == STA_PREC_F16X3H ? CLS_HEAD : 0;
 }
 
 extern "C" void sta_default_config(sta_config* c) {
@@ -340,7 +341,7 @@ extern "C" int sta_create(const sta_config* cfg, int device, sta_handle** out) {
     REQUIRE(cfg->enc_embed_dim % 128 == 0 && cfg->enc_embed_dim <= 1024, "enc_embed_dim must be a multiple of 128, <= 1024");
     REQUIRE(cfg->dec_embed_dim % 128 == 0 && cfg->dec_embed_dim <= 1024, "dec_embed_dim must be a multiple of 128, <= 1024");
     REQUIRE(cfg->dec_depth > 9, "dec_depth must be > 9 (heads/dpt_head.py:102)");
-    REQUIRE(cfg->precision == STA_PREC_F16 || cfg->precision == STA_PREC_F16X3 || cfg->precision == STA_PREC_F16MX || cfg->precision == STA_PREC_F16X3H, "unknown precision %d", cfg->precision);
+    REQUIRE(cfg->precision == STA_PREC_F16 || cfg->precision == STA_PREC_F16X3 || cfg->precision == STA_PREC_F16X3H, "unknown precision %d", cfg->precision);
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     REQUIRE(device >= 0 && device < ndev, "device %d out of range (%d visible)", device, ndev);
@@ -391,14 +392,8 @@ extern "C" int sta_destroy(sta_handle* h) {
 
 extern "C" int sta_set_precision(sta_handle* h, int precision) {
     REQUIRE(h, "null handle");
-    REQUIRE(precision == STA_PREC_F16 || precision == STA_PREC_F16X3 || precision == STA_PREC_F16MX || precision == STA_PREC_F16X3H, "unknown precision %d", precision);
+    REQUIRE(precision == STA_PREC_F16 || precision == STA_PREC_F16X3 || precision == STA_PREC_F16X3H, "unknown precision %d", precision);
     h->prec = precision; h->mx_mask = mask_of_precision(precision);
-    return 0;
-}
-extern "C" int sta_set_mx_mask(sta_handle* h, int mask) {
-    REQUIRE(h && mask >= 0 && mask <= CLS_ALL, "bad mask");
-    REQUIRE(h->prec != STA_PREC_F16, "the f16mx arithmetic needs the split (f16x3) plane format");
-    h->mx_mask = mask;
     return 0;
 }
 extern "C" int sta_set_deterministic(sta_handle* h, int on) {
@@ -628,6 +623,8 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
         constexpr bool tail_epi = EPI == EPI_F32 || EPI == EPI_F32R || EPI == EPI_GELU || EPI == EPI_QKV;   // gemm2_body: HAS_TAIL
         if (p.m_tail && (bm_v == 0 || (p.M - p.m_tail) % bm_v != 0 || !tail_epi)) p.m_tail = 0;
     }
+    constexpr bool MX_EPI = EPI == EPI_F16 || EPI == EPI_CONVT || EPI == EPI_HEAD;    // the DPT head's epilogues: only they have f16mx kernels
+    REQUIRE(MX_EPI || !p.mx, "internal: f16mx arithmetic outside the DPT head");
     if (p.mx && variant == 1) variant = 5;     // no f16mx form of the register-staged kernel (use_mx() already requires N % 64 == 0)
     // per-launch HIP-event timing (bench / tools): every launch (mode 2), or only the launches of ONE kernel symbol
     // (mode 3, sta_kernel_timing_filter: the event pairs break back-to-back dispatch, ~3.5 us each, so the timed region of
@@ -675,24 +672,24 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
     } else
     if constexpr (EPI == EPI_HEAD) {      // exists for the 192x128 family only (conv3_head checks the shape)
         REQUIRE(variant == 5 && p.N == 128, "internal: fused head epilogue on a tile family without it");
-        if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4, 2, true>(p, st, h->device)));
+        if (p.mx) { if constexpr (MX_EPI) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4, 2, true>(p, st, h->device))); }
         else if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4>(p, st, h->device)));
         else STA_F16ONLY(CHK((launch_gemm2<false, AMODE, EPI, 192, 128, 2, 4>(p, st, h->device))));
     } else
     if (variant == 2) {
-        if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 256, 256, 4, 4, 2, true>(p, st, h->device)));
+        if (p.mx) { if constexpr (MX_EPI) CHK((launch_gemm2<true, AMODE, EPI, 256, 256, 4, 4, 2, true>(p, st, h->device))); }
         else if (split) CHK((launch_gemm2<true, AMODE, EPI, 256, 256, 4, 4>(p, st, h->device)));
         else STA_F16ONLY(CHK((launch_gemm2<false, AMODE, EPI, 256, 256, 4, 4>(p, st, h->device))));
     } else if (variant == 3) {
-        if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 192, 256, 3, 4, 2, true>(p, st, h->device)));
+        if (p.mx) { if constexpr (MX_EPI) CHK((launch_gemm2<true, AMODE, EPI, 192, 256, 3, 4, 2, true>(p, st, h->device))); }
         else if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 256, 3, 4>(p, st, h->device)));
         else STA_F16ONLY(CHK((launch_gemm2<false, AMODE, EPI, 192, 256, 3, 4>(p, st, h->device))));
     } else if (variant == 5) {
-        if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4, 2, true>(p, st, h->device)));
+        if (p.mx) { if constexpr (MX_EPI) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4, 2, true>(p, st, h->device))); }
         else if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4>(p, st, h->device)));
         else STA_F16ONLY(CHK((launch_gemm2<false, AMODE, EPI, 192, 128, 2, 4>(p, st, h->device))));
     } else if (variant == 6) {
-        if (p.mx) CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 2, 2, 3, true>(p, st, h->device)));
+        if (p.mx) { if constexpr (MX_EPI) CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 2, 2, 3, true>(p, st, h->device))); }
         else if (split) CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 2, 2, 3>(p, st, h->device)));
         else STA_F16ONLY(CHK((launch_gemm2<false, AMODE, EPI, 128, 64, 2, 2, 3>(p, st, h->device))));
         if (EPI == EPI_QKV && p.ksplit > 1) {
@@ -754,6 +751,7 @@ static int gemm_f32(sta_handle* h, const Planes& A, const Lin& W, int M, float* 
 }
 // c_mx: the output planes feed an f16mx GEMM (mlp.fc1 -> GELU -> mlp.fc2)
 static int gemm_f16(sta_handle* h, const Planes& A, const Lin& W, int M, const Planes& out, int act, hipStream_t st, bool c_mx = false) {
+    REQUIRE(h->dry || !c_mx || act != ACT_GELU, "internal: the GELU epilogue (mlp.fc1) has no f16mx output form");
     GemmParams p = gp_dense(A, W.K, W, M, use_mx(h, W));
     p.C_hi = out.hi; p.C_lo = out.lo; p.ldc16 = W.N; p.act = act; p.c_rp = out.rp; p.c_mx = c_mx ? 1 : 0;
     REQUIRE(h->dry || (A.rp >= M && out.rp >= M), "internal: plane rows mismatch in gemm_f16");
@@ -763,13 +761,13 @@ static int gemm_f16(sta_handle* h, const Planes& A, const Lin& W, int M, const P
     return launch_gemm<A_DENSE, EPI_F16>(h, p, st);
 }
 static int run_ln(sta_handle* h, const float* x, int M, int C, const LNp& a, const Planes& oa, const LNp* b, const Planes* ob,
-                  float* o32, hipStream_t st, bool mx, const float* slab, int nslab);
+                  float* o32, hipStream_t st, const float* slab, int nslab);
 // x += A W^T + b (attn.proj, mlp.fc2, cross_attn.proj) followed by the LayerNorm(s) of x the next GEMM(s) read (la == nullptr:
 // none).  Throughput scale: the in-place GEMM, then the LayerNorm kernel.  Small-M regime (SLAM scale): the K slices store
 // partial tiles to slabs and the LayerNorm kernel adds them into x before normalising - the same two dispatches without
 // the atomics epilogue (13-15 us -> 8 us per GEMM at M = 196), and bit-reproducible.
 static int gemm_resid_ln(sta_handle* h, const Planes& A, const Lin& W, int M, float* x, int ld, const LNp* la, const Planes* oa,
-                         const LNp* lb, const Planes* ob, bool ln_mx, hipStream_t st) {
+                         const LNp* lb, const Planes* ob, hipStream_t st) {
     static const LNp no_ln = {nullptr, nullptr};
     static const Planes no_planes;
     const bool small = small_grid(M, W.N) && W.N % 64 == 0 && W.N <= 1024 && auto_family(h) && ld == W.N;
@@ -783,11 +781,11 @@ static int gemm_resid_ln(sta_handle* h, const Planes& A, const Lin& W, int M, fl
         CHK((launch_gemm<A_DENSE, EPI_F32>(h, p, st)));
         const int ks = h->slab_ks;
         h->slab_ks = 0;
-        if (ks > 1) return run_ln(h, x, M, W.N, la ? *la : no_ln, oa ? *oa : no_planes, lb, ob, nullptr, st, ln_mx, p.slab, ks);
+        if (ks > 1) return run_ln(h, x, M, W.N, la ? *la : no_ln, oa ? *oa : no_planes, lb, ob, nullptr, st, p.slab, ks);
     } else {
         CHK(gemm_f32(h, A, W, M, x, ld, x, st));
     }
-    if (la) return run_ln(h, x, M, W.N, *la, *oa, lb, ob, nullptr, st, ln_mx, nullptr, 0);
+    if (la) return run_ln(h, x, M, W.N, *la, *oa, lb, ob, nullptr, st, nullptr, 0);
     return 0;
 }
 struct QKVOut { Planes q, k, vt; int npad; };
@@ -902,12 +900,11 @@ static int conv3_head(sta_handle* h, const Planes& in, int nimg, int Hi, int Wi,
 }
 
 static int run_ln(sta_handle* h, const float* x, int M, int C, const LNp& a, const Planes& oa,
-                  const LNp* b, const Planes* ob, float* o32, hipStream_t st, bool mx = false,
+                  const LNp* b, const Planes* ob, float* o32, hipStream_t st,
                   const float* slab = nullptr, int nslab = 0) {
     if (h->dry) return 0;
     LnParams p; memset(&p, 0, sizeof p);
     p.slab = slab; p.nslab = nslab; p.xw = const_cast<float*>(x);     // slab split-K: x += sum of the slices first (x is the residual stream)
-    p.mx = mx ? 1 : 0;     // plane format of the consumer GEMM (f16mx rows when that linear runs in the f16mx arithmetic)
     p.x = x; p.ldx = C; p.M = M; p.C = C; p.eps = h->cfg.ln_eps;
     p.g1 = a.g; p.b1 = a.b; p.o1_hi = oa.hi; p.o1_lo = oa.lo;
     if (b) { p.g2 = b->g; p.b2 = b->b; p.o2_hi = ob->hi; p.o2_lo = ob->lo; }
@@ -928,12 +925,11 @@ static int run_ln(sta_handle* h, const float* x, int M, int C, const LNp& a, con
 
 // pose: token index nq (== nk) of the buffers is the pose token (decoder row order, see decode_impl / AttnParams::pose)
 static int run_attn(sta_handle* h, const QKVOut& qkv, const Planes& out, int ldo, int S, int heads,
-                    int nq, int nk, int kv_shift, hipStream_t st, bool o_mx = false, bool pose = false) {
+                    int nq, int nk, int kv_shift, hipStream_t st, bool pose = false) {
     if (h->dry) return 0;
     REQUIRE(!pose || (nq == nk && nq + 1 <= qkv.npad), "internal: pose-token attention needs nq == nk < npad");
     AttnParams p; memset(&p, 0, sizeof p);
     p.pose = pose ? 1 : 0;
-    p.o_mx = o_mx ? 1 : 0;   // attention output feeds attn.proj / cross_attn.proj: their plane format
     p.Q_hi = qkv.q.hi; p.Q_lo = qkv.q.lo; p.K_hi = qkv.k.hi; p.K_lo = qkv.k.lo; p.Vt_hi = qkv.vt.hi; p.Vt_lo = qkv.vt.lo;
     p.O_hi = out.hi; p.O_lo = out.lo; p.ldo = ldo;
     p.S = S; p.heads = heads; p.nq = nq; p.nk = nk; p.npad = qkv.npad; p.kv_shift = kv_shift;
@@ -1026,15 +1022,15 @@ static int encode_impl(sta_handle* h, Bump& ws, const void* const* imgs, bool u8
     }
     CHK(gemm_f32(h, patches, h->patch, M, feat, E, nullptr, st));
     // every in-place residual GEMM is issued together with the LayerNorm that reads its result (gemm_resid_ln)
-    if (c.enc_depth > 0) CHK(run_ln(h, feat, M, E, h->enc[0].n1, lnp, nullptr, nullptr, nullptr, st, use_mx(h, h->enc[0].qkv)));
+    if (c.enc_depth > 0) CHK(run_ln(h, feat, M, E, h->enc[0].n1, lnp, nullptr, nullptr, nullptr, st));
     for (int i = 0; i < c.enc_depth; ++i) {
         const EncBlk& b = h->enc[i];
         CHK(gemm_qkv(h, lnp, b.qkv, M, E, E, E, qkv, N, Hh, wp, 0, st));
-        CHK(run_attn(h, qkv, ao, E, n, Hh, N, N, 0, st, use_mx(h, b.proj)));
-        CHK(gemm_resid_ln(h, ao, b.proj, M, feat, E, &b.n2, &lnp, nullptr, nullptr, use_mx(h, b.fc1), st));
-        CHK(gemm_f16(h, lnp, b.fc1, M, f1, ACT_GELU, st, use_mx(h, b.fc2)));
-        if (i + 1 < c.enc_depth) CHK(gemm_resid_ln(h, f1, b.fc2, M, feat, E, &h->enc[i + 1].n1, &lnp, nullptr, nullptr, use_mx(h, h->enc[i + 1].qkv), st));
-        else CHK(gemm_resid_ln(h, f1, b.fc2, M, feat, E, nullptr, nullptr, nullptr, nullptr, false, st));
+        CHK(run_attn(h, qkv, ao, E, n, Hh, N, N, 0, st));
+        CHK(gemm_resid_ln(h, ao, b.proj, M, feat, E, &b.n2, &lnp, nullptr, nullptr, st));
+        CHK(gemm_f16(h, lnp, b.fc1, M, f1, ACT_GELU, st));
+        if (i + 1 < c.enc_depth) CHK(gemm_resid_ln(h, f1, b.fc2, M, feat, E, &h->enc[i + 1].n1, &lnp, nullptr, nullptr, st));
+        else CHK(gemm_resid_ln(h, f1, b.fc2, M, feat, E, nullptr, nullptr, nullptr, nullptr, st));
     }
     return 0;
 }
@@ -1101,7 +1097,7 @@ static int decode_impl(sta_handle* h, Bump& ws, const float* feat1, const float*
     TailHint tail(h, S);                 // every dense GEMM below: the last S rows are the pose-token rows
     // norm1(x) and norm_y(x) from one read: y of one side == x of the other (sta_model.py:231-235); qkv and projk|projv:
     // one class, one plane format.  Layer i+1's pair is issued with layer i's mlp.fc2 (gemm_resid_ln).
-    if (c.dec_depth > 0) CHK(run_ln(h, x, M, D, h->dec[0].n1, a1, &h->dec[0].ny, &ay, nullptr, st, use_mx(h, h->dec[0].qkv)));
+    if (c.dec_depth > 0) CHK(run_ln(h, x, M, D, h->dec[0].n1, a1, &h->dec[0].ny, &ay, nullptr, st));
     for (int i = 0; i < c.dec_depth; ++i) {
         const DecBlk& b = h->dec[i];
         // self-attention q,k,v and the cross-attention k,v of the OTHER side depend only on the layer input: one launch.
@@ -1112,18 +1108,18 @@ static int decode_impl(sta_handle* h, Bump& ws, const float* feat1, const float*
             CHK(gp_qkv(h, pkv, ay, b.ckv, M, 0, D, D, cqkv, N, Hh, wp, 0, Mp));
             CHK(gemm_qkv_pair(h, pq, pkv, st));
         }
-        CHK(run_attn(h, qkv, ao, D, S, Hh, N, N, 0, st, use_mx(h, b.proj), true));
-        CHK(gemm_resid_ln(h, ao, b.proj, M, x, D, &b.n2, &a1, nullptr, nullptr, use_mx(h, b.cq), st));
+        CHK(run_attn(h, qkv, ao, D, S, Hh, N, N, 0, st, true));
+        CHK(gemm_resid_ln(h, ao, b.proj, M, x, D, &b.n2, &a1, nullptr, nullptr, st));
         CHK(gemm_qkv(h, a1, b.cq, M, D, 0, 0, cqkv, N, Hh, wp, 0, st, Mp));
-        CHK(run_attn(h, cqkv, ao, D, S, Hh, N, N, B, st, use_mx(h, b.cproj), true));
-        CHK(gemm_resid_ln(h, ao, b.cproj, M, x, D, &b.n3, &a1, nullptr, nullptr, use_mx(h, b.fc1), st));
-        CHK(gemm_f16(h, a1, b.fc1, M, f1, ACT_GELU, st, use_mx(h, b.fc2)));
+        CHK(run_attn(h, cqkv, ao, D, S, Hh, N, N, B, st, true));
+        CHK(gemm_resid_ln(h, ao, b.cproj, M, x, D, &b.n3, &a1, nullptr, nullptr, st));
+        CHK(gemm_f16(h, a1, b.fc1, M, f1, ACT_GELU, st));
         if (i + 1 < c.dec_depth) {
             const DecBlk& nb = h->dec[i + 1];
-            CHK(gemm_resid_ln(h, f1, b.fc2, M, x, D, &nb.n1, &a1, &nb.ny, &ay, use_mx(h, nb.qkv), st));
+            CHK(gemm_resid_ln(h, f1, b.fc2, M, x, D, &nb.n1, &a1, &nb.ny, &ay, st));
             CHK(emit(i + 1, x));
         } else {   // final_x[-1] = dec_norm(final_x[-1])  (sta_model.py:241-242)
-            CHK(gemm_resid_ln(h, f1, b.fc2, M, x, D, nullptr, nullptr, nullptr, nullptr, false, st));
+            CHK(gemm_resid_ln(h, f1, b.fc2, M, x, D, nullptr, nullptr, nullptr, nullptr, st));
             const bool wanted = (want1 && want1[i + 1]) || (ref_layout && want2 && want2[i + 1]);
             if (wanted) {
                 Planes none;
@@ -1522,15 +1518,23 @@ extern "C" int sta_get_stage_ms(sta_handle* h, float ms[4]) {
     return 0;
 }
 
-extern "C" int sta_rope2d_inplace(float* tokens_dev, int64_t stride_b, int64_t stride_n, const int64_t* pos_dev,
-                                  int B, int N, int Hh, int D, float base, float fwd, void* stream) {
+extern "C" int sta_rope2d_inplace_dtype(void* tokens_dev, int dtype, int64_t stride_b, int64_t stride_n, const int64_t* pos_dev,
+                                        int B, int N, int Hh, int D, float base, float fwd, void* stream) {
     REQUIRE(tokens_dev && pos_dev, "null device pointer");
     REQUIRE(D % 4 == 0, "token dim must be multiple of 4");
+    REQUIRE(dtype == STA_DTYPE_F32 || dtype == STA_DTYPE_F16 || dtype == STA_DTYPE_F64, "rope_2d: unsupported token dtype %d", dtype);
     int64_t total = (int64_t)B * N * Hh * (D / 2);
-    hipLaunchKernelGGL(rope2d_inplace_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       tokens_dev, stride_b, stride_n, pos_dev, B, N, Hh, D, base, fwd);
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == STA_DTYPE_F32) hipLaunchKernelGGL(rope2d_inplace_kernel<float>, grid, block, 0, st, (float*)tokens_dev, stride_b, stride_n, pos_dev, B, N, Hh, D, base, fwd);
+    else if (dtype == STA_DTYPE_F16) hipLaunchKernelGGL(rope2d_inplace_kernel<f16>, grid, block, 0, st, (f16*)tokens_dev, stride_b, stride_n, pos_dev, B, N, Hh, D, base, fwd);
+    else hipLaunchKernelGGL(rope2d_inplace_kernel<double>, grid, block, 0, st, (double*)tokens_dev, stride_b, stride_n, pos_dev, B, N, Hh, D, base, fwd);
     HIPCHK(hipGetLastError());
     return 0;
+}
+extern "C" int sta_rope2d_inplace(float* tokens_dev, int64_t stride_b, int64_t stride_n, const int64_t* pos_dev,
+                                  int B, int N, int Hh, int D, float base, float fwd, void* stream) {
+    return sta_rope2d_inplace_dtype(tokens_dev, STA_DTYPE_F32, stride_b, stride_n, pos_dev, B, N, Hh, D, base, fwd, stream);
 }
 
 #include "sta_bench.inc"    // FLOP model + GEMM micro-benchmark entry points

@@ -12,8 +12,8 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 #define STA_F16_MAX 65504.0f
 
-// Range report (sta_range_report): how many values did not fit the fp16 planes (|x| > 65504, or NaN) and how many fp8
-// correction bytes of the f16mx arithmetic saturated at +-448, since the last reset.  The planes SATURATE instead of
+// Range report (sta_range_report): how many values did not fit the fp16 planes (|x| > 65504) and how many fp8 correction
+// bytes of the f16mx arithmetic saturated (activations: e5m2, +-57344; weights: e4m3, |w| > 28), since the last reset.  The planes SATURATE instead of
 // producing inf; a non-zero count says the result is no longer backed by the parity goldens.  Rare path: one compare per value.
 // A writer tracks the largest magnitude it stored in a RangeAcc (ONE v_max_f32 per value, no compare, no branch) and
 // flushes once per tile / row / call: the counters count (lane, flush) events with at least one out-of-range value, not values.
@@ -21,11 +21,11 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 __device__ unsigned long long g_sta_range[2];
 struct RangeAcc {
     float amax = 0.f;       // largest |x| written as an fp16 (hi, residual) pair
-    float amax8 = 0.f;      // largest |x| whose e4m3 copy was written (f16mx activation rows: saturates beyond 448)
+    float amax8 = 0.f;      // largest |x| whose fp8 (e5m2) copy was written (f16mx activation rows: saturates beyond 57344)
     bool w8 = false;        // a WEIGHT e4m3 byte saturated (packing at load time: exact check)
     __device__ __forceinline__ void flush() {
         if (__builtin_expect(amax > STA_F16_MAX, 0)) atomicAdd(&g_sta_range[0], 1ull);
-        if (__builtin_expect(amax8 > 448.f || w8, 0)) atomicAdd(&g_sta_range[1], 1ull);
+        if (__builtin_expect(amax8 > 57344.f || w8, 0)) atomicAdd(&g_sta_range[1], 1ull);
         amax = amax8 = 0.f; w8 = false;
     }
 };
@@ -88,25 +88,35 @@ __device__ __forceinline__ size_t blk_off(int64_t row, int col, int64_t rows) {
 
 // ---------------------------------------------------------------------------------------------------------
 // Precision f16mx ("f16 main product + block-scaled fp8 corrections"): x ~= hi + lo as in f16x3, but the two correction
-// products Al*Bh + Ah*Bl are issued as ONE v_mfma_scale_f32_32x32x64_f8f6f4 (2x the f16 MFMA rate) on fp8-e4m3 copies.
+// products Al*Bh + Ah*Bl are issued as ONE v_mfma_scale_f32_32x32x64_f8f6f4 (2x the f16 MFMA rate) on fp8 copies.
 // Row block of 32 k (128 B: same size and the same blocked layout as f16x3):
 //     [ hi f16 x32 (64 B) | 32 byte pairs (64 B) ]
-//   activation pair k = ( e4m3(hi * 2^0),  e4m3(lo * 2^11) )        (|lo| <= 2^-11 |hi|)
+//   activation pair k = ( e5m2(hi * 2^0),  e5m2(lo * 2^11) )        (|lo| <= 2^-11 |hi|; e5m2 since round 3, see cvt2_fp8)
 //   weight     pair k = ( e4m3(lo * 2^15), e4m3(hi * 2^4)  )        (|w| << 1) - the OPPOSITE order, so that byte q of
 //   an activation row meets byte q of a weight row as hi8 x lo8 / lo8 x hi8, i.e. exactly the two correction products;
 //   both carry the same combined scale 2^-(0+15) = 2^-(11+4) = 2^-15, applied by the instruction's E8M0 block scales.
-// Relative error of a GEMM ~1e-5 (f16x3: 9e-7, one-product f16: 3e-4) - measured in tests/test_gpu_kernels.py.
+// Relative error of a GEMM ~2e-5 with e5m2 activation bytes, ~1e-5 with e4m3 (f16x3: 9e-7, one-product f16: 3e-4) - measured in tests/test_gpu_kernels.py.
 #define STA_MX_A_SHI 0
 #define STA_MX_A_SLO 11
 #define STA_MX_W_SHI 4
 #define STA_MX_W_SLO 15
 static_assert(STA_MX_A_SHI + STA_MX_W_SLO == STA_MX_A_SLO + STA_MX_W_SHI, "both correction products must share one scale");
 
-__device__ __forceinline__ float clamp_e4m3(float x) { return fminf(fmaxf(x, -448.f), 448.f); }
-// (first, second) -> two OCP e4m3 bytes (RNE, saturating) in the low / high 16 bits of `old`
-__device__ __forceinline__ int cvt2_e4m3(float first, float second, int old, bool high) {
-    return high ? __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(first), clamp_e4m3(second), old, true)
-                : __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(first), clamp_e4m3(second), old, false);
+// fp8 formats of the correction bytes: WEIGHTS e4m3 (|w * 2^4| <= 448, 3 mantissa bits: static, small values); ACTIVATIONS
+// e5m2 ("bf8", +-57344 - the fp16 planes' own range - at 2 mantissa bits: round 3, after the outlier goldens showed DPT feature
+// maps past +-448 saturating the e4m3 copy and the head's error growing from 2e-5 to 3e-4).  The MFMA takes one format per
+// operand (cbsz = 1: A is bf8, blgp = 0: B is fp8).
+#define STA_MX_A_MAX 57344.f
+#define STA_MX_W_MAX 448.f
+__device__ __forceinline__ float clamp_e4m3(float x) { return fminf(fmaxf(x, -STA_MX_W_MAX), STA_MX_W_MAX); }
+__device__ __forceinline__ float clamp_e5m2(float x) { return fminf(fmaxf(x, -STA_MX_A_MAX), STA_MX_A_MAX); }
+// (first, second) -> two fp8 bytes (RNE, saturating) in the low / high 16 bits of `old`: OCP e4m3 (weights) or e5m2 (activations)
+template <bool WEIGHT>
+__device__ __forceinline__ int cvt2_fp8(float first, float second, int old, bool high) {
+    if (WEIGHT) return high ? __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(first), clamp_e4m3(second), old, true)
+                            : __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(first), clamp_e4m3(second), old, false);
+    return high ? __builtin_amdgcn_cvt_pk_bf8_f32(clamp_e5m2(first), clamp_e5m2(second), old, true)
+                : __builtin_amdgcn_cvt_pk_bf8_f32(clamp_e5m2(first), clamp_e5m2(second), old, false);
 }
 struct MX4 { uint2 hi; uint2 pairs; };
 template <bool WEIGHT>
@@ -122,13 +132,13 @@ __device__ __forceinline__ MX4 split_mx4(const float y[4], RangeAcc& ra) {
         const float hf = (float)h.e[e], lf = x - hf;
         a[e] = WEIGHT ? lf * KLO : hf * KHI;
         b[e] = WEIGHT ? hf * KHI : lf * KLO;
-        // activations: |lo * 2^11| <= |hi|, so the pair saturates iff |hi| > 448; weights (load time): exact check
-        if (WEIGHT) ra.w8 |= fabsf(a[e]) > 448.f || fabsf(b[e]) > 448.f;
+        // activations: |lo * 2^11| <= |hi|, so the pair saturates iff |hi| > 57344; weights (load time): exact check
+        if (WEIGHT) ra.w8 |= fabsf(a[e]) > STA_MX_W_MAX || fabsf(b[e]) > STA_MX_W_MAX;
     }
     if (!WEIGHT) ra.amax8 = ra.amax;      // (this accumulator only ever sees f16mx rows)
     MX4 r; r.hi = h.u;
-    int w0 = cvt2_e4m3(a[0], b[0], 0, false); w0 = cvt2_e4m3(a[1], b[1], w0, true);
-    int w1 = cvt2_e4m3(a[2], b[2], 0, false); w1 = cvt2_e4m3(a[3], b[3], w1, true);
+    int w0 = cvt2_fp8<WEIGHT>(a[0], b[0], 0, false); w0 = cvt2_fp8<WEIGHT>(a[1], b[1], w0, true);
+    int w1 = cvt2_fp8<WEIGHT>(a[2], b[2], 0, false); w1 = cvt2_fp8<WEIGHT>(a[3], b[3], w1, true);
     r.pairs = make_uint2((unsigned)w0, (unsigned)w1);
     return r;
 }
@@ -142,7 +152,7 @@ __device__ __forceinline__ void store_mx4(f16* base, size_t o, const MX4& v) {
 // value of an f16mx ACTIVATION element: hi + lo8 * 2^-11 (readers outside the GEMMs: residual adds, bilinear, head)
 __device__ __forceinline__ float load_mx_act(const f16* base, size_t o) {
     const int pair = reinterpret_cast<const unsigned short*>(base)[o + 32];
-    return (float)base[o] + __builtin_amdgcn_cvt_f32_fp8(pair, 1) * (1.0f / (float)(1 << STA_MX_A_SLO));
+    return (float)base[o] + __builtin_amdgcn_cvt_f32_bf8(pair, 1) * (1.0f / (float)(1 << STA_MX_A_SLO));
 }
 template <bool WEIGHT>
 __device__ __forceinline__ void store_mx1(f16* base, size_t o, float x, RangeAcc& ra) {     // scalar variant (column-per-lane epilogues)
@@ -150,8 +160,8 @@ __device__ __forceinline__ void store_mx1(f16* base, size_t o, float x, RangeAcc
     constexpr float KLO = WEIGHT ? (float)(1 << STA_MX_W_SLO) : (float)(1 << STA_MX_A_SLO);
     x = sat_f16_range(x, ra);
     const f16 h = (f16)x; const float hf = (float)h, lf = x - hf;
-    if (WEIGHT) ra.w8 |= fabsf(lf * KLO) > 448.f || fabsf(hf * KHI) > 448.f; else ra.amax8 = ra.amax;
-    const int b = WEIGHT ? cvt2_e4m3(lf * KLO, hf * KHI, 0, false) : cvt2_e4m3(hf * KHI, lf * KLO, 0, false);
+    if (WEIGHT) ra.w8 |= fabsf(lf * KLO) > STA_MX_W_MAX || fabsf(hf * KHI) > STA_MX_W_MAX; else ra.amax8 = ra.amax;
+    const int b = WEIGHT ? cvt2_fp8<true>(lf * KLO, hf * KHI, 0, false) : cvt2_fp8<false>(hf * KHI, lf * KLO, 0, false);
     base[o] = h;
     reinterpret_cast<unsigned short*>(base)[o + 32] = (unsigned short)(b & 0xFFFF);
 }

@@ -103,7 +103,7 @@ class STAFrontend:
         self.precision = precision
 
     def range_report(self, reset: bool = True):
-        """(fp16 saturations, e4m3 saturations) counted by the plane writers on this GPU since the last reset
+        """(fp16 saturations, fp8 correction-byte saturations) counted by the plane writers on this GPU since the last reset
         (sta_range_report): non-zero fp16 saturations = the forward left the range the fp16 planes can carry."""
         c = (C.c_ulonglong * 2)()
         _lib.check(self.lib.sta_range_report(self._h, c, int(reset)))
@@ -394,8 +394,8 @@ class STAFrontend:
 
 
 def rope2d_inplace(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: float = 1.0):
-    """curope.rope_2d drop-in (pos_embed/curope/curope.cpp:49-65): tokens (B,N,H,D) fp32 CUDA view with
-    stride(3)==1 and stride(2)==D, positions (B,N,2) int64 contiguous; rotates in place."""
+    """curope.rope_2d drop-in (pos_embed/curope/curope.cpp:49-65): tokens (B,N,H,D) fp16 / fp32 / fp64 CUDA view (the dtypes
+    kernels.cu:101 dispatches on) with stride(3)==1 and stride(2)==D, positions (B,N,2) int64 contiguous; rotates in place."""
     lib = _lib.load()
     assert tokens.dim() == 4, "tokens must have 4 dimensions"
     assert positions.dim() == 3, "positions must have 3 dimensions"
@@ -403,11 +403,13 @@ def rope2d_inplace(tokens: torch.Tensor, positions: torch.Tensor, base: float, f
     assert tokens.size(1) == positions.size(1), "seq_length differs between tokens & positions"
     assert positions.size(2) == 2, "positions.shape[2] must be equal to 2"
     assert tokens.is_cuda and positions.is_cuda, "tokens and positions must be on the GPU"
-    assert tokens.dtype == torch.float32 and positions.dtype == torch.int64
+    dt = {torch.float32: 0, torch.float16: 1, torch.float64: 2}.get(tokens.dtype)
+    assert dt is not None, f"rope_2d: unsupported token dtype {tokens.dtype}"       # (AT_DISPATCH_FLOATING_TYPES_AND_HALF)
+    assert positions.dtype == torch.int64
     B, N, Hh, D = tokens.shape
     assert tokens.stride(3) == 1 and tokens.stride(2) == D, "tokens are not contiguous"
     assert positions.is_contiguous(), "positions are not contiguous"
     assert D % 4 == 0, "token dim must be multiple of 4"
-    _lib.check(lib.sta_rope2d_inplace(tokens.data_ptr(), tokens.stride(0), tokens.stride(1), positions.data_ptr(),
-                                      B, N, Hh, D, float(base), float(fwd), _stream_ptr(tokens.device)))
+    _lib.check(lib.sta_rope2d_inplace_dtype(tokens.data_ptr(), dt, tokens.stride(0), tokens.stride(1), positions.data_ptr(),
+                                            B, N, Hh, D, float(base), float(fwd), _stream_ptr(tokens.device)))
     return tokens

@@ -192,8 +192,8 @@ def _outlier(cfg: STAConfig, seed: int, level: int, src: str, kind: str, a: np.n
       hooks see them;
     * DPT head (no normalisation layers, dpt_block.py:264-324, use_bn=False): the four act_postprocess 1x1 convolutions are
       scaled by OUTLIER_DPT_SCALE[level] and head.4 by its inverse, so every feature map of the head is 300x larger
-      (level 1: past the +-448 of the e4m3 correction bytes of the f16mx arithmetic) or 3e4x larger (level 2: past the
-      +-65504 of the fp16 planes) while the fp32 reference's outputs keep their scale."""
+      (level 1: up to 6.5e3 - past the +-448 an e4m3 correction byte could carry, which is why the f16mx arithmetic keeps
+      its ACTIVATION bytes in e5m2) or 3e4x larger (level 2: past the +-65504 of the fp16 planes) while the fp32 reference's outputs keep their scale."""
     if kind == "ln_w":
         n = a.size
         u = hash_uniform(_name_seed(seed, src + "/outlier"), 2 * n)
@@ -225,7 +225,7 @@ def generate(cfg: STAConfig = FULL, seed: int = 43, qk_gain: float = 1.0,
     hides under the 1e-3 bar.
 
     outlier > 0 adds trained-checkpoint-like range statistics (`_outlier`): 1 = heavy-tailed LayerNorm gains, massive
-    activation channels, DPT feature maps past +-448; 2 = DPT feature maps past the fp16 range as well.
+    activation channels, DPT feature maps up to 6.5e3; 2 = DPT feature maps past the fp16 range as well.
     """
     E, D = cfg.enc_embed_dim, cfg.dec_embed_dim
     sch = schema(cfg)
