@@ -16,8 +16,16 @@ extern "C" {
 /* Force the GEMM tile family: 0 = automatic (product behaviour), 1 = 128x128 register-staged kernel,
  * 2 = 256-row direct-to-LDS kernels, 3 = 192-row ones (whenever N % 128 == 0), 4 = 192x128 everywhere, 8 = the halo-tiled
  * 3x3 convolution kernel (conv3h.h) wherever it is legal (stride 1, Cout 128 / 256), 9 = automatic WITHOUT that kernel
- * (same-box A/B).  Lets the tests cover the families on small shapes. */
+ * (same-box A/B), 10 / 11 = automatic with the small-grid family switched off / extended to 4x its threshold (process-wide;
+ * tools/tile_table.py only).  Lets the tests cover the families on small shapes. */
 int sta_set_gemm_variant(sta_handle* h, int variant);
+
+/* The tile family launch_gemm's cost model picks for a GEMM / convolution (pure host function, no handle, no GPU:
+ * tests/test_tile_table.py replays profiles/r03_tile_table.txt through it).  amode: 0 dense, 1 3x3 convolution; epi: 0 f32,
+ * 1 f16 planes, 2 qkv, 3 convT, 4 gelu, 5 f32 in-place residual, 6 fused head; M without the pose-token tail rows; split: 1 for
+ * the f16x3 / f16x3h precisions; cstride / Ho / Wo: convolutions only (0 otherwise).  Returns 1, 2, 3, 5, 6 or 8
+ * (sta_api.hip: pick_family). */
+int sta_debug_pick_family(int amode, int epi, long long M, int N, int K, int split, int cstride, int Ho, int Wo);
 
 /* nn.Linear (+GELU/ReLU, +residual): out[M,N] = act(A[M,K] W[N,K]^T + bias) (+resid).
  * act: 0 none, 1 erf-GELU, 2 ReLU.  via_f16 != 0 uses the fp16-plane epilogue (sta_blocks.py:73-79). */

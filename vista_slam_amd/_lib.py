@@ -82,6 +82,7 @@ SIGNATURES = {
     "sta_debug_attention_pose": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _vp]),
     "sta_debug_set_tail_hint": (_i, [_vp, _i]),
     "sta_debug_set_option": (_i, [_vp, _i, _i]),
+    "sta_debug_pick_family": (_i, [_i, _i, C.c_longlong, _i, _i, _i, _i, _i, _i]),
     "sta_debug_conv3x3": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _fp, _fp, _vp]),
     "sta_debug_convt": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _vp]),
     "sta_debug_up2": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _i, _fp, _vp]),

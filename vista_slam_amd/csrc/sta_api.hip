@@ -407,9 +407,11 @@ extern "C" int sta_set_concurrency(sta_handle* h, int n_slices) {
     h->n_streams = n_slices;
     return 0;
 }
+static int g_small_grid_mode = 0;        // tools/tile_table.py only (sta_set_gemm_variant 10 / 11): 1 = never, 2 = 4x the product threshold
 extern "C" int sta_set_gemm_variant(sta_handle* h, int variant) {
-    REQUIRE(h && ((variant >= 0 && variant <= 4) || variant == 8 || variant == 9), "bad gemm variant");
-    h->gemm_variant = variant;
+    REQUIRE(h && ((variant >= 0 && variant <= 4) || (variant >= 8 && variant <= 11)), "bad gemm variant");
+    g_small_grid_mode = variant == 10 ? 1 : (variant == 11 ? 2 : 0);      // process-wide: measurement tool only
+    h->gemm_variant = variant >= 10 ? 0 : variant;
     return 0;
 }
 extern "C" int sta_range_report(sta_handle* h, unsigned long long counts[2], int reset) {
@@ -511,10 +513,66 @@ static int launch_conv3h(const GemmParams& p, hipStream_t st, int dev) {
 
 static inline bool auto_family(const sta_handle* h) { return h->gemm_variant == 0 || h->gemm_variant == 9; }
 
-// The ONE small-grid predicate (SLAM scale: 224x224, batch 1..6 -> M = 196..2400 rows): below it the 128x64 split-K family
-// runs (launch_gemm), in-place residual GEMMs hand their K slices to resid_ln_kernel (gemm_resid_ln), and the specialised
-// throughput epilogues / the paired launch are not used (gemm_f32, gemm_qkv_pair).
-static inline bool small_grid(int64_t M, int N) { return M <= 640 || ((M + 191) / 192) * (int64_t)((N + 127) / 128) < 128; }
+// The ONE small-grid predicate (SLAM scale: 224x224, batch 1..8 -> M = 196..3200 rows; the DPT levels with <= 12288 pixels
+// at any scale): below it the 128x64 split-K family runs (launch_gemm), in-place residual GEMMs hand their K slices to
+// resid_ln_kernel (gemm_resid_ln), and the specialised throughput epilogues / the paired launch are not used (gemm_f32,
+// gemm_qkv_pair).  Threshold measured (profiles/r03_tile_table.txt): with fewer than 192 tiles of 192x128 the 128x64 family is
+// 15-40 % faster (162 tiles: 36 vs 45 us; 136: 113 vs 144 us; 128: 113 vs 133 us), from 216 tiles on it is slower.
+static inline bool small_grid(int64_t M, int N) {
+    if (g_small_grid_mode == 1) return false;
+    const int64_t t = ((M + 191) / 192) * (int64_t)((N + 127) / 128);
+    if (g_small_grid_mode == 2) return M <= 2560 || t < 512;
+    return M <= 640 || t < 192;
+}
+
+// Tile-family choice = a quantisation-aware cost model calibrated on profiles/r03_tile_table.txt (tools/tile_table.py: every
+// GEMM / convolution shape of the forward at B in {1,2,4,8} x {224x224, 384x512}, in-model HIP-event durations under every forced
+// family; tests/test_tile_table.py replays the table through this function).  Every family saturates at the same 300-400
+// algorithmic TFLOP/s (the chip is power-bound on this instruction mix), so a launch costs
+//     rounds x tile area / rate,   rounds = ceil(tiles / 256 CUs),
+// `rate` = the family's measured advantage on that class of GEMM at a full grid, x a penalty when the last round is < 90 %
+// full (one-workgroup-per-CU families lose more there than 192x128, whose second resident workgroup evens the CUs out):
+//   5: 192x128, 8 waves, two workgroups per CU (one block's HBM-bound epilogue hides under the other's main loop): rate 1;
+//   3: 192x256, 12 waves, one workgroup per CU, 30 % less L2->LDS traffic per FLOP: +2 % mlp.fc1 (GELU), +4 % the long-K
+//      in-place-residual GEMMs (mlp.fc2), +6 % the Cout = 256 convolutions with K >= 1728;
+//   2: 256x256, 16 waves: +5 % mlp.fc1, +10 % those convolutions, -10 % the in-place-residual epilogue;
+//   8: halo-tiled 3x3 convolution (conv3h.h; 8 x 32-pixel tiles of one image): +12 % at Cout = 256, -3 % at Cout = 128
+//      (head.0), equal with the fused head epilogue;
+//   6: small-grid family (predicate above);  1: 128x128 register-staged kernel: N not a multiple of 128;
+//   7 (paired 192x128 launch) is chosen by gemm_qkv_pair.
+struct FamilyQuery { int amode, epi; int64_t M; int N, K; int split, cstride, Ho, Wo; };
+static int pick_family(const FamilyQuery& q) {
+    const bool sg = small_grid(q.M, q.N) && q.N % 64 == 0;
+    if (q.N % 128 != 0) return sg ? 6 : 1;
+    if (sg) return 6;
+    auto cost = [](int64_t tiles, int area, double rate, double pen) {
+        const int64_t rounds = (tiles + 255) / 256;
+        const double fill = (double)tiles / (double)(rounds * 256);
+        return (double)rounds * area / (rate * (fill < 0.9 ? pen : 1.0));
+    };
+    auto tiles = [&](int bm, int bn) { return ((q.M + bm - 1) / bm) * (int64_t)((q.N + bn - 1) / bn); };
+    int best = 5;
+    double cbest = cost(tiles(192, 128), 192 * 128, 1.0, 0.96);
+    auto consider = [&](int fam, double c) { if (c <= cbest) { cbest = c; best = fam; } };      // ties: the later (larger) family
+    if (q.split && q.N % 256 == 0 && q.epi != EPI_QKV) {
+        double r3 = 0, r2 = 0;
+        if (q.amode == A_DENSE && q.epi == EPI_GELU) { r3 = 1.02; r2 = 1.05; }
+        else if (q.amode == A_DENSE && q.epi == EPI_F32R && q.K >= 2048) { r3 = 1.04; r2 = 0.9; }
+        else if (q.amode == A_CONV3 && q.N == 256 && q.K >= 1728) { r3 = 1.06; r2 = 1.10; }
+        if (r3 > 0) { consider(3, cost(tiles(192, 256), 192 * 256, r3, 0.93)); consider(2, cost(tiles(256, 256), 256 * 256, r2, 0.93)); }
+    }
+    if (q.amode == A_CONV3 && (q.epi == EPI_F16 || q.epi == EPI_HEAD) && q.cstride == 1 && (q.N == 128 || q.N == 256) &&
+        q.Wo >= 32 && q.M >= 16384 && q.Ho > 0) {
+        const int64_t imgs = q.M / ((int64_t)q.Ho * q.Wo);
+        const int64_t t8 = imgs * ((q.Ho + 7) / 8) * ((q.Wo + 31) / 32);
+        consider(8, cost(t8, 256 * q.N, q.epi == EPI_HEAD ? 1.0 : (q.N == 128 ? 0.97 : 1.12), 0.96));
+    }
+    return best;
+}
+extern "C" int sta_debug_pick_family(int amode, int epi, long long M, int N, int K, int split, int cstride, int Ho, int Wo) {
+    FamilyQuery q{amode, epi, M, N, K, split, cstride, Ho, Wo};
+    return pick_family(q);
+}
 
 template <int AMODE, int EPI>
 static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
@@ -536,27 +594,15 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
     }
     const int M_all = p.M;
     p.M -= p.m_tail;
-    // Tile family selection.  Measured in the model, per shape, with HIP events around every launch (tools/gemm_tiles.py
-    // shapes; profiles/r02_gemm_shapes.txt): every family saturates at the same 300-400 algorithmic TFLOP/s - the chip is
-    // power-bound on this instruction mix - so the choice is about tile quantisation and epilogue overlap:
-    //   5: 192x128, 8 waves, two workgroups per CU (one block's HBM-bound epilogue hides under the other's main loop):
-    //      best or equal on almost every shape of the path -> the default;
-    //   3: 192x256, 12 waves (wave tile 64x64), one workgroup per CU, 30 % less L2->LDS traffic per FLOP: wins the long-K
-    //      in-place-residual GEMMs (mlp.fc2: -4 %) and the mid-resolution convolutions (-9 %);
-    //   2: 256x256, 16 waves (wave tile 64x64): wins mlp.fc1 of the encoder (768 tiles = exactly 3 rounds of 256 CUs, -4 %)
-    //      and the 4x-resolution refinement convolutions (-9 %);
-    //   1: 128x128 register-staged kernel: shapes whose N is not a multiple of 128;  6: small-grid family, below.
-    int variant = p.N % 128 == 0 ? 5 : 1;
-    if (split && p.N % 256 == 0 && EPI != EPI_QKV) {
-        if (AMODE == A_DENSE && EPI == EPI_F32R && p.K >= 2048) variant = 3;
-        if (AMODE == A_DENSE && EPI == EPI_GELU && p.M % 256 == 0 && ((int64_t)(p.M / 256) * (p.N / 256)) % 256 == 0) variant = 2;
-        if (AMODE == A_CONV3 && p.N == 256 && p.K >= 864) variant = p.M >= 131072 ? 2 : (p.M >= 32768 ? 3 : 5);
-    }
+    // Tile family (pick_family above: cost model calibrated on the measured table); a forced family never displaces the
+    // small-grid one, whose split-K plumbing the callers rely on
+    const FamilyQuery fq{AMODE, EPI, p.M, p.N, p.K, split ? 1 : 0, p.cstride, p.Ho, p.Wo};
+    int variant = pick_family(fq);
+    if (h->gemm_variant == 9 && variant == 8) { FamilyQuery f2 = fq; f2.Wo = 0; variant = pick_family(f2); }     // A/B: no halo kernel
     // Small-M (SLAM-scale: 224x224, batch 1 -> M = 196..394 rows): 128x64 tiles, 3-stage DMA ring, and for
     // the in-place residual GEMMs (proj / fc2: out += A W^T + b) split-K with fp32 atomics so that ~256
     // workgroups stream the weights once instead of 16-64 workgroups looping over all of K.
-    if (small_grid(p.M, p.N) && p.N % 64 == 0) {
-        variant = 6;
+    if (variant == 6) {
         const int tiles_r = ((p.M + 127) / 128) * (p.N / 64);
         const int tiles = h->deterministic ? (1 << 30) : tiles_r;    // deterministic: no ATOMIC split-K (the slab forms below have a fixed order)
         if (AMODE == A_DENSE && EPI == EPI_F32 && p.resid == p.C32 && p.rows_in == 0 && p.slab) {
@@ -612,9 +658,8 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
         variant = (p.N % 256 == 0 && EPI != EPI_QKV) ? h->gemm_variant : 5;
     if (h->gemm_variant == 4 && variant != 6 && p.N % 128 == 0) variant = 5;
     if (h->gemm_variant == 1) variant = 1;
-    // 8: halo-tiled 3x3 convolution (conv3h.h): stride 1, Cout 128 / 256, at throughput scale (or forced: tests)
-    if (AMODE == A_CONV3 && (EPI == EPI_F16 || EPI == EPI_HEAD) && p.cstride == 1 && (p.N == 128 || p.N == 256) &&
-        ((h->gemm_variant == 0 && p.M >= 32768 && p.Wo >= 32 && variant != 6) || h->gemm_variant == 8)) variant = 8;
+    // 8 forced (tests): the halo-tiled 3x3 convolution wherever it is legal (stride 1, Cout 128 / 256)
+    if (AMODE == A_CONV3 && (EPI == EPI_F16 || EPI == EPI_HEAD) && p.cstride == 1 && (p.N == 128 || p.N == 256) && h->gemm_variant == 8) variant = 8;
     if (variant != 6) { p.ksplit = 1; h->slab_ks = 0; }
     if (h->slab_ks == 0) p.slab = nullptr;
     p.M = M_all;
@@ -880,7 +925,7 @@ static int conv3(sta_handle* h, const Planes& in, int nimg, int Hi, int Wi, int 
 // head.2 (3x3 conv 128 -> 128) + ReLU + head.4 (1x1 conv 128 -> 4) + point-map / confidence activations as ONE kernel
 // (EPI_HEAD): true when it was launched; false = the caller runs conv3 + head_final_kernel (small grids, forced tile families).
 static bool conv3_head_ok(sta_handle* h, const Lin& W, int64_t M) {
-    return W.N == 128 && ((auto_family(h) && (M + 191) / 192 >= 128) || h->gemm_variant == 8);
+    return W.N == 128 && ((auto_family(h) && !small_grid(M, W.N)) || h->gemm_variant == 8);
 }
 static int conv3_head(sta_handle* h, const Planes& in, int nimg, int Hi, int Wi, int Cin, const Lin& W, const F32Lin& W4,
                       float* ptsA, float* confA, int nA, float* ptsB, float* confB, hipStream_t st) {
