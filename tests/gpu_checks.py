@@ -169,7 +169,7 @@ def check_qkv_rope_decoder_rows(precision, S=2, hp=3, wp=4, K=128, Cdim=128, see
 
 def check_attention_pose(precision, S=2, heads=2, n=196, kv_shift=0, sharp=1.0, seed=13):
     """Decoder form of the attention kernel: n patch tokens + the pose token (last): as a key it is folded into the initial
-    softmax state, as a query it is served by the pose blocks."""
+    softmax state; as a query it rides in the last query block's spare rows (n % 128 != 0) or is served by the pose blocks."""
     m, lib, h = kernel_handle(precision)
     g = torch.Generator().manual_seed(seed)
     nt = n + 1

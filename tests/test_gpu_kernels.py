@@ -61,7 +61,8 @@ def test_qkv_rope_decoder_rows(G, prec, kw):
 
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("kw", [dict(), dict(kv_shift=1), dict(n=768, S=2, heads=1, sharp=3.0), dict(n=12, sharp=6.0), dict(n=64),
-                                dict(n=129, sharp=10.0, S=3, heads=1, kv_shift=2)])
+                                dict(n=129, sharp=10.0, S=3, heads=1, kv_shift=2), dict(n=128, S=3), dict(n=127, sharp=3.0), dict(n=256, S=1, heads=3),
+                                dict(n=255, S=1, heads=1)])
 def test_attention_pose_token(G, prec, kw):
     r = G.check_attention_pose(prec, **kw)
     assert r["nan"] == 0, r

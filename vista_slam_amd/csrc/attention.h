@@ -33,7 +33,8 @@ struct AttnParams {
     float scale_log2e;       // head_dim^-0.5 * log2(e)
     int pose;                // decoder: token index nk (== nq) of Q / K / V^T is the pose token.  As a KEY it is folded into the
                              // initial online-softmax state of every query (no 13th key tile for one key); as a QUERY it is served by
-                             // the pose blocks (one wave per (sequence, head), plain fp32 dot products); its output row is S*nq + s
+                             // the pose blocks (pose == 1: one wave per (sequence, head), plain fp32 dot products; nq % 128 == 0) or
+                             // rides as query nq in the last query block's spare rows (pose == 2); its output row is S*nq + s
 };
 
 #define ATT_KV 64
@@ -68,7 +69,8 @@ __device__ __forceinline__ void attn_pose_query(const AttnParams& p, char* smem)
     }
     const int nkeys = p.nk + 1;
     float mx = -INFINITY;
-    for (int j = lane; j < p.npad; j += 64) {
+#pragma unroll 2
+    for (int j = lane; j < p.npad; j += 64) {       // latency-bound: two keys' loads (32 x 16 B) in flight per lane
         float t = -INFINITY;
         if (j < nkeys) {
             float acc = 0.f;
@@ -96,14 +98,20 @@ __device__ __forceinline__ void attn_pose_query(const AttnParams& p, char* smem)
     __syncthreads();
     const f16* vh = p.Vt_hi + voff + (size_t)lane * p.npad;
     const f16* vl = SPLIT ? p.Vt_lo + voff + (size_t)lane * p.npad : nullptr;
+    // latency-bound (one wave walks npad keys): 8 chunks (64 keys: npad is a multiple of 64) of loads in flight per batch
     float o = 0.f;
-    for (int c = 0; c < p.npad; c += 8) {                          // V^T columns >= nkeys are zero (memset) and their p is 0
-        H8 a, b; a.u = ldg16(vh + c);
-        if (SPLIT) b.u = ldg16(vl + c);
-        const float4 p0 = *reinterpret_cast<const float4*>(pl + c), p1 = *reinterpret_cast<const float4*>(pl + c + 4);
-        const float pe[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+    for (int c0 = 0; c0 < p.npad; c0 += 64) {                      // V^T columns >= nkeys are zero (memset) and their p is 0
+        H8 a[8], b[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o = __builtin_fmaf(pe[e], (float)a.e[e] + (SPLIT ? (float)b.e[e] : 0.f), o);
+        for (int u = 0; u < 8; ++u) { a[u].u = ldg16(vh + c0 + u * 8); if (SPLIT) b[u].u = ldg16(vl + c0 + u * 8); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u * 8;
+            const float4 p0 = *reinterpret_cast<const float4*>(pl + c), p1 = *reinterpret_cast<const float4*>(pl + c + 4);
+            const float pe[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o = __builtin_fmaf(pe[e], (float)a[u].e[e] + (SPLIT ? (float)b[u].e[e] : 0.f), o);
+        }
     }
     if (!live) return;
     o /= sum;
@@ -119,14 +127,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     constexpr int NPL = SPLIT ? 2 : 1;
     constexpr int STAGE = 2 * NPL * ATT_TILE_BYTES;   // K planes then V^T planes
     // pose blocks first in the grid (short: they end while the first round of query blocks is still running)
-    const int npose_blocks = p.pose ? (p.S * p.heads + 3) / 4 : 0;
+    const int npose_blocks = p.pose == 1 ? (p.S * p.heads + 3) / 4 : 0;
+    const int nqe = p.nq + (p.pose == 2 ? 1 : 0);       // pose == 2: the pose query rides in the last query block's spare rows
     if ((int)blockIdx.x < npose_blocks) { attn_pose_query<SPLIT>(p, smem); return; }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhi = lane >> 5;
     // 1-D grid, XCD-aware: block b runs on XCD b%8 (observed dispatch); give each XCD a contiguous range
     // of logical ids so the query blocks of one (sequence, head) share that XCD's L2 copy of K/V.
-    const int nqb = (p.nq + 127) / 128;
+    const int nqb = (nqe + 127) / 128;
     const int nwg = nqb * p.heads * p.S;
     int logical;
     {
@@ -145,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     // ---- Q fragments (B operand: col = query, 8 consecutive d per lane-half per k-step)
     half8 qf_hi[4], qf_lo[4];
     {
-        int qrow = q0 + l31; if (qrow > p.nq - 1) qrow = p.nq - 1;
+        int qrow = q0 + l31; if (qrow > nqe - 1) qrow = nqe - 1;
         const f16* qp = p.Q_hi + qoff + (size_t)qrow * 64 + lhi * 8;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { H8 t; t.u = ldg16(qp + kk * 16); qf_hi[kk] = t.h; }
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;       // running max in scaled (log2) units
-    const bool wave_active = q0 < p.nq;         // decoder: 769 = 6 x 128 + 1 queries -> the last block has one live wave
+    const bool wave_active = q0 < nqe;         // decoder: 769 = 6 x 128 + 1 queries -> the last block has one live wave
 
     // ---- the pose token as a key (index nk): initial online-softmax state m = s_p, l = 1, O = v_p in fp32
     if (p.pose && wave_active) {
@@ -366,9 +375,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     const int q = q0 + l31;
-    if (q < p.nq) {
+    if (q < nqe) {
         RangeAcc ra;        // never flushed (dead code): a convex combination of V rows stays inside V's range
-        const int64_t orow = (int64_t)s * p.nq + q, orows = (int64_t)p.S * p.nq + (p.pose ? p.S : 0);
+        const int64_t orow = q < p.nq ? (int64_t)s * p.nq + q : (int64_t)p.S * p.nq + s, orows = (int64_t)p.S * p.nq + (p.pose ? p.S : 0);
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
