@@ -239,6 +239,41 @@ def test_full_size_batch_rows_are_independent(full_b8):
         assert rel_l2(m1["relative_pose"].cpu().numpy(), main["relative_pose"][i:i + 1].cpu().numpy()) < ctol(DEFAULT)
 
 
+@pytest.mark.parametrize("cfg", [(2, 224, 224), (4, 224, 224), (8, 224, 224), (2, 384, 512), (4, 384, 512)])
+def test_mid_size_batches_match_the_golden_pair(G, cfg):
+    """Batch sizes between the SLAM regime and the benchmark (where the tile cost model switches families: small-grid split-K
+    below 192 tiles, 192x128 / 192x256 / 256x256 above, profiles/r03_tile_table.txt): pair 0 of every batch is the committed
+    reference golden's pair (full_224_b1 / full_384x512_b1 use images 0 and 1 of the same procedural set), every other pair
+    must equal the same pair run alone."""
+    import numpy as np
+    import torch
+    from helpers import load_golden, rel_l2
+    from vista_slam_amd import weights as W
+    B, H, Wd = cfg
+    G.drop_models()
+    m = G.model("full", 1.0, DEFAULT)
+    G.set_variant(m, 0)
+    g, meta = load_golden("full_224_b1" if H == 224 else "full_384x512_b1")
+    assert int(meta["H"]) == H and int(meta["W"]) == Wd and int(meta["seed"]) == 43
+    im = W.synth_images(2, H, Wd, seed=43, tag=0)
+    extra = W.synth_images(2 * B, H, Wd, seed=43, tag=5)
+    a = torch.from_numpy(np.concatenate([im[:1], extra[:B - 1]])).cuda()
+    b = torch.from_numpy(np.concatenate([im[1:], extra[B:2 * B - 1]])).cuda()
+    main, supp = m.forward_pair(a, b)
+    torch.cuda.synchronize()
+    sub = int(meta["sub"])
+    assert rel_l2(main["pts3d_pred"][:1].cpu().numpy()[:, ::sub, ::sub], g["main_pts3d"]) < TOL
+    assert rel_l2(supp["conf"][:1].cpu().numpy()[:, ::sub, ::sub], g["supp_conf"]) < TOL
+    assert rel_l2(main["relative_pose"][:1].cpu().numpy(), g["main_pose"]) < TOL
+    assert rel_l2(supp["relative_pose"][:1].cpu().numpy(), g["supp_pose"]) < TOL
+    i = B - 1
+    m1, s1 = m.forward_pair(a[i:i + 1], b[i:i + 1])
+    torch.cuda.synchronize()
+    assert rel_l2(m1["pts3d_pred"].cpu().numpy(), main["pts3d_pred"][i:i + 1].cpu().numpy()) < ctol(DEFAULT)
+    assert rel_l2(s1["conf"].cpu().numpy(), supp["conf"][i:i + 1].cpu().numpy()) < ctol(DEFAULT)
+    assert rel_l2(s1["relative_pose"].cpu().numpy(), supp["relative_pose"][i:i + 1].cpu().numpy()) < ctol(DEFAULT)
+
+
 def test_full_size_view_swap_symmetry(full_b8):
     """The decoder weights are shared between the two sides (sta_model.py:231-235), so swapping the views
     swaps the outputs: forward(b, a).main == forward(a, b).support."""
