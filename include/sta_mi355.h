@@ -57,7 +57,8 @@ enum {
      *  MFMA.  +10 % but above the 1e-3 bar on five of the ten stress goldens; retired in round 3, the value is rejected.) */
     STA_PREC_F16X3H = 5  /* DEFAULT.  f16x3 in the transformer (encoder, decoder, attention, embeddings, pose head); the DPT
                           * head's convolutions in the f16mx arithmetic: fp16 main product + ONE block-scaled fp8 MFMA that
-                          * carries both correction products (GEMM error ~1e-5, 2 instead of 3 MFMA units).  The head is
+                          * carries both correction products (activation bytes e5m2, weight bytes e4m3: GEMM error ~2e-5, 2 instead of 3 MFMA
+                          * units).  The head is
                           * feed-forward and is not followed by any attention layer, so that error is not amplified */
 };
 

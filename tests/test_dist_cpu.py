@@ -116,3 +116,23 @@ def test_two_rank_keyframe_edge_scatter(num_edges):
     ret = mp.Manager().dict()
     mp.spawn(_edge_worker, args=(world, _free_port(), num_edges, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def test_pack_edges_portrait_views_round_trip_and_reject_mismatched_dims():
+    """Portrait frames: regress_views returns TRANSPOSED views of [2, H_img, W_img] storage (slam_scheduler.py, like the
+    reference's utils/misc.py:60-61,81).  pack_edges / gather_edges take the dims of the views; the image dims are refused
+    instead of silently scrambling the maps."""
+    Hi, Wi = 12, 8                                        # portrait image: H_img > W_img
+
+    class PEdge(_Edge):
+        def __init__(self, e):
+            super().__init__(e, True)
+            g = torch.Generator().manual_seed(7 + e)
+            self.depths = torch.rand(2, Hi, Wi, generator=g).swapaxes(1, 2)     # [2, W_img, H_img] view, non-contiguous
+            self.confs = torch.rand(2, Hi, Wi, generator=g).swapaxes(1, 2)
+    edges = [PEdge(0), PEdge(1)]
+    with pytest.raises(ValueError):
+        P.pack_edges(edges, Hi, Wi, device="cpu")
+    out = P.gather_edges(P.pack_edges(edges, Wi, Hi, device="cpu"), 2, Wi, Hi)
+    for e, d in zip(edges, out):
+        assert torch.equal(d["depths"], e.depths) and torch.equal(d["confs"], e.confs)

@@ -354,8 +354,8 @@ def test_u8_hwc_input_matches_normalised_fp32(G, prec):
     fa, _ = m._encode_image(f32, None, normalize=False)
     fb, _ = m.encode_u8hwc(u8)
     torch.cuda.synchronize()
-    # the gathered patches are bit-identical; downstream the small-M GEMMs use split-K with fp32 atomics
-    # (summation order varies run to run), so features agree to fp32 rounding, not bitwise
+    # the gathered patches are bit-identical and the default mode is bit-reproducible (slab split-K, no atomics, since round 2);
+    # the bound stays a tolerance so that the test does not pin the two entry points to the same tile path
     from helpers import rel_l2
     assert rel_l2(fb.cpu().numpy(), fa.cpu().numpy()) < 2e-6
     m1, s1 = m.forward_pair(f32[:2], f32[2:])
@@ -760,3 +760,16 @@ def test_deterministic_mode_is_bit_reproducible_at_slam_scale(G):
     finally:
         m.set_deterministic(False)
     G.drop_models()
+
+
+def test_decode_stereo_unequal_token_counts_is_refused(G):
+    """`_decode_stereo` with N1 != N2 (two views of different resolution): allowed by the reference's module code
+    (sta_blocks.py:193-205), never produced by slam.py / forward (sta_model.py:257-262); the batched decoder here needs equal
+    token grids and says so instead of padding silently."""
+    import torch
+    m = G.model("tiny", 1.0, DEFAULT)
+    E = m.cfg.enc_embed_dim
+    f1 = torch.zeros(1, 12, E, device="cuda"); f2 = torch.zeros(1, 8, E, device="cuda")
+    p1 = torch.zeros(1, 12, 2, dtype=torch.int64, device="cuda"); p2 = torch.zeros(1, 8, 2, dtype=torch.int64, device="cuda")
+    with pytest.raises(AssertionError, match="same token grid"):
+        m._decode_stereo(f1, f2, p1, p2)

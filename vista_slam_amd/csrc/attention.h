@@ -43,22 +43,23 @@ struct AttnParams {
 template <bool SPLIT>
 constexpr int attn_smem_bytes() { return 2 * (SPLIT ? 4 : 2) * ATT_TILE_BYTES; }
 
-// The pose-token query of one (sequence, head) per wave: 1 x (nk + 1) scores, softmax and 1 x 64 output as fp32 dot products
-// (an MFMA tile would carry 31 dead queries through every key tile).  Phase 1: lane = key (K rows are 128 contiguous bytes),
-// phase 2: wave-wide max / sum, probabilities parked in LDS, phase 3: lane = d (V^T rows are contiguous along the keys).
+// The pose-token query of one (sequence, head) per workgroup: 1 x (nk + 1) scores, softmax and 1 x 64 output as fp32 dot products
+// (an MFMA tile would carry 31 dead queries through every key tile).  Phase 1: thread = key (K rows are 128 contiguous bytes),
+// phase 2: block-wide max / sum, probabilities parked in LDS, phase 3: lane = d (V^T rows are contiguous along the keys).
 template <bool SPLIT>
 __device__ __forceinline__ void attn_pose_query(const AttnParams& p, char* smem) {
+    // One workgroup per (sequence, head); its four waves split the keys (a single wave walking all 769 keys was a 58-us
+    // dependent chain - longer than the whole kernel at B <= 4).  Phase 1: thread = key; phase 2: block-wide max / sum;
+    // phase 3: lane = d, wave w sums over its quarter of the keys; wave partials meet in LDS.
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nsh = p.S * p.heads;
-    int sh = blockIdx.x * (blockDim.x >> 6) + wave;
-    const bool live = sh < nsh;
-    if (!live) sh = nsh - 1;                                  // duplicate work, no store: every wave reaches the barriers
+    const int sh = blockIdx.x;
     const int s = sh / p.heads, h = sh - s * p.heads;
     const int skv = (s + p.kv_shift) % p.S;
     const size_t qoff = ((size_t)(s * p.heads + h) * p.npad + p.nq) * 64;
     const size_t koff = (size_t)(skv * p.heads + h) * p.npad * 64;
     const size_t voff = (size_t)(skv * p.heads + h) * 64 * p.npad;
-    float* pl = reinterpret_cast<float*>(smem) + (size_t)wave * p.npad;
+    float* pl = reinterpret_cast<float*>(smem);               // [npad] scores, then probabilities
+    float* red = pl + p.npad;                                 // [4] wave maxima, [4] wave sums, [4][64] partial outputs
     float q[64];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -69,8 +70,7 @@ __device__ __forceinline__ void attn_pose_query(const AttnParams& p, char* smem)
     }
     const int nkeys = p.nk + 1;
     float mx = -INFINITY;
-#pragma unroll 2
-    for (int j = lane; j < p.npad; j += 64) {       // latency-bound: two keys' loads (32 x 16 B) in flight per lane
+    for (int j = tid; j < p.npad; j += 256) {
         float t = -INFINITY;
         if (j < nkeys) {
             float acc = 0.f;
@@ -88,24 +88,29 @@ __device__ __forceinline__ void attn_pose_query(const AttnParams& p, char* smem)
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float sum = 0.f;
-    for (int j = lane; j < p.npad; j += 64) {
+    for (int j = tid; j < p.npad; j += 256) {
         const float e = __builtin_amdgcn_exp2f(pl[j] - mx);       // exp2(-inf) = 0 for the padding
         pl[j] = e;
         sum += e;
     }
     sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
+    // wave w: keys [w * npad / 4, (w + 1) * npad / 4) (npad % 64 == 0: whole 16-key groups), two 8-key chunks in flight
     const f16* vh = p.Vt_hi + voff + (size_t)lane * p.npad;
     const f16* vl = SPLIT ? p.Vt_lo + voff + (size_t)lane * p.npad : nullptr;
-    // latency-bound (one wave walks npad keys): 8 chunks (64 keys: npad is a multiple of 64) of loads in flight per batch
+    const int k0 = wave * (p.npad >> 2), k1 = k0 + (p.npad >> 2);
     float o = 0.f;
-    for (int c0 = 0; c0 < p.npad; c0 += 64) {                      // V^T columns >= nkeys are zero (memset) and their p is 0
-        H8 a[8], b[8];
+    for (int c0 = k0; c0 < k1; c0 += 16) {                         // V^T columns >= nkeys are zero (memset) and their p is 0
+        H8 a[2], b[2];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { a[u].u = ldg16(vh + c0 + u * 8); if (SPLIT) b[u].u = ldg16(vl + c0 + u * 8); }
+        for (int u = 0; u < 2; ++u) { a[u].u = ldg16(vh + c0 + u * 8); if (SPLIT) b[u].u = ldg16(vl + c0 + u * 8); }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 2; ++u) {
             const int c = c0 + u * 8;
             const float4 p0 = *reinterpret_cast<const float4*>(pl + c), p1 = *reinterpret_cast<const float4*>(pl + c + 4);
             const float pe[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
@@ -113,8 +118,11 @@ __device__ __forceinline__ void attn_pose_query(const AttnParams& p, char* smem)
             for (int e = 0; e < 8; ++e) o = __builtin_fmaf(pe[e], (float)a[u].e[e] + (SPLIT ? (float)b[u].e[e] : 0.f), o);
         }
     }
-    if (!live) return;
-    o /= sum;
+    red[8 + wave * 64 + lane] = o;
+    __syncthreads();
+    if (wave != 0) return;
+    o = (red[8 + lane] + red[8 + 64 + lane]) + (red[8 + 128 + lane] + red[8 + 192 + lane]);
+    o /= (red[4] + red[5]) + (red[6] + red[7]);
     const int64_t orow = (int64_t)p.S * p.nq + s, orows = (int64_t)p.S * p.nq + p.S;
     const size_t oo = blk_off<SPLIT>(orow, h * 64 + lane, orows);
     if (SPLIT) { f16 hh, ll; split_f16(o, hh, ll); p.O_hi[oo] = hh; p.O_hi[oo + 32] = ll; }
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     constexpr int NPL = SPLIT ? 2 : 1;
     constexpr int STAGE = 2 * NPL * ATT_TILE_BYTES;   // K planes then V^T planes
     // pose blocks first in the grid (short: they end while the first round of query blocks is still running)
-    const int npose_blocks = p.pose == 1 ? (p.S * p.heads + 3) / 4 : 0;
+    const int npose_blocks = p.pose == 1 ? p.S * p.heads : 0;
     const int nqe = p.nq + (p.pose == 2 ? 1 : 0);       // pose == 2: the pose query rides in the last query block's spare rows
     if ((int)blockIdx.x < npose_blocks) { attn_pose_query<SPLIT>(p, smem); return; }
     const int tid = threadIdx.x, lane = tid & 63;

@@ -106,7 +106,6 @@ struct sta_handle {
     f16* zero_page = nullptr;
     float* skbuf = nullptr;   // fp32 partial sums of split-K GEMMs with the plane epilogue (SKBUF_SLOTS x SKBUF_ELEMS floats)
     float* slab = nullptr;    // slab split-K of the small-M in-place residual GEMMs (GemmParams::slab), same slots and size as skbuf
-    int slab_ks = 0;          // set by launch_gemm: K slices the last slab GEMM wrote (0: it did not take the slab path)
     int opt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // experiment switches (sta_debug_set_option; 0 = product behaviour)
     int tail_hint = 0;      // decode_impl: the last tail_hint rows of every dense GEMM are pose-token rows (GemmParams::m_tail)
     int gemm_variant = 0;   // tests / tools: 0 auto, 1..4 forced GEMM families, 8 = conv3h wherever legal, 9 = auto WITHOUT conv3h (A/B)
@@ -574,9 +573,12 @@ extern "C" int sta_debug_pick_family(int amode, int epi, long long M, int N, int
     return pick_family(q);
 }
 
+// slab_ks_out: K slices a slab GEMM wrote (0: it did not take the slab path) - the caller's finisher sums exactly those
 template <int AMODE, int EPI>
-static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
+static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st, int* slab_ks_out = nullptr) {
     GemmParams p = p_in;
+    int slab_ks = 0;
+    if (slab_ks_out) *slab_ks_out = 0;
     p.zero_page = h->zero_page;
     REQUIRE(p.K % GEMM_BK == 0, "GEMM K=%d must be a multiple of %d", p.K, GEMM_BK);
     REQUIRE(p.M > 0 && p.N > 0, "empty GEMM");
@@ -599,9 +601,11 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
     const FamilyQuery fq{AMODE, EPI, p.M, p.N, p.K, split ? 1 : 0, p.cstride, p.Ho, p.Wo};
     int variant = pick_family(fq);
     if (h->gemm_variant == 9 && variant == 8) { FamilyQuery f2 = fq; f2.Wo = 0; variant = pick_family(f2); }     // A/B: no halo kernel
-    // Small-M (SLAM-scale: 224x224, batch 1 -> M = 196..394 rows): 128x64 tiles, 3-stage DMA ring, and for
-    // the in-place residual GEMMs (proj / fc2: out += A W^T + b) split-K with fp32 atomics so that ~256
-    // workgroups stream the weights once instead of 16-64 workgroups looping over all of K.
+    // Small grids (SLAM scale: 224x224, batch 1..8 -> M = 196..3200 rows; the coarse DPT levels at any scale): 128x64 tiles,
+    // 3-stage DMA ring, and split-K so that ~256 workgroups stream the weights once instead of 16-64 workgroups looping over
+    // all of K.  The K slices go to fp32 SLABS that the next kernel sums (resid_ln_kernel / qkv_finish_kernel /
+    // splitk_finish_kernel: fixed order, bit-reproducible) - the product path.  Only an in-place residual GEMM whose caller
+    // passed no slab (forced tile families, N > 1024) still adds its slices with fp32 atomics, and not in deterministic mode.
     if (variant == 6) {
         const int tiles_r = ((p.M + 127) / 128) * (p.N / 64);
         const int tiles = h->deterministic ? (1 << 30) : tiles_r;    // deterministic: no ATOMIC split-K (the slab forms below have a fixed order)
@@ -615,7 +619,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
             const int max_ks = p.K / 128;                 // keep >= 4 K tiles per slice
             if (ks > max_ks) ks = max_ks;
             while (ks > 1 && (int64_t)ks * p.M * p.N > SKBUF_ELEMS) --ks;
-            if (ks > 1) { p.ksplit = ks; h->slab_ks = ks; } else p.slab = nullptr;
+            if (ks > 1) { p.ksplit = ks; slab_ks = ks; } else p.slab = nullptr;
         } else if (AMODE == A_DENSE && EPI == EPI_F32 && p.resid == p.C32 && p.rows_in == 0 && tiles < 256) {
             int ks = (256 + tiles - 1) / tiles;
             const int max_ks = p.K / 128;                 // keep >= 4 K tiles per slice
@@ -660,8 +664,9 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st) {
     if (h->gemm_variant == 1) variant = 1;
     // 8 forced (tests): the halo-tiled 3x3 convolution wherever it is legal (stride 1, Cout 128 / 256)
     if (AMODE == A_CONV3 && (EPI == EPI_F16 || EPI == EPI_HEAD) && p.cstride == 1 && (p.N == 128 || p.N == 256) && h->gemm_variant == 8) variant = 8;
-    if (variant != 6) { p.ksplit = 1; h->slab_ks = 0; }
-    if (h->slab_ks == 0) p.slab = nullptr;
+    if (variant != 6) { p.ksplit = 1; slab_ks = 0; }
+    if (slab_ks == 0) p.slab = nullptr;
+    if (slab_ks_out) *slab_ks_out = slab_ks;
     p.M = M_all;
     {
         const int bm_v = variant == 2 ? 256 : ((variant == 3 || variant == 5) ? 192 : 0);
@@ -816,16 +821,14 @@ static int gemm_resid_ln(sta_handle* h, const Planes& A, const Lin& W, int M, fl
     static const LNp no_ln = {nullptr, nullptr};
     static const Planes no_planes;
     const bool small = small_grid(M, W.N) && W.N % 64 == 0 && W.N <= 1024 && auto_family(h) && ld == W.N;
-    h->slab_ks = 0;
     if (small) {
         int slot = 0;
         for (int q = 0; q < 4; ++q) if (h->aux[q] && st == h->aux[q]) slot = q + 1;
         GemmParams p = gp_dense(A, W.K, W, M, use_mx(h, W));
         p.C32 = x; p.ldc = ld; p.resid = x; p.ldr = ld; p.rows_in = 0; p.rows_out = 0; p.row_off = 0;
         p.slab = h->slab + (size_t)slot * SKBUF_ELEMS;
-        CHK((launch_gemm<A_DENSE, EPI_F32>(h, p, st)));
-        const int ks = h->slab_ks;
-        h->slab_ks = 0;
+        int ks = 0;
+        CHK((launch_gemm<A_DENSE, EPI_F32>(h, p, st, &ks)));
         if (ks > 1) return run_ln(h, x, M, W.N, la ? *la : no_ln, oa ? *oa : no_planes, lb, ob, nullptr, st, p.slab, ks);
     } else {
         CHK(gemm_f32(h, A, W, M, x, ld, x, st));
@@ -982,8 +985,9 @@ static int run_attn(sta_handle* h, const QKVOut& qkv, const Planes& out, int ldo
     p.O_hi = out.hi; p.O_lo = out.lo; p.ldo = ldo;
     p.S = S; p.heads = heads; p.nq = nq; p.nk = nk; p.npad = qkv.npad; p.kv_shift = kv_shift;
     p.scale_log2e = 0.125f * 1.44269504088896340736f;
-    const int npose = p.pose == 1 ? (S * heads + 3) / 4 : 0;
-    REQUIRE(!pose || (int64_t)4 * qkv.npad * 4 <= attn_smem_bytes<false>(), "internal: pose-query scratch exceeds the LDS allocation");
+    const int npose = p.pose == 1 ? S * heads : 0;
+    REQUIRE(!pose || (int64_t)(qkv.npad + 8 + 256) * 4 <= attn_smem_bytes<false>(), "internal: pose-query scratch exceeds the LDS allocation");
+    REQUIRE(!pose || qkv.npad % 64 == 0, "internal: pose-query path needs npad % 64 == 0");
     dim3 grid((unsigned)(((nq + (p.pose == 2 ? 1 : 0) + 127) / 128) * heads * S + npose));
     if (h->prec != STA_PREC_F16) {
         static unsigned attr_done = 0;      // one bit per device

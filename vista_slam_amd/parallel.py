@@ -90,9 +90,15 @@ def edge_elems(H: int, W: int) -> int:
 
 
 def pack_edges(results, H: int, W: int, device=None) -> torch.Tensor:
-    """`results`: list of slam_scheduler.EdgeResult (or objects with the same fields) of THIS rank's edges."""
+    """`results`: list of slam_scheduler.EdgeResult (or objects with the same fields) of THIS rank's edges.
+    H, W = the dims of the maps AS RETURNED: for portrait frames regress_views hands out transposed views ([2, W_img, H_img],
+    like the reference, utils/misc.py:60-61,81), so pass (W_img, H_img) here and to gather_edges - a mismatch would scramble the
+    gathered maps silently, hence the check."""
     rows = []
     for r in results:
+        if r.accepted and (tuple(r.depths.shape[-2:]) != (H, W) or tuple(r.confs.shape[-2:]) != (H, W)):
+            raise ValueError(f"pack_edges(H={H}, W={W}) got maps of shape {tuple(r.depths.shape)} / {tuple(r.confs.shape)}: "
+                             "pass the dims of the returned maps (transposed for portrait frames)")
         dev = r.pose.device if device is None else device
         head = torch.tensor([1.0 if r.accepted else 0.0, float(r.rel_pose_conf)], device=dev)
         if r.accepted:

@@ -194,6 +194,11 @@ class STAFrontend:
         feat1 = self._f32(feat1).contiguous()
         feat2 = self._f32(feat2).contiguous()
         B, N, E = feat1.shape
+        # The module code would accept two views with different token counts (cross-attention takes any memory length,
+        # sta_blocks.py:193-205); the pipeline never produces them (one process_image resolution, sta_model.py:257-262), and
+        # here both sides run as ONE batch of 2B sequences over the shared decoder weights: not served
+        assert feat2.shape[1] == N and feat2.shape[0] == B, \
+            f"both views must have the same token grid (got {tuple(feat1.shape)} and {tuple(feat2.shape)})"
         assert feat2.shape == feat1.shape and E == self.cfg.enc_embed_dim
         hp, wp = self._grid_from_pos(pose1, N)
         L = self.cfg.dec_depth + 1
