@@ -61,7 +61,7 @@ def summarize_gemm_records(recs, precision):
     for (M_, N_, K_, epi, amode, mx, fam, ms_) in recs:
         sym = (f"gemm_kernel<{sp}, {amode}, {epi}>" if fam == 1 else
                f"gemm2_pair_kernel<{sp}, {amode}, {epi}, 192, 128, 2, 4>" if fam == 7 else      # decoder: attn.qkv + cross_attn.projk|projv
-               f"conv3h_kernel<{sp}, {epi}, 256, {128 if N_ == 128 else 256}, 4, 4, {'true' if mx else 'false'}, 2>" if fam == 8 else   # halo-tiled 3x3 convolution
+               f"conv3h_kernel<{sp}, {epi}, 256, {128 if N_ == 128 else 256}, 4, 4, {'true' if mx else 'false'}>" if fam == 8 else   # halo-tiled 3x3 convolution
                f"gemm2_kernel<{sp}, {amode}, {epi}, {fam_tpl[fam]}, {'true' if mx else 'false'}>")
         g = groups.setdefault(sym, {"ms": 0.0, "fl": 0.0, "by": 0.0, "n": 0, "mx": mx, "epi": epi, "amode": amode, "fam": fam})
         g["ms"] += ms_; g["fl"] += 2.0 * M_ * N_ * K_; g["n"] += 1

@@ -51,10 +51,10 @@ int sta_debug_attention(sta_handle* h, const float* q, const float* k, const flo
 int sta_debug_attention_pose(sta_handle* h, const float* q, const float* k, const float* v, int S, int heads,
                              int n, int kv_shift, float* out, void* stream);
 
-/* Experiment switches of the tools (0 everywhere = product behaviour).  idx 0: conv3h configuration (bits 0-1: 0 = 16 waves /
- * 2 weight stages, 1 = 16 waves / 3-stage weight ring, 2 = 8 waves with 64x64 wave tiles / ring; bit 3: Cout = 256 as two
- * 128-column tiles).  idx 4 = 1: sta_debug_gemm (plane epilogue) / conv3x3 / convt / up2 run in the DPT head's f16mx arithmetic
- * (f16mx rows in and out, f16mx weights) when the handle's precision is f16x3h - the kernels that precision uses inside the head. */
+/* Switches of the tests / tools (0 everywhere = product behaviour; indices 0-3 and 5-7 are free for one-off experiments, see
+ * tools/ab_option.py; also settable as STA_OPT<idx> in the environment at sta_create).  idx 4 = 1: sta_debug_gemm (plane
+ * epilogue) / conv3x3 / convt / up2 run in the DPT head's f16mx arithmetic (f16mx rows in and out, f16mx weights) when the
+ * handle's precision is f16x3h - the kernels that precision uses inside the head. */
 int sta_debug_set_option(sta_handle* h, int idx, int value);
 
 /* Row-tail hint for the dense GEMMs (what the decoder sets to its 2B pose-token rows): the last `rows` (<= 32) rows of the

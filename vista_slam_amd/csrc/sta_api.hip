@@ -494,12 +494,12 @@ static int launch_gemm2(const GemmParams& p, hipStream_t st, int dev = 0) {
     return 0;
 }
 
-template <bool SPLIT, int EPI, int BM, int BN, bool MX, int WMS = 4, int WNS = 4, int NSTGB = 2>
+template <bool SPLIT, int EPI, int BM, int BN, bool MX, int WMS = 4, int WNS = 4>
 static int launch_conv3h(const GemmParams& p, hipStream_t st, int dev) {
     static unsigned attr_done = 0;        // one bit per device
-    constexpr int smem = conv3h_smem_bytes<SPLIT, BM, BN>(NSTGB);
+    constexpr int smem = conv3h_smem_bytes<SPLIT, BM, BN>();
     static_assert(smem <= 160 * 1024, "conv3h: LDS budget");
-    auto kern = conv3h_kernel<SPLIT, EPI, BM, BN, WMS, WNS, MX, NSTGB>;
+    auto kern = conv3h_kernel<SPLIT, EPI, BM, BN, WMS, WNS, MX>;
     if (!(attr_done >> (dev & 31) & 1u)) {
         HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_done |= 1u << (dev & 31);
@@ -699,15 +699,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st, in
     if constexpr (AMODE == A_CONV3 && (EPI == EPI_F16 || EPI == EPI_HEAD)) {
         if (variant == 8) {
             REQUIRE((int64_t)p.Ho * p.Wo > 0 && p.M % (p.Ho * p.Wo) == 0, "internal: conv3h needs whole images");
-            const int cfg = h->opt[0];      // experiments (sta_debug_set_option 0): conv3h configuration of the Cout = 128 tile
-            if (p.N == 128 || (cfg & 8)) {  // (cfg & 8: Cout = 256 as two 128-column tiles as well)
-                if ((cfg & 3) == 1 && split) {
-                    if (p.mx) CHK((launch_conv3h<true, EPI, 256, 128, true, 4, 4, 3>(p, st, h->device)));
-                    else CHK((launch_conv3h<true, EPI, 256, 128, false, 4, 4, 3>(p, st, h->device)));
-                } else if ((cfg & 3) == 2 && split) {
-                    if (p.mx) CHK((launch_conv3h<true, EPI, 256, 128, true, 4, 2, 3>(p, st, h->device)));
-                    else CHK((launch_conv3h<true, EPI, 256, 128, false, 4, 2, 3>(p, st, h->device)));
-                } else
+            if (p.N == 128) {
                 if (p.mx) CHK((launch_conv3h<true, EPI, 256, 128, true>(p, st, h->device)));
                 else if (split) CHK((launch_conv3h<true, EPI, 256, 128, false>(p, st, h->device)));
                 else STA_F16ONLY(CHK((launch_conv3h<false, EPI, 256, 128, false>(p, st, h->device))));
