@@ -20,13 +20,22 @@ struct LnParams {
 };
 
 // normalised values n[4] of columns idx..idx+3 of `row` -> affine set 1 (fp32 copy and / or planes) and optional set 2
+// The affine parameters come in registers (LnAffine, loaded by the caller together with the row, BEFORE its first store: a load
+// issued between two stores waits for the first store's acknowledgement - loads and stores share vmcnt on gfx9).
+struct LnAffine { float4 g1, b1, g2, b2; };
+__device__ __forceinline__ LnAffine ln_load_affine(const LnParams& p, int idx) {
+    LnAffine a;
+    a.g1 = *reinterpret_cast<const float4*>(p.g1 + idx); a.b1 = *reinterpret_cast<const float4*>(p.b1 + idx);
+    if (p.g2) { a.g2 = *reinterpret_cast<const float4*>(p.g2 + idx); a.b2 = *reinterpret_cast<const float4*>(p.b2 + idx); }
+    else { a.g2 = a.g1; a.b2 = a.b1; }
+    return a;
+}
 template <bool SPLIT>
-__device__ __forceinline__ void ln_store4(const LnParams& p, int row, int idx, const float n[4]) {
+__device__ __forceinline__ void ln_store4(const LnParams& p, int row, int idx, const float n[4], const LnAffine& af) {
     RangeAcc ra;       // never flushed (dead code): a normalised row times the gains cannot leave the fp16 range; what can go wrong is a
                        // non-finite ROW (inf / NaN in the residual stream), which ln_kernel / resid_ln_kernel count from the row statistics
     {
-        float4 g = *reinterpret_cast<const float4*>(p.g1 + idx);
-        float4 b = *reinterpret_cast<const float4*>(p.b1 + idx);
+        const float4 g = af.g1, b = af.b1;
         float y[4] = {n[0] * g.x + b.x, n[1] * g.y + b.y, n[2] * g.z + b.z, n[3] * g.w + b.w};
         if (p.o32) *reinterpret_cast<float4*>(p.o32 + (size_t)row * p.ldo32 + idx) = make_float4(y[0], y[1], y[2], y[3]);
         if (p.o1_hi) {
@@ -39,8 +48,7 @@ __device__ __forceinline__ void ln_store4(const LnParams& p, int row, int idx, c
         }
     }
     if (p.g2) {
-        float4 g = *reinterpret_cast<const float4*>(p.g2 + idx);
-        float4 b = *reinterpret_cast<const float4*>(p.b2 + idx);
+        const float4 g = af.g2, b = af.b2;
         float y[4] = {n[0] * g.x + b.x, n[1] * g.y + b.y, n[2] * g.z + b.z, n[3] * g.w + b.w};
         const size_t o = blk_off<SPLIT>(row, idx, p.M);
         H4 h, l;
@@ -58,12 +66,14 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
     if (row >= p.M) return;
     const float* xr = p.x + (size_t)row * p.ldx;
     float4 v[4];
+    LnAffine af[4];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int idx = (i * 64 + lane) * 4;
         if (idx < p.C) {
             v[i] = *reinterpret_cast<const float4*>(xr + idx);
+            af[i] = ln_load_affine(p, idx);
             sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         }
     }
@@ -84,7 +94,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
         int idx = (i * 64 + lane) * 4;
         if (idx < p.C) {
             float n[4] = {(v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd};
-            ln_store4<SPLIT>(p, row, idx, n);
+            ln_store4<SPLIT>(p, row, idx, n, af[i]);
         }
     }
 }
@@ -98,6 +108,8 @@ __global__ __launch_bounds__(256) void resid_ln_kernel(const LnParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool on = idx < p.C;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    LnAffine af;
+    if (on && p.g1) af = ln_load_affine(p, idx);
     if (on) {
         v = *reinterpret_cast<const float4*>(p.x + (size_t)row * p.ldx + idx);
         for (int s = 0; s < p.nslab; ++s) {
@@ -121,7 +133,7 @@ __global__ __launch_bounds__(256) void resid_ln_kernel(const LnParams p) {
     if (threadIdx.x == 0 && !(fabsf(mean) <= 3.0e38f && rstd <= 3.0e38f)) atomicAdd(&g_sta_range[0], 1ull);   // non-finite row (range report)
     if (on) {
         float n[4] = {(v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd};
-        ln_store4<SPLIT>(p, row, idx, n);
+        ln_store4<SPLIT>(p, row, idx, n, af);
     }
 }
 

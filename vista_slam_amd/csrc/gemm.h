@@ -172,14 +172,28 @@ __device__ __forceinline__ void epilogue_qkv_tile(const GemmParams& p, const flo
     }
     f16* const dh = seg == 0 ? p.Q_hi : p.K_hi;
     f16* const dl = seg == 0 ? p.Q_lo : p.K_lo;
+    // cos / sin pairs in two batches of 8 before their stores (a table load between two stores waits for the first one's
+    // acknowledgement; all 16 at once would push the 192x128 kernel past 128 VGPRs = one workgroup per CU)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int half = 0; half < 2; ++half) {
+    float2 cs8[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int r = half * 8 + q;
+        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        int s, t; bool pose_row;
+        qkv_row_token(p, row < p.M ? row : p.M - 1, s, t, pose_row);
+        const int pos = qkv_rope_pos(p, t, pose_row, xpart);               // table row 0 == position -1 (pose token)
+        cs8[q] = *reinterpret_cast<const float2*>(p.rope_tab + ((size_t)pos * 16 + (lane & 15)) * 2);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int r = half * 8 + q;
         const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
         const int rowc = row < p.M ? row : p.M - 1;
         int s, t; bool pose_row;
         qkv_row_token(p, rowc, s, t, pose_row);
-        const int pos = qkv_rope_pos(p, t, pose_row, xpart);               // table row 0 == position -1 (pose token)
-        const float2 cs = *reinterpret_cast<const float2*>(p.rope_tab + ((size_t)pos * 16 + (lane & 15)) * 2);
+        const float2 cs = cs8[q];
         float v = acc[r] + bv;
         const float other = __shfl_xor(v, 16);
         v = (lane & 16) ? (v * cs.x + other * cs.y) : (v * cs.x - other * cs.y);
@@ -188,6 +202,7 @@ __device__ __forceinline__ void epilogue_qkv_tile(const GemmParams& p, const flo
             if (SPLIT) { f16 h, l; split_f16(v, h, l, ra); dh[o] = h; dl[o] = l; }
             else dh[o] = to_f16_sat(v, ra);
         }
+    }
     }
 }
 
@@ -217,6 +232,18 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
         return;
     }
     const float bv = (p.bias != nullptr && col_ok && first_slice) ? p.bias[col] : 0.f;
+    if (EPI == EPI_F32R && row0 + 32 <= M_ && __all(col_ok)) {
+        // interior tile of the in-place residual epilogue.  ALL 16 residual loads first, then the 16 stores: written as
+        // `*c = v + *c` per element the compiler must keep load r+1 behind store r (it cannot prove ldc != 0), and on gfx9 loads
+        // and stores share vmcnt, where LLVM waits vmcnt(0) as soon as both kinds are pending - 16 dependent
+        // (store-ack, load) round trips per 32x32 tile: most of the 25-36 us this epilogue used to expose per launch.
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = p.C32[(size_t)(row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * p.ldc + col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p.C32[(size_t)(row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * p.ldc + col] = (acc[r] + bv) + old[r];
+        return;
+    }
     if ((EPI == EPI_F32R || EPI == EPI_GELU) && row0 + 32 <= M_ && __all(col_ok)) {
         // interior tile of a hot epilogue (every tile when M, N are tile multiples, as at bench scale): no per-element
         // bounds predicate -> no exec-mask save / branch per element
@@ -236,16 +263,41 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
         }
         return;
     }
+    // Everything this epilogue READS from global memory (residual stream, residual planes) is loaded before its first store:
+    // interleaved, every load would wait for the acknowledgement of the store before it (vmcnt(0), see above).
+    float pre1[16], pre2[16];
+    const bool rd32 = EPI == EPI_F32R || (EPI == EPI_F32 && p.resid != nullptr && p.ksplit <= 1);
+    const bool rd16 = EPI == EPI_F16 && p.ksplit <= 1 && (p.R1_hi != nullptr || p.R2_hi != nullptr);
+    if (rd32 || rd16) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            pre1[r] = 0.f; pre2[r] = 0.f;
+            if (!(col_ok && row < M_)) continue;
+            if (EPI == EPI_F32R) pre1[r] = p.C32[(size_t)row * p.ldc + col];
+            else if (EPI == EPI_F32) {
+                int orow = row;
+                if (p.rows_in > 0) orow = (row / p.rows_in) * p.rows_out + p.row_off + row % p.rows_in;
+                pre1[r] = p.resid[(size_t)orow * p.ldr + col];
+            } else {
+                const size_t o = blk_off<SPLIT>(row, col, p.c_rp);
+                if (SPLIT && p.r_mx) {
+                    if (p.R1_hi) pre1[r] = load_mx_act(p.R1_hi, o);
+                    if (p.R2_hi) pre2[r] = load_mx_act(p.R2_hi, o);
+                } else {
+                    if (p.R1_hi) pre1[r] = (float)p.R1_hi[o] + (SPLIT ? (float)p.R1_hi[o + 32] : 0.f);
+                    if (p.R2_hi) pre2[r] = (float)p.R2_hi[o] + (SPLIT ? (float)p.R2_hi[o + 32] : 0.f);
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
         const bool ok = col_ok && row < M_;
         float v = acc[r] + bv;
         if (EPI == EPI_F32R) {
-            if (ok) {
-                float* c = p.C32 + (size_t)row * p.ldc + col;
-                *c = v + *c;
-            }
+            if (ok) p.C32[(size_t)row * p.ldc + col] = v + pre1[r];
         } else if (EPI == EPI_F32) {
             if (ok) {
                 int orow = row;
@@ -255,7 +307,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
                 } else if (p.ksplit > 1) {
                     unsafeAtomicAdd(p.C32 + (size_t)orow * p.ldc + col, v);       // hardware global_atomic_add_f32
                 } else {
-                    if (p.resid) v += p.resid[(size_t)orow * p.ldr + col];
+                    if (p.resid) v += pre1[r];
                     p.C32[(size_t)orow * p.ldc + col] = v;
                 }
             }
@@ -273,13 +325,8 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
                 if (p.act == ACT_GELU) v = gelu_erf(v);
                 else if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
                 const size_t o = blk_off<SPLIT>(row, col, p.c_rp);
-                if (SPLIT && p.r_mx) {
-                    if (p.R1_hi) v += load_mx_act(p.R1_hi, o);
-                    if (p.R2_hi) v += load_mx_act(p.R2_hi, o);
-                } else {
-                    if (p.R1_hi) { v += (float)p.R1_hi[o]; if (SPLIT) v += (float)p.R1_hi[o + 32]; }
-                    if (p.R2_hi) { v += (float)p.R2_hi[o]; if (SPLIT) v += (float)p.R2_hi[o + 32]; }
-                }
+                if (p.R1_hi) v += pre1[r];
+                if (p.R2_hi) v += pre2[r];
                 if (SPLIT && p.c_mx) store_mx1<false>(p.C_hi, o, v, ra);
                 else if (SPLIT) { f16 h, l; split_f16(v, h, l, ra); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
                 else p.C_hi[o] = to_f16_sat(v, ra);

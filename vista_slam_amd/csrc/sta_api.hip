@@ -535,8 +535,8 @@ static inline bool small_grid(int64_t M, int N) {
 //   3: 192x256, 12 waves, one workgroup per CU, 30 % less L2->LDS traffic per FLOP: +2 % mlp.fc1 (GELU), +4 % the long-K
 //      in-place-residual GEMMs (mlp.fc2), +6 % the Cout = 256 convolutions with K >= 1728;
 //   2: 256x256, 16 waves: +5 % mlp.fc1, +10 % those convolutions, -10 % the in-place-residual epilogue;
-//   8: halo-tiled 3x3 convolution (conv3h.h; 8 x 32-pixel tiles of one image): +12 % at Cout = 256, -3 % at Cout = 128
-//      (head.0), equal with the fused head epilogue;
+//   8: halo-tiled 3x3 convolution (conv3h.h; 8 x 32-pixel tiles of one image): +12 % at Cout = 256, equal at Cout = 128
+//      (head.0: ties go to the halo form, which moves 1.3x instead of 6.5x the algorithmic bytes), -2.5 % with the fused head epilogue;
 //   6: small-grid family (predicate above);  1: 128x128 register-staged kernel: N not a multiple of 128;
 //   7 (paired 192x128 launch) is chosen by gemm_qkv_pair.
 struct FamilyQuery { int amode, epi; int64_t M; int N, K; int split, cstride, Ho, Wo; };
@@ -558,13 +558,14 @@ static int pick_family(const FamilyQuery& q) {
         if (q.amode == A_DENSE && q.epi == EPI_GELU) { r3 = 1.02; r2 = 1.05; }
         else if (q.amode == A_DENSE && q.epi == EPI_F32R && q.K >= 2048) { r3 = 1.04; r2 = 0.9; }
         else if (q.amode == A_CONV3 && q.N == 256 && q.K >= 1728) { r3 = 1.06; r2 = 1.10; }
+        else if (q.amode == A_DENSE && q.epi == EPI_F16) { r3 = 1.0; r2 = 1.0; }      // 1x1 convolutions of the head: quantisation only
         if (r3 > 0) { consider(3, cost(tiles(192, 256), 192 * 256, r3, 0.93)); consider(2, cost(tiles(256, 256), 256 * 256, r2, 0.93)); }
     }
     if (q.amode == A_CONV3 && (q.epi == EPI_F16 || q.epi == EPI_HEAD) && q.cstride == 1 && (q.N == 128 || q.N == 256) &&
         q.Wo >= 32 && q.M >= 16384 && q.Ho > 0) {
         const int64_t imgs = q.M / ((int64_t)q.Ho * q.Wo);
         const int64_t t8 = imgs * ((q.Ho + 7) / 8) * ((q.Wo + 31) / 32);
-        consider(8, cost(t8, 256 * q.N, q.epi == EPI_HEAD ? 1.0 : (q.N == 128 ? 0.97 : 1.12), 0.96));
+        consider(8, cost(t8, 256 * q.N, q.epi == EPI_HEAD ? 0.975 : (q.N == 128 ? 1.0 : 1.12), 0.96));
     }
     return best;
 }
@@ -710,6 +711,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st, in
             }
         }
     }
+    if (variant == 2 || variant == 3) REQUIRE(EPI != EPI_QKV, "internal: the RoPE epilogue exists on the 192x128 / 128x64 / 128x128 tiles only");
     if (variant == 8) {
     } else
     if constexpr (EPI == EPI_HEAD) {      // exists for the 192x128 family only (conv3_head checks the shape)
@@ -719,13 +721,17 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st, in
         else STA_F16ONLY(CHK((launch_gemm2<false, AMODE, EPI, 192, 128, 2, 4>(p, st, h->device))));
     } else
     if (variant == 2) {
+      if constexpr (EPI != EPI_QKV) {
         if (p.mx) { if constexpr (MX_EPI) CHK((launch_gemm2<true, AMODE, EPI, 256, 256, 4, 4, 2, true>(p, st, h->device))); }
         else if (split) CHK((launch_gemm2<true, AMODE, EPI, 256, 256, 4, 4>(p, st, h->device)));
         else STA_F16ONLY(CHK((launch_gemm2<false, AMODE, EPI, 256, 256, 4, 4>(p, st, h->device))));
+      }
     } else if (variant == 3) {
+      if constexpr (EPI != EPI_QKV) {
         if (p.mx) { if constexpr (MX_EPI) CHK((launch_gemm2<true, AMODE, EPI, 192, 256, 3, 4, 2, true>(p, st, h->device))); }
         else if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 256, 3, 4>(p, st, h->device)));
         else STA_F16ONLY(CHK((launch_gemm2<false, AMODE, EPI, 192, 256, 3, 4>(p, st, h->device))));
+      }
     } else if (variant == 5) {
         if (p.mx) { if constexpr (MX_EPI) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4, 2, true>(p, st, h->device))); }
         else if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4>(p, st, h->device)));
