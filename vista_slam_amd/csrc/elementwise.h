@@ -21,7 +21,7 @@ struct LnParams {
 
 // normalised values n[4] of columns idx..idx+3 of `row` -> affine set 1 (fp32 copy and / or planes) and optional set 2
 // The affine parameters come in registers (LnAffine, loaded by the caller together with the row, BEFORE its first store: a load
-// issued between two stores waits for the first store's acknowledgement - loads and stores share vmcnt on gfx9).
+// issued behind a store waits for that store's acknowledgement - loads and stores retire through one in-order vmcnt on gfx9).
 struct LnAffine { float4 g1, b1, g2, b2; };
 __device__ __forceinline__ LnAffine ln_load_affine(const LnParams& p, int idx) {
     LnAffine a;

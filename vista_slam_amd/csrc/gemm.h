@@ -172,8 +172,8 @@ __device__ __forceinline__ void epilogue_qkv_tile(const GemmParams& p, const flo
     }
     f16* const dh = seg == 0 ? p.Q_hi : p.K_hi;
     f16* const dl = seg == 0 ? p.Q_lo : p.K_lo;
-    // cos / sin pairs in two batches of 8 before their stores (a table load between two stores waits for the first one's
-    // acknowledgement; all 16 at once would push the 192x128 kernel past 128 VGPRs = one workgroup per CU)
+    // cos / sin pairs in two batches of 8 before their stores (a table load issued behind a store waits for that store's
+    // acknowledgement; hoisting the per-tile bias loads as well and reading the table from an LDS copy measured 0.0 %; all 16 at once would push the 192x128 kernel past 128 VGPRs = one workgroup per CU)
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
     float2 cs8[8];
@@ -235,8 +235,9 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
     if (EPI == EPI_F32R && row0 + 32 <= M_ && __all(col_ok)) {
         // interior tile of the in-place residual epilogue.  ALL 16 residual loads first, then the 16 stores: written as
         // `*c = v + *c` per element the compiler must keep load r+1 behind store r (it cannot prove ldc != 0), and on gfx9 loads
-        // and stores share vmcnt, where LLVM waits vmcnt(0) as soon as both kinds are pending - 16 dependent
-        // (store-ack, load) round trips per 32x32 tile: most of the 25-36 us this epilogue used to expose per launch.
+        // and stores retire through ONE in-order counter (vmcnt): the data of a load cannot be used before every store issued
+        // ahead of it has been acknowledged - 16 dependent (store-ack, load) round trips per 32x32 tile: most of the 25-36 us
+        // this epilogue used to expose per launch (tools/isa_serial_scan.py finds the pattern in the built code).
         float old[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) old[r] = p.C32[(size_t)(row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * p.ldc + col];
@@ -244,27 +245,21 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
         for (int r = 0; r < 16; ++r) p.C32[(size_t)(row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * p.ldc + col] = (acc[r] + bv) + old[r];
         return;
     }
-    if ((EPI == EPI_F32R || EPI == EPI_GELU) && row0 + 32 <= M_ && __all(col_ok)) {
-        // interior tile of a hot epilogue (every tile when M, N are tile multiples, as at bench scale): no per-element
+    if (EPI == EPI_GELU && row0 + 32 <= M_ && __all(col_ok)) {
+        // interior tile of the other hot epilogue (every tile when M, N are tile multiples, as at bench scale): no per-element
         // bounds predicate -> no exec-mask save / branch per element
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            float v = acc[r] + bv;
-            if (EPI == EPI_F32R) {
-                float* c = p.C32 + (size_t)row * p.ldc + col;
-                *c = v + *c;
-            } else {
-                v = gelu_erf(v);
-                const size_t o = blk_off<SPLIT>(row, col, p.c_rp);
-                if (SPLIT) { f16 h, l; split_f16(v, h, l, ra); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
-                else p.C_hi[o] = to_f16_sat(v, ra);
-            }
+            const float v = gelu_erf(acc[r] + bv);
+            const size_t o = blk_off<SPLIT>(row, col, p.c_rp);
+            if (SPLIT) { f16 h, l; split_f16(v, h, l, ra); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
+            else p.C_hi[o] = to_f16_sat(v, ra);
         }
         return;
     }
     // Everything this epilogue READS from global memory (residual stream, residual planes) is loaded before its first store:
-    // interleaved, every load would wait for the acknowledgement of the store before it (vmcnt(0), see above).
+    // interleaved, every load would wait for the acknowledgement of the store before it (in-order vmcnt, see above).
     float pre1[16], pre2[16];
     const bool rd32 = EPI == EPI_F32R || (EPI == EPI_F32 && p.resid != nullptr && p.ksplit <= 1);
     const bool rd16 = EPI == EPI_F16 && p.ksplit <= 1 && (p.R1_hi != nullptr || p.R2_hi != nullptr);
