@@ -35,7 +35,10 @@ def test_gemm(G, prec, kw):
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("kw", [dict(), dict(hp=14, wp=14, pose_tok=0, S=1), dict(hp=3, wp=5, pose_tok=1, S=3),
                                 dict(hp=14, wp=14, pose_tok=1, S=2, variant=2), dict(hp=5, wp=7, pose_tok=0, S=3, Cdim=256, K=256, variant=2),
-                                dict(hp=14, wp=14, pose_tok=1, S=2, variant=3)])
+                                dict(hp=14, wp=14, pose_tok=1, S=2, variant=3),
+                                # throughput tile (192x128: >= 192 tiles), token rows 32-aligned: the V^T LDS-transpose path; with a pose
+                                # token in front (t0 = 32k + 1: unaligned) its fallback
+                                dict(hp=24, wp=32, pose_tok=0, S=4, K=64, Cdim=512), dict(hp=24, wp=32, pose_tok=1, S=4, K=64, Cdim=512)])
 def test_qkv_rope(G, prec, kw):
     r = G.check_qkv_rope(prec, **kw)
     assert r["q"] < TOL[prec] and r["k"] < TOL[prec] and r["v"] < TOL[prec], r
@@ -52,7 +55,8 @@ def test_gemm_tail_rows(G, prec, kw):
 
 
 @pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("kw", [dict(), dict(hp=14, wp=14, S=2), dict(hp=14, wp=14, S=2, variant=3), dict(hp=24, wp=32, S=4, K=64)])
+@pytest.mark.parametrize("kw", [dict(), dict(hp=14, wp=14, S=2), dict(hp=14, wp=14, S=2, variant=3), dict(hp=24, wp=32, S=4, K=64),
+                                dict(hp=24, wp=32, S=4, K=64, Cdim=512)])      # 192x128 tiles + tail blocks: V^T LDS-transpose path
 def test_qkv_rope_decoder_rows(G, prec, kw):
     r = G.check_qkv_rope_decoder_rows(prec, **kw)
     assert r["q"] < TOL[prec] and r["k"] < TOL[prec] and r["v"] < TOL[prec], r

@@ -123,7 +123,7 @@ typedef uint2 __attribute__((aligned(2))) uint2_a2;   // 8-byte store of 4 halve
 // from the table), head-major Q/K stores, and V written TRANSPOSED ([d][token]) - a lane owns one d
 // column and 4 consecutive tokens per register group, i.e. one 8-byte run of V^T per group.
 template <bool SPLIT>
-__device__ __forceinline__ void epilogue_qkv_tile(const GemmParams& p, const floatx16& acc, int row0, int col, int lane) {
+__device__ __forceinline__ void epilogue_qkv_tile(const GemmParams& p, const floatx16& acc, int row0, int col, int lane, char* wave_lds = nullptr) {
     const int lhi = lane >> 5;
     const bool col_ok = col < p.N;
     RangeAcc ra;                      // never flushed: q / k / v are linear maps of LayerNorm outputs (bounded by sqrt(C) x the gains x
@@ -135,6 +135,39 @@ __device__ __forceinline__ void epilogue_qkv_tile(const GemmParams& p, const flo
     else if (cbase >= p.nq) { seg = 1; cc = cbase - p.nq; }
     const int head = cc >> 6, dcol = col - cbase, xpart = (dcol >> 5) & 1;
     if (seg == 2) {
+        // V^T through the wave's LDS scratch (QKV_LDS_BYTES, gemm2_body): a lane owns ONE d column and 16 tokens, so written
+        // straight from the accumulators a store instruction scatters 64 x 8 B into 64 different 128-B lines (measured: the V
+        // third of this epilogue cost 1.6 % of the whole step).  Transposed in LDS ([d][32 tokens], 80-B rows) the same tile
+        // leaves as 2 x 2 instructions of 16 B per lane: 64 contiguous bytes per d row.  Fast path: the 32 rows are patch /
+        // token rows of ONE sequence and 16-B aligned in V^T; everything else (sequence boundaries, M tail, pose rows) below.
+        if (wave_lds != nullptr && __all(col_ok) && row0 + 32 <= (p.pose_base > 0 ? p.pose_base : p.M)) {
+            const int s0 = fast_div(row0, p.ntok, p.ntok_magic), t0 = row0 - s0 * p.ntok;      // wave-uniform
+            if (t0 + 32 <= p.ntok && (t0 & 7) == 0) {
+                char* Lh = wave_lds; char* Ll = wave_lds + 32 * 80;
+                const int d = lane & 31;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    H4 ph, pl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = acc[g * 4 + e] + bv;
+                        if (SPLIT) split_f16(v, ph.e[e], pl.e[e], ra); else { ph.e[e] = to_f16_sat(v, ra); pl.e[e] = (f16)0; }
+                    }
+                    *reinterpret_cast<uint2*>(Lh + d * 80 + (8 * g + 4 * lhi) * 2) = ph.u;
+                    if (SPLIT) *reinterpret_cast<uint2*>(Ll + d * 80 + (8 * g + 4 * lhi) * 2) = pl.u;
+                }
+                const int dbase = dcol - d;                      // first d of this 32-column tile (0 or 32): wave-uniform
+                const size_t obase = ((size_t)(s0 * p.heads + head) * 64 + dbase) * p.npad + t0;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int dr = (lane >> 2) + 16 * half, c = lane & 3;
+                    const size_t o = obase + (size_t)dr * p.npad + c * 8;
+                    *reinterpret_cast<uint4*>(p.Vt_hi + o) = *reinterpret_cast<const uint4*>(Lh + dr * 80 + c * 16);
+                    if (SPLIT) *reinterpret_cast<uint4*>(p.Vt_lo + o) = *reinterpret_cast<const uint4*>(Ll + dr * 80 + c * 16);
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int rowg = row0 + 8 * g + 4 * lhi;
@@ -212,15 +245,16 @@ __device__ __forceinline__ void epilogue_qkv_tile(const GemmParams& p, const flo
 // of 64, so segment, head and the RoPE half (y for d<32, x for d>=32) are wave-uniform.
 // mlim >= 0: rows >= mlim are not stored (halo-tiled convolutions: a 32-row MFMA tile = 32 pixels of ONE image row, the rest
 // of the tile lies beyond the row's end); default: the GEMM's M.
+#define QKV_LDS_BYTES (2 * 32 * 80)      // per-wave LDS scratch of the V^T transpose in epilogue_qkv_tile
 template <bool SPLIT, int EPI>
 __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx16& acc, int row0, int col, int lane,
-                                              int kslice = 0, int mlim = -1) {
+                                              int kslice = 0, int mlim = -1, char* wave_lds = nullptr) {
     const bool first_slice = kslice == 0;
     const int M_ = mlim >= 0 ? mlim : p.M;
     RangeAcc ra;                      // range report (sta_common.h): one flush per tile - for the plane epilogues of the DPT head
                                       // (no normalisation layers) and the generic EPI_F16; mlp.fc1's GELU tile (EPI_GELU) is a
                                       // function of a LayerNorm output and stays uncounted (its compares are dead code)
-    if (EPI == EPI_QKV && p.ksplit <= 1) { epilogue_qkv_tile<SPLIT>(p, acc, row0, col, lane); return; }
+    if (EPI == EPI_QKV && p.ksplit <= 1) { epilogue_qkv_tile<SPLIT>(p, acc, row0, col, lane, wave_lds); return; }
     const int lhi = lane >> 5;
     const bool col_ok = col < p.N;
     if (EPI == EPI_QKV) {          // split-K (small-M regime): raw partial tile to the slab of this slice; qkv_finish_kernel does the rest

@@ -495,11 +495,14 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
     if constexpr (EPI == EPI_HEAD) {
         if constexpr (BN == 128) head_epilogue<BM, MT, NT, WM, WAVES_N>(p, acc, m0, 32, BM / 32, 32, wm, wn, tid, smem);
     } else {
+        // EPI_QKV: a private LDS scratch per wave for the V^T transpose (the stage buffers are free: with two stages every wave
+        // is past the last barrier of the main loop; the ring form, used for QKV only with split K, goes without)
+        char* const wave_lds = (EPI == EPI_QKV && !RING && NW * QKV_LDS_BYTES <= NSTG * STAGE) ? smem + wave * QKV_LDS_BYTES : nullptr;
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
-                epilogue_tile<SPLIT, EPI>(p, acc[i][j], m0 + wm * WM + i * 32, n0 + wn * WN + j * 32 + l31, lane, kslice);
+                epilogue_tile<SPLIT, EPI>(p, acc[i][j], m0 + wm * WM + i * 32, n0 + wn * WN + j * 32 + l31, lane, kslice, -1, wave_lds);
     }
     if (p.clk_dbg && tid == 0 && (block_id & 63) == 0) {      // effective shader clock = cycles / (ticks / 100 MHz)
         atomicAdd(p.clk_dbg, __builtin_readcyclecounter() - clk0);
