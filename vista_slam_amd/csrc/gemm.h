@@ -205,6 +205,14 @@ __device__ __forceinline__ void epilogue_qkv_tile(const GemmParams& p, const flo
     }
     f16* const dh = seg == 0 ? p.Q_hi : p.K_hi;
     f16* const dl = seg == 0 ? p.Q_lo : p.K_lo;
+    // Q / K through the same LDS scratch when the 32 rows are consecutive tokens of one sequence: [token][32 d] rows of 64 B
+    // per plane, written back as 16 B per lane (2 x 2 store instructions instead of 32 of 2 B per lane)
+    bool staged = false;
+    int s0 = 0, t0 = 0;
+    if (wave_lds != nullptr && __all(col_ok) && row0 + 32 <= (p.pose_base > 0 ? p.pose_base : p.M)) {
+        s0 = fast_div(row0, p.ntok, p.ntok_magic); t0 = row0 - s0 * p.ntok;
+        staged = t0 + 32 <= p.ntok;
+    }
     // cos / sin pairs in two batches of 8 before their stores (a table load issued behind a store waits for that store's
     // acknowledgement; hoisting the per-tile bias loads as well and reading the table from an LDS copy measured 0.0 %; all 16 at once would push the 192x128 kernel past 128 VGPRs = one workgroup per CU)
 #pragma unroll
@@ -230,12 +238,29 @@ __device__ __forceinline__ void epilogue_qkv_tile(const GemmParams& p, const flo
         float v = acc[r] + bv;
         const float other = __shfl_xor(v, 16);
         v = (lane & 16) ? (v * cs.x + other * cs.y) : (v * cs.x - other * cs.y);
-        if (col_ok && row < p.M) {
+        if (staged) {
+            const int k = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (SPLIT) {
+                f16 h, l; split_f16(v, h, l, ra);
+                *reinterpret_cast<f16*>(wave_lds + k * 80 + (lane & 31) * 2) = h;
+                *reinterpret_cast<f16*>(wave_lds + 32 * 80 + k * 80 + (lane & 31) * 2) = l;
+            } else *reinterpret_cast<f16*>(wave_lds + k * 80 + (lane & 31) * 2) = to_f16_sat(v, ra);
+        } else if (col_ok && row < p.M) {
             const size_t o = ((size_t)(s * p.heads + head) * p.npad + t) * 64 + dcol;
             if (SPLIT) { f16 h, l; split_f16(v, h, l, ra); dh[o] = h; dl[o] = l; }
             else dh[o] = to_f16_sat(v, ra);
         }
     }
+    }
+    if (staged) {
+        const int dbase = dcol - (lane & 31);
+        const size_t obase = ((size_t)(s0 * p.heads + head) * p.npad + t0) * 64 + dbase;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int k = (lane >> 2) + 16 * half, c = lane & 3;
+            *reinterpret_cast<uint4*>(dh + obase + (size_t)k * 64 + c * 8) = *reinterpret_cast<const uint4*>(wave_lds + k * 80 + c * 16);
+            if (SPLIT) *reinterpret_cast<uint4*>(dl + obase + (size_t)k * 64 + c * 8) = *reinterpret_cast<const uint4*>(wave_lds + 32 * 80 + k * 80 + c * 16);
+        }
     }
 }
 
@@ -246,6 +271,7 @@ __device__ __forceinline__ void epilogue_qkv_tile(const GemmParams& p, const flo
 // mlim >= 0: rows >= mlim are not stored (halo-tiled convolutions: a 32-row MFMA tile = 32 pixels of ONE image row, the rest
 // of the tile lies beyond the row's end); default: the GEMM's M.
 #define QKV_LDS_BYTES (2 * 32 * 80)      // per-wave LDS scratch of the V^T transpose in epilogue_qkv_tile
+#define EPI_LDS_BYTES 5120               // per-wave LDS scratch of the epilogues (>= QKV_LDS_BYTES, >= 32 x 144 for the plane tiles)
 template <bool SPLIT, int EPI>
 __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx16& acc, int row0, int col, int lane,
                                               int kslice = 0, int mlim = -1, char* wave_lds = nullptr) {
@@ -277,6 +303,28 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
         for (int r = 0; r < 16; ++r) old[r] = p.C32[(size_t)(row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * p.ldc + col];
 #pragma unroll
         for (int r = 0; r < 16; ++r) p.C32[(size_t)(row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * p.ldc + col] = (acc[r] + bv) + old[r];
+        return;
+    }
+    if (EPI == EPI_GELU && SPLIT && wave_lds != nullptr && row0 + 32 <= M_ && __all(col_ok)) {
+        // interior tile of mlp.fc1 through the wave's LDS scratch: a lane owns ONE column and 16 rows, so straight from the
+        // accumulators the tile leaves as 32 store instructions of 2 B per lane.  Staged as [row][hi 64 B | lo 64 B] (exactly
+        // one 128-B row block of the blocked plane layout) it leaves as 4 instructions of 16 B per lane: 8 whole lines each.
+        constexpr int RS = 144;                               // LDS row stride (128 B + 16: 16-B aligned reads, no 2^k stride)
+        const int c = lane & 31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            const float v = gelu_erf(acc[r] + bv);
+            f16 h, l; split_f16(v, h, l, ra);
+            *reinterpret_cast<f16*>(wave_lds + k * RS + c * 2) = h;
+            *reinterpret_cast<f16*>(wave_lds + k * RS + 64 + c * 2) = l;
+        }
+        const size_t o0 = blk_off<SPLIT>(row0, col - c, p.c_rp);       // first element of the tile's first row block (64 elements per row)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int k = (lane >> 3) + 8 * it, ch = lane & 7;
+            *reinterpret_cast<uint4*>(p.C_hi + o0 + (size_t)k * 64 + ch * 8) = *reinterpret_cast<const uint4*>(wave_lds + k * RS + ch * 16);
+        }
         return;
     }
     if (EPI == EPI_GELU && row0 + 32 <= M_ && __all(col_ok)) {

@@ -495,9 +495,9 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
     if constexpr (EPI == EPI_HEAD) {
         if constexpr (BN == 128) head_epilogue<BM, MT, NT, WM, WAVES_N>(p, acc, m0, 32, BM / 32, 32, wm, wn, tid, smem);
     } else {
-        // EPI_QKV: a private LDS scratch per wave for the V^T transpose (the stage buffers are free: with two stages every wave
+        // EPI_QKV / EPI_GELU: a private LDS scratch per wave for the epilogue's transposes (the stage buffers are free: with two stages every wave
         // is past the last barrier of the main loop; the ring form, used for QKV only with split K, goes without)
-        char* const wave_lds = (EPI == EPI_QKV && !RING && NW * QKV_LDS_BYTES <= NSTG * STAGE) ? smem + wave * QKV_LDS_BYTES : nullptr;
+        char* const wave_lds = ((EPI == EPI_QKV || EPI == EPI_GELU) && !RING && NW * EPI_LDS_BYTES <= NSTG * STAGE) ? smem + wave * EPI_LDS_BYTES : nullptr;
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll

@@ -155,15 +155,21 @@ __device__ __forceinline__ float load_mx_act(const f16* base, size_t o) {
     return (float)base[o] + __builtin_amdgcn_cvt_f32_bf8(pair, 1) * (1.0f / (float)(1 << STA_MX_A_SLO));
 }
 template <bool WEIGHT>
-__device__ __forceinline__ void store_mx1(f16* base, size_t o, float x, RangeAcc& ra) {     // scalar variant (column-per-lane epilogues)
+__device__ __forceinline__ void split_mx1(float x, RangeAcc& ra, f16& h, unsigned short& pair) {     // scalar variant (column-per-lane epilogues)
     constexpr float KHI = WEIGHT ? (float)(1 << STA_MX_W_SHI) : (float)(1 << STA_MX_A_SHI);
     constexpr float KLO = WEIGHT ? (float)(1 << STA_MX_W_SLO) : (float)(1 << STA_MX_A_SLO);
     x = sat_f16_range(x, ra);
-    const f16 h = (f16)x; const float hf = (float)h, lf = x - hf;
+    h = (f16)x; const float hf = (float)h, lf = x - hf;
     if (WEIGHT) ra.w8 |= fabsf(lf * KLO) > STA_MX_W_MAX || fabsf(hf * KHI) > STA_MX_W_MAX; else ra.amax8 = ra.amax;
     const int b = WEIGHT ? cvt2_fp8<true>(lf * KLO, hf * KHI, 0, false) : cvt2_fp8<false>(hf * KHI, lf * KLO, 0, false);
+    pair = (unsigned short)(b & 0xFFFF);
+}
+template <bool WEIGHT>
+__device__ __forceinline__ void store_mx1(f16* base, size_t o, float x, RangeAcc& ra) {
+    f16 h; unsigned short pair;
+    split_mx1<WEIGHT>(x, ra, h, pair);
     base[o] = h;
-    reinterpret_cast<unsigned short*>(base)[o + 32] = (unsigned short)(b & 0xFFFF);
+    reinterpret_cast<unsigned short*>(base)[o + 32] = pair;
 }
 template <bool WEIGHT>
 __device__ __forceinline__ void store_mx1(f16* base, size_t o, float x) { RangeAcc ra; store_mx1<WEIGHT>(base, o, x, ra); ra.flush(); }
