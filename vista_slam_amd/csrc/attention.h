@@ -379,27 +379,55 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
         else step(integral_constant<int, 0>{}, T{}, it, ntiles);
     }
 
-    // ---- normalise and store: lane owns query q, d = dt*32 + (r&3) + 8*(r>>2) + 4*lhi
+    // ---- normalise and store: lane owns query q, d = dt*32 + (r&3) + 8*(r>>2) + 4*lhi.
+    // Straight from the registers a store instruction would scatter 64 x 8 B over 32 rows; the wave stages its 32 queries x 64 d
+    // as [query][column block][hi 64 B | lo 64 B] (= the row blocks of the output planes) in LDS and writes whole 128-B lines.
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
-    const int q = q0 + l31;
-    if (q < nqe) {
+    const int64_t orows = (int64_t)p.S * p.nq + (p.pose ? p.S : 0);
+    if constexpr (SPLIT) {
+        constexpr int RS = 144, QS = 2 * RS;            // LDS bytes per (query, column block) / per query
+        __syncthreads();                                // every wave is done with the K / V^T stages (all waves reach this point)
+        char* const wl = smem + wave * (32 * QS);
         RangeAcc ra;        // never flushed (dead code): a convex combination of V rows stays inside V's range
-        const int64_t orow = q < p.nq ? (int64_t)s * p.nq + q : (int64_t)p.S * p.nq + s, orows = (int64_t)p.S * p.nq + (p.pose ? p.S : 0);
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int dcol = d * 32 + 8 * g + 4 * lhi;
-                const size_t o = blk_off<SPLIT>(orow, h * 64 + dcol, orows);    // blocked planes [ldo/32][S*nq][hi32|lo32]
                 H4 oh, ol;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = oacc[d][g * 4 + e] * inv;
-                    if (SPLIT) split_f16(v, oh.e[e], ol.e[e], ra); else oh.e[e] = to_f16_sat(v, ra);
-                }
-                *reinterpret_cast<uint2*>(p.O_hi + o) = oh.u;
-                if (SPLIT) *reinterpret_cast<uint2*>(p.O_hi + o + 32) = ol.u;
+                for (int e = 0; e < 4; ++e) split_f16(oacc[d][g * 4 + e] * inv, oh.e[e], ol.e[e], ra);
+                *reinterpret_cast<uint2*>(wl + l31 * QS + d * RS + (8 * g + 4 * lhi) * 2) = oh.u;
+                *reinterpret_cast<uint2*>(wl + l31 * QS + d * RS + 64 + (8 * g + 4 * lhi) * 2) = ol.u;
             }
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int qq = (lane >> 3) + 8 * it, ch = lane & 7;
+                const int q = q0 + qq;
+                if (q < nqe) {
+                    const int64_t orow = q < p.nq ? (int64_t)s * p.nq + q : (int64_t)p.S * p.nq + s;
+                    const size_t o = blk_off<true>(orow, h * 64 + d * 32, orows);
+                    *reinterpret_cast<uint4*>(p.O_hi + o + ch * 8) = *reinterpret_cast<const uint4*>(wl + qq * QS + d * RS + ch * 16);
+                }
+            }
+    } else {
+        const int q = q0 + l31;
+        if (q < nqe) {
+            RangeAcc ra;
+            const int64_t orow = q < p.nq ? (int64_t)s * p.nq + q : (int64_t)p.S * p.nq + s;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int dcol = d * 32 + 8 * g + 4 * lhi;
+                    const size_t o = blk_off<false>(orow, h * 64 + dcol, orows);    // blocked planes [ldo/32][S*nq][32]
+                    H4 oh;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) oh.e[e] = to_f16_sat(oacc[d][g * 4 + e] * inv, ra);
+                    *reinterpret_cast<uint2*>(p.O_hi + o) = oh.u;
+                }
+        }
     }
 }
