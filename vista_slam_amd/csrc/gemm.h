@@ -205,61 +205,83 @@ __device__ __forceinline__ void epilogue_qkv_tile(const GemmParams& p, const flo
     }
     f16* const dh = seg == 0 ? p.Q_hi : p.K_hi;
     f16* const dl = seg == 0 ? p.Q_lo : p.K_lo;
-    // Q / K through the same LDS scratch when the 32 rows are consecutive tokens of one sequence: [token][32 d] rows of 64 B
-    // per plane, written back as 16 B per lane (2 x 2 store instructions instead of 32 of 2 B per lane)
-    bool staged = false;
-    int s0 = 0, t0 = 0;
+    // Fast path: the 32 rows are consecutive patch tokens of ONE sequence (every tile of the decoder's [patch rows | pose rows]
+    // order and of the encoder at 768 tokens).  (sequence, token, grid position) of row0 are wave-uniform - one division on
+    // the scalar unit instead of two magic divisions per element - and row k of the tile is token t0 + k; the rotated values
+    // go through the wave's LDS scratch ([token][32 d] rows of 64 B per plane) and leave as 16 B per lane (2 x 2 store
+    // instructions instead of 32 of 2 B per lane).
     if (wave_lds != nullptr && __all(col_ok) && row0 + 32 <= (p.pose_base > 0 ? p.pose_base : p.M)) {
-        s0 = fast_div(row0, p.ntok, p.ntok_magic); t0 = row0 - s0 * p.ntok;
-        staged = t0 + 32 <= p.ntok;
-    }
-    // cos / sin pairs in two batches of 8 before their stores (a table load issued behind a store waits for that store's
-    // acknowledgement; hoisting the per-tile bias loads as well and reading the table from an LDS copy measured 0.0 %; all 16 at once would push the 192x128 kernel past 128 VGPRs = one workgroup per CU)
+        const int s0 = fast_div(row0, p.ntok, p.ntok_magic), t0 = row0 - s0 * p.ntok;
+        if (t0 + 32 <= p.ntok && !(p.has_pose_tok && t0 == 0) && p.wp >= 11) {
+            const int tt0 = p.has_pose_tok ? t0 - 1 : t0;                  // index in the patch grid
+            const int y0 = fast_div(tt0, p.wp, p.wp_magic), x0 = tt0 - y0 * p.wp;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-    float2 cs8[8];
+            for (int half = 0; half < 2; ++half) {
+                float2 cs8[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int r = half * 8 + q;
-        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        int s, t; bool pose_row;
-        qkv_row_token(p, row < p.M ? row : p.M - 1, s, t, pose_row);
-        const int pos = qkv_rope_pos(p, t, pose_row, xpart);               // table row 0 == position -1 (pose token)
-        cs8[q] = *reinterpret_cast<const float2*>(p.rope_tab + ((size_t)pos * 16 + (lane & 15)) * 2);
-    }
+                for (int q = 0; q < 8; ++q) {
+                    const int r = half * 8 + q, k = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    int x = x0 + k, y = y0;                                    // x0 < wp, k <= 31, wp >= 11: at most three wraps
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int r = half * 8 + q;
-        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        const int rowc = row < p.M ? row : p.M - 1;
-        int s, t; bool pose_row;
-        qkv_row_token(p, rowc, s, t, pose_row);
-        const float2 cs = cs8[q];
-        float v = acc[r] + bv;
-        const float other = __shfl_xor(v, 16);
-        v = (lane & 16) ? (v * cs.x + other * cs.y) : (v * cs.x - other * cs.y);
-        if (staged) {
-            const int k = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            if (SPLIT) {
-                f16 h, l; split_f16(v, h, l, ra);
-                *reinterpret_cast<f16*>(wave_lds + k * 80 + (lane & 31) * 2) = h;
-                *reinterpret_cast<f16*>(wave_lds + 32 * 80 + k * 80 + (lane & 31) * 2) = l;
-            } else *reinterpret_cast<f16*>(wave_lds + k * 80 + (lane & 31) * 2) = to_f16_sat(v, ra);
-        } else if (col_ok && row < p.M) {
-            const size_t o = ((size_t)(s * p.heads + head) * p.npad + t) * 64 + dcol;
-            if (SPLIT) { f16 h, l; split_f16(v, h, l, ra); dh[o] = h; dl[o] = l; }
-            else dh[o] = to_f16_sat(v, ra);
+                    for (int w = 0; w < 3; ++w) { const int over = x >= p.wp ? 1 : 0; x -= over * p.wp; y += over; }
+                    const int pos = (xpart ? x : y) + 1;                       // table row 0 == position -1
+                    cs8[q] = *reinterpret_cast<const float2*>(p.rope_tab + ((size_t)pos * 16 + (lane & 15)) * 2);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = half * 8 + q, k = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const float2 cs = cs8[q];
+                    float v = acc[r] + bv;
+                    const float other = __shfl_xor(v, 16);
+                    v = (lane & 16) ? (v * cs.x + other * cs.y) : (v * cs.x - other * cs.y);
+                    if (SPLIT) {
+                        f16 h, l; split_f16(v, h, l, ra);
+                        *reinterpret_cast<f16*>(wave_lds + k * 80 + (lane & 31) * 2) = h;
+                        *reinterpret_cast<f16*>(wave_lds + 32 * 80 + k * 80 + (lane & 31) * 2) = l;
+                    } else *reinterpret_cast<f16*>(wave_lds + k * 80 + (lane & 31) * 2) = to_f16_sat(v, ra);
+                }
+            }
+            const int dbase = dcol - (lane & 31);
+            const size_t obase = ((size_t)(s0 * p.heads + head) * p.npad + t0) * 64 + dbase;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int k = (lane >> 2) + 16 * half, c = lane & 3;
+                *reinterpret_cast<uint4*>(dh + obase + (size_t)k * 64 + c * 8) = *reinterpret_cast<const uint4*>(wave_lds + k * 80 + c * 16);
+                if (SPLIT) *reinterpret_cast<uint4*>(dl + obase + (size_t)k * 64 + c * 8) = *reinterpret_cast<const uint4*>(wave_lds + 32 * 80 + k * 80 + c * 16);
+            }
+            return;
         }
     }
-    }
-    if (staged) {
-        const int dbase = dcol - (lane & 31);
-        const size_t obase = ((size_t)(s0 * p.heads + head) * p.npad + t0) * 64 + dbase;
+    // General path (sequence boundaries, M tail, pose rows, small-grid family): cos / sin pairs in two batches of 8 before their
+    // stores (a table load issued behind a store waits for that store's acknowledgement; all 16 at once would push the 192x128
+    // kernel past 128 VGPRs = one workgroup per CU; hoisting the per-tile bias loads as well and an LDS copy of the table: 0.0 %)
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int k = (lane >> 2) + 16 * half, c = lane & 3;
-            *reinterpret_cast<uint4*>(dh + obase + (size_t)k * 64 + c * 8) = *reinterpret_cast<const uint4*>(wave_lds + k * 80 + c * 16);
-            if (SPLIT) *reinterpret_cast<uint4*>(dl + obase + (size_t)k * 64 + c * 8) = *reinterpret_cast<const uint4*>(wave_lds + 32 * 80 + k * 80 + c * 16);
+    for (int half = 0; half < 2; ++half) {
+        float2 cs8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = half * 8 + q;
+            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            int s, t; bool pose_row;
+            qkv_row_token(p, row < p.M ? row : p.M - 1, s, t, pose_row);
+            const int pos = qkv_rope_pos(p, t, pose_row, xpart);               // table row 0 == position -1 (pose token)
+            cs8[q] = *reinterpret_cast<const float2*>(p.rope_tab + ((size_t)pos * 16 + (lane & 15)) * 2);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = half * 8 + q;
+            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            int s, t; bool pose_row;
+            qkv_row_token(p, row < p.M ? row : p.M - 1, s, t, pose_row);
+            const float2 cs = cs8[q];
+            float v = acc[r] + bv;
+            const float other = __shfl_xor(v, 16);
+            v = (lane & 16) ? (v * cs.x + other * cs.y) : (v * cs.x - other * cs.y);
+            if (col_ok && row < p.M) {
+                const size_t o = ((size_t)(s * p.heads + head) * p.npad + t) * 64 + dcol;
+                if (SPLIT) { f16 h, l; split_f16(v, h, l, ra); dh[o] = h; dl[o] = l; }
+                else dh[o] = to_f16_sat(v, ra);
+            }
         }
     }
 }
