@@ -535,7 +535,8 @@ static inline bool small_grid(int64_t M, int N) {
 //   3: 192x256, 12 waves, one workgroup per CU, 30 % less L2->LDS traffic per FLOP: +2 % mlp.fc1 (GELU), +4 % the long-K
 //      in-place-residual GEMMs (mlp.fc2), +6 % the Cout = 256 convolutions with K >= 1728;
 //   2: 256x256, 16 waves: +5 % mlp.fc1, +10 % those convolutions, -10 % the in-place-residual epilogue;
-//   8: halo-tiled 3x3 convolution (conv3h.h; 8 x 32-pixel tiles of one image): +12 % at Cout = 256, equal at Cout = 128
+//   8: halo-tiled 3x3 convolution (conv3h.h; 8 x 32-pixel tiles of one image): +12 % at Cout = 256 (x1.47 from three
+//      well-filled rounds on), equal at Cout = 128
 //      (head.0: ties go to the halo form, which moves 1.3x instead of 6.5x the algorithmic bytes), -2.5 % with the fused head epilogue below 2M pixels, equal from there on (the benchmark's 3.1M: 1.25x instead of 6.6x the bytes);
 //   6: small-grid family (predicate above);  1: 128x128 register-staged kernel: N not a multiple of 128;
 //   7 (paired 192x128 launch) is chosen by gemm_qkv_pair.
@@ -565,7 +566,15 @@ static int pick_family(const FamilyQuery& q) {
         q.Wo >= 32 && q.M >= 16384 && q.Ho > 0) {
         const int64_t imgs = q.M / ((int64_t)q.Ho * q.Wo);
         const int64_t t8 = imgs * ((q.Ho + 7) / 8) * ((q.Wo + 31) / 32);
-        consider(8, cost(t8, 256 * q.N, q.epi == EPI_HEAD ? (q.M >= (1 << 21) ? 1.0 : 0.975) : (q.N == 128 ? 1.0 : 1.12), 0.96));
+        if (q.N == 256) {
+            // +12 % per tile against 192x128 in general (a single round: equal to 192x256 within the +-3 % the boxes differ by,
+            // which keeps its choice there), 1.47x from three well-filled rounds on (196608 pixels: 539 vs 576 / 640 us)
+            const int64_t rounds = (t8 + 255) / 256;
+            const double fill = (double)t8 / (double)(rounds * 256);
+            consider(8, (double)rounds * 256 * 256 / (fill >= 0.7 && rounds >= 3 ? 1.47 : 1.12));
+        } else {
+            consider(8, cost(t8, 256 * q.N, q.epi == EPI_HEAD ? (q.M >= (1 << 21) ? 1.0 : 0.975) : 1.0, 0.96));
+        }
     }
     return best;
 }
