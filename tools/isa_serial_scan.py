@@ -17,8 +17,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import kernel_resources as kr  # noqa: E402
 
 
-def main():
-    filt = sys.argv[1:]
+def scan():
+    """{kernel symbol: {"serial", "ld", "st"}} for every kernel of the built library."""
     with tempfile.NamedTemporaryFile(suffix=".co", delete=False) as f:
         f.write(kr.code_object(kr.LIB))
         path = f.name
@@ -46,6 +46,12 @@ def main():
                 s["serial"] += 1
             if "vmcnt(0)" in ln:
                 s["pending"] = False; s["ld_after"] = False
+    return stats
+
+
+def main():
+    filt = sys.argv[1:]
+    stats = scan()
     print("%6s %6s %6s  kernel   (serial = waits on a load issued behind a still-pending store, in program order; static count:\n"
           "                              boundary / fallback paths of a kernel are included whether or not they ever run)" % ("serial", "loads", "stores"))
     for n in sorted(stats, key=lambda n: -stats[n]["serial"]):
