@@ -1,4 +1,5 @@
-"""A few whole-path steps (8 pairs @512x384) with a forced GEMM tile family, for rocprofv3 --kernel-trace.
+"""A few whole-path steps (8 pairs @512x384; AB_B / AB_H / AB_W in the environment change that) with a forced GEMM tile family,
+for rocprofv3 --kernel-trace.
 
     rocprofv3 --kernel-trace -d gpurun_out/prof_v9 -- python tools/model_steps.py 9 [steps] [precision]
 """
@@ -12,7 +13,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 prec = sys.argv[3] if len(sys.argv) > 3 else "f16x3"
 m = STAFrontend(W.FULL, "cuda:0", precision=prec).load_procedural(seed=43)
 _lib.check(m.lib.sta_set_gemm_variant(m._h, variant))
-B, H, Wd = 8, 384, 512
+B, H, Wd = (int(os.environ.get(k, d)) for k, d in (("AB_B", 8), ("AB_H", 384), ("AB_W", 512)))      # workload: env AB_B / AB_H / AB_W
 imgs = torch.from_numpy(W.synth_images(2 * B, H, Wd, seed=43, tag=0)).cuda()
 for _ in range(steps):
     m.forward_pair(imgs[:B], imgs[B:])
