@@ -130,7 +130,14 @@ def slam_replay(model, dev, frames=120, warm=12, res=(224, 224), src_hw=(480, 64
     raw = [distinct[f % 16] for f in range(n_all)]                      # frames resident in HBM (16 distinct ones, cycled)
     torch.cuda.synchronize()
 
-    def run(nf, thres, timed):
+    main_stream = torch.cuda.current_stream(dev)
+    enc_stream = torch.cuda.Stream(device=dev)
+
+    def run(nf, thres, pipelined):
+        """pipelined: the input step + encode of frame i+1 are enqueued on a SECOND stream before the edges of frame i are
+        processed on the first (add_view of the next keyframe does not depend on the current keyframe's edges: slam.py:258 vs
+        :263-277; the library keeps one scratch context per stream) - at 224x224, batch 1 either chain alone leaves most of the
+        chip idle between its dependent dispatches, and the scheduler's host synchronisation (slam.py:169) no longer idles the GPU."""
         feats, rgbs, first = [], [], {}          # encoder feature cache; normalised frames; first node of every view: (depth, conf, K, pose)
         poses = {0: torch.eye(4, device=dev)}
         ev = {k: [] for k in ("f3", "encode", "edges", "f1")}
@@ -138,13 +145,30 @@ def slam_replay(model, dev, frames=120, warm=12, res=(224, 224), src_hw=(480, 64
 
         def mark():
             e = torch.cuda.Event(enable_timing=True); e.record(); return e
-        for i in range(nf):
+
+        def add_view(i):                        # f3 + encode of frame i on the CURRENT stream -> (feat, rgb, done event)
             t0 = mark()
             pre = process_image(model, raw[i], resolution=(Wr, Hr))
             t1 = mark()
             feat, _pos = model.encode_u8hwc(pre["u8"][None])
             t2 = mark()
-            feats.append(feat); rgbs.append(pre["rgb"])
+            ev["f3"].append((t0, t1)); ev["encode"].append((t1, t2))
+            return feat, pre["rgb"], t2
+        nxt = None
+        if pipelined:
+            with torch.cuda.stream(enc_stream):
+                nxt = add_view(0)
+        for i in range(nf):
+            if pipelined:
+                feat, rgb, done = nxt
+                if i + 1 < nf:
+                    with torch.cuda.stream(enc_stream):
+                        nxt = add_view(i + 1)
+                main_stream.wait_event(done)
+            else:
+                feat, rgb, done = add_view(i)
+            t2 = mark()
+            feats.append(feat); rgbs.append(rgb)
             far = max(0, i - neighbor_edge_num)
             calls = [list(range(far, i))]
             if far >= 8:                     # loop candidates among the views older than the neighbour window
@@ -176,7 +200,7 @@ def slam_replay(model, dev, frames=120, warm=12, res=(224, 224), src_hw=(480, 64
                     f1 = mark()
                     ev["f1"].append((f0, f1))
             t3 = mark()
-            ev["f3"].append((t0, t1)); ev["encode"].append((t1, t2)); ev["edges"].append((t2, t3))
+            ev["edges"].append((t2, t3))
         # f4: world point cloud of every view that has a node (slam.py:396-408)
         t4 = mark()
         ids = sorted(v for v in first if v in poses)
@@ -195,20 +219,159 @@ def slam_replay(model, dev, frames=120, warm=12, res=(224, 224), src_hw=(480, 64
         return ms, stats, npts, len(ids)
 
     _, st_w, _, _ = run(warm, -1.0, False)                               # warm-up: workspace, tables, threshold
+    run(warm, -1.0, True)                                                # ... and the second stream's scratch context
     conf = sorted(st_w["nonadj_conf"])
     thres = conf[int(0.4 * len(conf))] if conf else -1.0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ms_s, st_s, npts_s, _ = run(frames, thres, False)
+    dt_s = time.perf_counter() - t0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ms, st, npts, nviews = run(frames, thres, True)
     dt = time.perf_counter() - t0
     nonadj = len(st["nonadj_conf"])
     return {"frames": frames, "keyframes_per_s": round(frames / dt, 2), "ms_per_keyframe": round(dt / frames * 1e3, 3),
+            "same_result_as_single_stream": bool(npts == npts_s and st["rejected"] == st_s["rejected"] and st["edges"] == st_s["edges"]),
+            "schedule": "two streams: f3 + encode of keyframe i+1 under the edges of keyframe i (one library scratch context per stream)",
             "stage_ms_per_keyframe": {k: round(v / frames, 3) for k, v in ms.items()},
+            "single_stream": {"keyframes_per_s": round(frames / dt_s, 2), "ms_per_keyframe": round(dt_s / frames * 1e3, 3),
+                              "stage_ms_per_keyframe": {k: round(v / frames, 3) for k, v in ms_s.items()}},
             "edges_per_keyframe": round(st["edges"] / frames, 2), "rejected_frac_of_non_adjacent": round(st["rejected"] / max(1, nonadj), 3),
             "scale_edges": st["scale_edges"], "views_in_cloud": nviews, "cloud_points": npts, "source_frames": f"{Ws}x{Hs} uint8 -> {Wr}x{Hr}",
             "note": "frontend + f1-f4 rows in OnlineSLAM.step order on synthetic frames with a growing feature cache (every frame a "
                     "keyframe); the reference's CPU stages (optical-flow keyframing, ORB / DBoW3 loop detection, pypose PGO) are not part of "
                     "it and no ATE can be produced without the dataset and the checkpoint"}
+
+
+def rank_env(environ=None):
+    """(world, rank, local_rank, use_dist) from the launcher's environment (torch.distributed.run sets WORLD_SIZE / RANK /
+    LOCAL_RANK / MASTER_*).  use_dist is True whenever a launcher started us - also with ONE rank, which exercises the RCCL
+    path on a 1-GPU box.  One process per GPU: rank r of a node drives device index LOCAL_RANK of the devices visible to it
+    (HIP_VISIBLE_DEVICES, when a launcher narrows it per process, already renumbers them from 0 - then LOCAL_RANK must be 0)."""
+    env = os.environ if environ is None else environ
+    world = int(env.get("WORLD_SIZE", "1"))
+    rank = int(env.get("RANK", "0"))
+    local = int(env.get("LOCAL_RANK", "0"))
+    assert 0 <= rank < world, f"RANK={rank} outside WORLD_SIZE={world}"
+    return world, rank, local, "WORLD_SIZE" in env
+
+
+def local_device(local, visible_count):
+    """cuda:<LOCAL_RANK>, or a loud failure when the launcher handed this rank a GPU index it cannot see."""
+    assert visible_count > local, (f"LOCAL_RANK={local} but only {visible_count} GPU(s) visible to this process "
+                                   f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES', '<unset>')})")
+    return f"cuda:{local}"
+
+
+class StepRunner:
+    """One bench step = `forward()` over this rank's B pairs + (under a launcher) the step's one exchange: the compact
+    per-pair records (parallel.pack_compact: ONE kernel, written straight into the send buffer) all-gathered to every rank.
+    On a GPU the gather of step i runs on its own stream into one of two receive buffers and overlaps the forward of step
+    i+1; the closing device synchronize of the timed region waits for the last one, so every gather is inside the measured
+    time.  The same code runs on CPU tensors with the gloo backend (tests/test_dist_cpu.py: world 2, fabricated outputs)."""
+
+    def __init__(self, forward, B, H, W, world, use_dist, dev, model=None):
+        import torch
+        from vista_slam_amd import parallel as P
+        self.torch, self.P = torch, P
+        self.forward, self.B, self.H, self.W, self.world, self.use_dist, self.dev, self.model = forward, B, H, W, world, use_dist, dev, model
+        self.cuda = torch.device(dev).type == "cuda"
+        self.n = 0
+        self.gather_ev, self.gather_ms_cpu = [], []
+        self.send = self.gathered = self.comm_stream = None
+        self.sent = [None, None]
+        if use_dist:
+            width = P.compact_elems_per_pair(H, W)
+            self.send = [torch.empty(B, width, device=dev) for _ in range(2)]
+            self.gathered = [torch.empty(world * B, width, device=dev) for _ in range(2)]
+            if self.cuda:
+                self.comm_stream = torch.cuda.Stream(device=dev)
+
+    def step(self, timed=False):
+        torch, P = self.torch, self.P
+        main_o, supp_o = self.forward()
+        if self.use_dist:
+            k = self.n & 1
+            if self.cuda:
+                if self.sent[k] is not None:                 # the gather of step n-2 read this send buffer: it must be done
+                    torch.cuda.current_stream(self.dev).wait_event(self.sent[k])
+                P.pack_compact(main_o, supp_o, model=self.model, out=self.send[k])
+                ready = torch.cuda.Event(); ready.record()
+                with torch.cuda.stream(self.comm_stream):
+                    self.comm_stream.wait_event(ready)
+                    if timed:
+                        e0 = torch.cuda.Event(enable_timing=True); e0.record()
+                    P.gather_compact(self.send[k], self.world * self.B, out=self.gathered[k])
+                    if timed:
+                        e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                        self.gather_ev.append((e0, e1))
+                    self.sent[k] = torch.cuda.Event(); self.sent[k].record()
+            else:
+                P.pack_compact(main_o, supp_o, model=None, out=self.send[k])
+                t0 = time.perf_counter()
+                P.gather_compact(self.send[k], self.world * self.B, out=self.gathered[k])
+                if timed:
+                    self.gather_ms_cpu.append((time.perf_counter() - t0) * 1e3)
+            self.n += 1
+        return main_o, supp_o
+
+    def last_gathered(self):
+        return None if not self.use_dist or self.n == 0 else self.gathered[(self.n - 1) & 1]
+
+    def gather_ms(self):
+        if self.cuda:
+            return sorted(a.elapsed_time(b) for a, b in self.gather_ev)
+        return sorted(self.gather_ms_cpu)
+
+
+def timed_region(runner, steps, warmup_done=True):
+    """EXACTLY `steps` steps between two (barrier + device synchronize) brackets -> (wall seconds of this rank, sorted per-step
+    ms from stream events on a GPU / host clocks on CPU, last outputs)."""
+    import torch
+    import torch.distributed as dist
+    cuda = runner.cuda
+
+    def fence():
+        if cuda:
+            torch.cuda.synchronize()
+        if runner.use_dist:
+            dist.barrier()
+    fence()
+    marks = []
+
+    def mark():
+        if cuda:
+            e = torch.cuda.Event(enable_timing=True); e.record(); marks.append(e)
+        else:
+            marks.append(time.perf_counter())
+    t0 = time.perf_counter()
+    mark()
+    out = None
+    for _ in range(steps):
+        out = runner.step(timed=True)
+        mark()                          # stream-ordered marker, no host sync inside the timed region
+    fence()                             # all streams of the device, the communication stream included
+    dt = time.perf_counter() - t0
+    if cuda:
+        step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    else:
+        step_ms = sorted((marks[i + 1] - marks[i]) * 1e3 for i in range(steps))
+    return dt, step_ms, out
+
+
+def distributed_fields(runner, dt, steps):
+    """MAX over ranks of the timed wall clock + the per-rank rates and the gather statistics of the JSON line."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([dt], device=runner.dev, dtype=torch.float64)
+    allt = [torch.zeros_like(t) for _ in range(runner.world)]
+    dist.all_gather(allt, t)
+    g = runner.gather_ms()
+    return max(float(x.item()) for x in allt), {
+        "per_rank_pairs_per_s": [round(runner.B * steps / float(x.item()), 3) for x in allt],
+        "all_gather_ms_median": round(g[len(g) // 2], 4) if g else None,
+        "all_gather_bytes_per_rank": int(runner.B * runner.P.compact_elems_per_pair(runner.H, runner.W) * 4)}
 
 
 def host_cores():
@@ -298,16 +461,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default="f16x3h", choices=["f16x3h", "f16x3", "f16"])
+    ap.add_argument("--precision", default="f16x3h", choices=["f16x3h", "f16x3"])
     ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="image pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-224", action="store_true", help="time the oracle on one 224x224 pair (4.3x less work) instead of 512x384")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-slam-probe", action="store_true")
     ap.add_argument("--slam-frames", type=int, default=120, help="frames of the slam_replay section (0 = skip)")
-    ap.add_argument("--no-alt-precision", action="store_true", help="skip the extra timed loop with two concurrent batch slices")
     ap.add_argument("--gemm-variant", type=int, default=0, help="experiments only: force a GEMM tile family (0 = product selection)")
-    ap.add_argument("--slices", type=int, default=1, help="batch slices run concurrently on internal streams (1 or 2)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -327,56 +488,27 @@ def main():
     from vista_slam_amd import weights as Wt
     from vista_slam_amd.sta_frontend import STAFrontend
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    use_dist = "WORLD_SIZE" in os.environ          # under a launcher (also with one rank: exercises the RCCL path on a 1-GPU box)
+    world, rank, local, use_dist = rank_env()
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.device_count() > local, f"rank {rank}: local GPU {local} not visible ({torch.cuda.device_count()} devices)"
+    dev = local_device(local, torch.cuda.device_count())
     torch.cuda.set_device(local)
-    dev = f"cuda:{local}"
 
-    model = STAFrontend(Wt.FULL, dev, precision=args.precision).load_procedural(seed=43)
+    model = STAFrontend(Wt.FULL, dev, precision=args.precision).load_procedural(seed=43)      # sta_create(device = LOCAL_RANK)
     if args.gemm_variant:
         from vista_slam_amd import _lib
         _lib.check(model.lib.sta_set_gemm_variant(model._h, args.gemm_variant))
-    model.set_concurrency(args.slices)
     B = args.pairs
     imgs = Wt.synth_images(2 * B, H, W_, seed=43, tag=rank)          # different pairs on every rank
     img_a = torch.from_numpy(imgs[:B]).to(dev)
     img_b = torch.from_numpy(imgs[B:]).to(dev)
 
     from vista_slam_amd import parallel as P
-    gathered = comm_stream = None
-    if use_dist:
-        # the all-gather of step i runs on its own stream and overlaps the forward of step i+1 (two receive buffers); the
-        # closing synchronize of the timed region waits for the last one, so every gather is inside the measured time
-        gathered = [torch.empty(world * B, P.compact_elems_per_pair(H, W_), device=dev) for _ in range(2)]
-        comm_stream = torch.cuda.Stream(device=dev)
-
-    gather_ev = []
-    step_no = [0]
-
-    def step(timed=False):
-        main_o, supp_o = model.forward_pair(img_a, img_b)
-        if use_dist:    # compact per-pair outputs -> every rank (slam.py consumes pose, conf, depth, conf map)
-            packed = P.pack_compact(main_o, supp_o)
-            ready = torch.cuda.Event(); ready.record()
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(ready)
-                if timed:
-                    e0 = torch.cuda.Event(enable_timing=True); e0.record()
-                P.gather_compact(packed, world * B, out=gathered[step_no[0] & 1])
-                if timed:
-                    e1 = torch.cuda.Event(enable_timing=True); e1.record()
-                    gather_ev.append((e0, e1))
-            packed.record_stream(comm_stream)
-            step_no[0] += 1
-        return main_o, supp_o
+    runner = StepRunner(lambda: model.forward_pair(img_a, img_b), B, H, W_, world, use_dist, dev, model=model)
+    step = runner.step
 
     for _ in range(args.warmup):
         step()
@@ -396,30 +528,11 @@ def main():
         model.kernel_timing(False)
         model.lib.sta_kernel_timing_filter(model._h, dom["epi"], dom["amode"], dom["fam"], dom["mx"])
         model.kernel_timing(3)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    step_ev[0].record()
-    for i in range(args.steps):
-        out = step(timed=True)
-        step_ev[i + 1].record()             # stream-ordered marker, no host sync inside the timed region
-    torch.cuda.synchronize()            # all streams of the device, the communication stream included
-    if use_dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    my_dt = dt
-    step_ms = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps))
+    dt, step_ms, out = timed_region(runner, args.steps)
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
-    per_rank = None
+    dist_fields = None
     if use_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        allt = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(allt, t)
-        per_rank = [round(B * args.steps / float(x.item()), 3) for x in allt]
-        dt = max(float(x.item()) for x in allt)
-    gather_ms = sorted(a.elapsed_time(b) for a, b in gather_ev)
+        dt, dist_fields = distributed_fields(runner, dt, args.steps)
     assert bool(torch.isfinite(out[0]["pts3d_pred"]).all()), "non-finite output"
 
     roof = None
@@ -435,7 +548,7 @@ def main():
         if groups:
             sym, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
             ach = g["fl"] / (g["ms"] * 1e-3) / 1e12
-            prod = 1 if args.precision == "f16" else (2 if g["mx"] else 3)
+            prod = 2 if g["mx"] else 3
             traffic, traffic_src = pmc_traffic(sym)
             tot_ms = sum(x["ms"] for x in symtab.values())          # survey step: all symbols, one step
             roof = {"bound": "mfma", "kernel": sym + " - " + ("3x3 convolution, " if g["amode"] else "") + epi_name[g["epi"]],
@@ -461,8 +574,7 @@ def main():
                "value_at_median_step": round(B * world / (median_ms * 1e-3), 3),
                "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": {"f16x3": "f16x3-split MFMA (3 fp16 products per contraction), fp32 accumulate",
-                                             "f16x3h": "f16x3-split MFMA (3 fp16 products) in the transformer and the pose head; fp16 MFMA + one block-scaled fp8 correction MFMA in the DPT head's convolutions; fp32 accumulate",
-                                             "f16": "f16 MFMA, fp32 accumulate"}[args.precision],
+                                             "f16x3h": "f16x3-split MFMA (3 fp16 products) in the transformer and the pose head; fp16 MFMA + one block-scaled fp8 correction MFMA in the DPT head's convolutions; fp32 accumulate"}[args.precision],
                "data": "synthetic (uint8-uniform RGB pairs, procedural weights of the full 438M-parameter architecture)",
                "config": {"workload": f"512x384 batch={B} pairs/GPU STA two-view forward (BASELINE configs[1])",
                           "pairs_per_gpu": B, "H": H, "W": W_, "precision": args.precision,
@@ -473,26 +585,7 @@ def main():
                "workspace_gb": round(model.workspace_bytes() / 1e9, 2),
                "roofline": roof}
         if use_dist:
-            res["per_rank_pairs_per_s"] = per_rank
-            res["all_gather_ms_median"] = round(gather_ms[len(gather_ms) // 2], 4) if gather_ms else None
-            res["all_gather_bytes_per_rank"] = int(B * P.compact_elems_per_pair(H, W_) * 4)
-        if world == 1 and args.slices == 1 and not args.no_alt_precision:
-            # the same K steps with the batch split into two slices on internal streams (sta_set_concurrency(2)): a product
-            # mode with identical outputs (tests/test_gpu_parity.py); not the default `value` because per-kernel durations -
-            # and with them the roofline object - are not attributable while two kernels share the chip
-            model.set_concurrency(2)
-            for _ in range(2):
-                step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            torch.cuda.synchronize()
-            dt3 = time.perf_counter() - t1
-            model.set_concurrency(1)
-            res["two_slice_concurrency"] = {"value": round(B * args.steps / dt3, 3), "unit": "pairs/s", "ms_per_step": round(dt3 / args.steps * 1e3, 3),
-                                            "note": "same precision, same inputs, bit-identical per-slice arithmetic; `python bench.py --slices 2` "
-                                                    "times it as the main region"}
+            res.update(dist_fields)
         if world == 1 and not args.no_slam_probe:
             res["slam_224_b1"] = slam_probe(model, dev)
             if args.slam_frames > 0:

@@ -23,12 +23,13 @@
  * Conventions
  *   - Plain C types only.  All *_dev pointers are device (HBM) pointers owned by the caller
  *     (the Python shim passes torch-ROCm tensor .data_ptr()).  The library owns only weights
- *     and an internal workspace; the workspace grows on the first call of a new shape and is
- *     then reused (no allocation in steady state).
+ *     and an internal workspace per caller stream; a workspace grows on the first call of a new shape
+ *     and is then reused (no allocation in steady state).
  *   - All work is enqueued on the caller-supplied hipStream_t (`stream`, passed as void*);
  *     no host synchronisation inside, so ordering with surrounding torch ops is preserved.
  *   - Return value: 0 on success, negative on error; sta_last_error() returns a thread-local
- *     message.  A handle is not thread-safe; one handle per device.
+ *     message.  A handle is not thread-safe (one host thread at a time; several STREAMS are fine, see
+ *     "Streams and concurrency" below); one handle per device.
  *   - Images are NCHW fp32 in [-1,1]; H and W must be multiples of 16.  Portrait frames (H > W) are tokenised row-major
  *     as they are (PatchEmbedDust3R, patch_embed.py:15-26) and every per-pixel output of this ABI is in IMAGE orientation
  *     [.., H, W, ..].  The reference's head wrapper returns portrait outputs as transposed VIEWS of exactly that memory
@@ -96,12 +97,14 @@ int sta_set_precision(sta_handle* h, int precision);
  * Default: off. */
 int sta_set_deterministic(sta_handle* h, int on);
 
-/* Batch-slice concurrency of sta_forward_pair*: 1 = one slice on the caller's stream (default); n = 2..4: the batch is cut
- * in n slices that run on n library-owned streams, forked from / joined to the caller's stream by events, so the
- * hardware overlaps one slice's GEMM tail rounds and HBM-bound kernels with the other's MFMA main loops.  Results are
- * identical per pair (no cross-pair arithmetic).  No reference counterpart (torch runs one stream).  (Worth +2.5 .. 5.8 %
- * through round 2; since the round-3 epilogues the single stream has no such tails left: -5 .. +0.7 %.) */
-int sta_set_concurrency(sta_handle* h, int n_slices);
+/* Streams and concurrency.  Every call enqueues on the caller's stream; the handle keeps ONE scratch context (workspace +
+ * split-K buffers) PER STREAM it has been called on (at most 8), created on the first call on that stream.  Calls on
+ * different streams therefore never share scratch memory and may overlap on the GPU - the intended use is the SLAM loop's
+ * own independence: sta_encode of keyframe i+1 (add_view, slam.py:142-151, 258) on a second stream under
+ * sta_regress_views of keyframe i (slam.py:263-277); at 224x224, batch 1 each of them alone leaves most of the chip idle
+ * between its ~200 dependent dispatches.  Host-side the handle is still single-threaded (one call at a time).
+ * (Rounds 2-3 had sta_set_concurrency(h, n): batch slices of ONE forward on library-owned streams.  It stopped paying once
+ * the epilogues no longer serialised - -1 % at the headline configuration in round 3 - and was removed in round 4.) */
 
 /* Range report.  Activations travel between kernels as fp16 planes (hi + residual), the f16mx arithmetic of the DPT head adds
  * fp8 correction bytes (activations e5m2, weights e4m3): values beyond +-65504 (or NaN) SATURATE when they are written to a
@@ -243,6 +246,27 @@ int sta_regress_views(sta_handle* h, const float* feat_i, const float* const* fe
                       const uint8_t* adjacent, float rel_pose_thres, int H, int W,
                       float* pose, float* pose_conf_host, int* slot_host, int* n_accepted,
                       float* pts, float* conf, float* K, float* depth, void* stream);
+
+/* The same call in two phases, so that the host can enqueue other work between them (e.g. the decode of the NEXT keyframe's
+ * edges on another stream while this keyframe's DPT heads run; the next keyframe's edges need only encoder features):
+ *   sta_regress_views_begin : gather + batched decode + pose head on `stream`; the k confidences travel to a pinned host
+ *                             buffer behind an event.  No host synchronisation.  `pose` [k,16] device as above.
+ *   sta_regress_views_finish: waits for that event only, takes the accept / reject decisions (slam.py:169), and enqueues the
+ *                             DPT heads + intrinsics + depths of the accepted edges; host outputs valid on return.
+ * The pending call owns its stream's scratch context: between begin and finish no other call of this handle may run on
+ * THAT stream (it fails loudly); calls on other streams are fine.  sta_regress_views == begin immediately followed by finish. */
+int sta_regress_views_begin(sta_handle* h, const float* feat_i, const float* const* feat_j, int k, int H, int W,
+                            float* pose, void* stream);
+int sta_regress_views_finish(sta_handle* h, const uint8_t* adjacent, float rel_pose_thres,
+                             float* pose_conf_host, int* slot_host, int* n_accepted,
+                             float* pts, float* conf, float* K, float* depth, void* stream);
+
+/* the compact per-pair record of one step's all-gather (vista_slam_amd/parallel.py; what a SLAM consumer
+ * reads of a pair, slam.py:165-185), packed from the outputs of sta_forward_pair* in one launch.  Row b of out_dev
+ * (rows `row_stride` floats apart, >= 2 * (17 + 2*H*W)) = for view 0 (main) then view 1 (support):
+ * pose[16] | pose_conf | depth = pts[..., 2] [H*W] | conf [H*W].  Inputs as sta_forward_pair wrote them (image orientation). */
+int sta_pack_compact(sta_handle* h, const float* const pts[2], const float* const conf[2], const float* const pose[2],
+                     const float* const pose_conf[2], int B, int H, int W, float* out_dev, int64_t row_stride, void* stream);
 
 /* In-place 2-D RoPE on fp32 tokens (B,N,Hh,D) with element strides (stride of D must be 1,
  * stride of Hh must be D; same contract as kernels.cu:91-94); pos int64 [B,N,2] contiguous. */

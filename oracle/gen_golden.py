@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 from vista_slam_amd import weights as W          # noqa: E402
 from oracle.ref_import import load_reference_model   # noqa: E402
 
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("STA_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden"))   # STA_GOLDEN_OUT: oracle/check_oracle_vs_ref.py regenerates into a scratch directory
 torch.set_grad_enabled(False)
 
 
@@ -87,6 +87,11 @@ def run_case(name, cfg, H, W_, B, qk_gain=1.0, taps=False, sub=1, smooth=False, 
     d1, d2 = model._decode_stereo(fa, fb, pa, pb)
     hooks = cfg.hooks
     tsub = max(1, sub)
+    # the integer position output of _encode_image (PositionGetter, sta_blocks.py:241-247; stored per keyframe by slam.py:144
+    # and fed back at :162): [B, N, 2] int64 (y, x) - compared bit-exactly
+    res["pos_a"] = pa.numpy().copy()
+    res["pos_b"] = pb.numpy().copy()
+    assert res["pos_a"].dtype == np.int64
     res["enc_feat_a"] = fa.numpy()[:, ::tsub].copy()
     res["enc_feat_b"] = fb.numpy()[:, ::tsub].copy()
     res["enc_feat_a_l2"] = np.sqrt((fa.double().numpy() ** 2).sum(axis=(1, 2)))
@@ -345,7 +350,6 @@ def gen_f2(name, cfg, H, W_, nview, sub=1, seed=43, tag=21):
 
 
 CASES = {
-    "sharpfull": [dict(name="full_224_b1_sharp", cfg=W.FULL, H=224, W_=224, B=1, sub=8, qk_gain=3.0)],
     "tiny": [
         dict(name="tiny_32x32_b1", cfg=W.TINY, H=32, W_=32, B=1, taps=True),
         dict(name="tiny_48x64_b2", cfg=W.TINY, H=48, W_=64, B=2),
@@ -381,6 +385,17 @@ CASES = {
     ],
     "full512": [
         dict(name="full_384x512_b1", cfg=W.FULL, H=384, W_=512, B=1, sub=16),
+    ],
+    # round 4: peaky attention and checkpoint-like range statistics AT THE HEADLINE RESOLUTION (nq = 768: pose side blocks,
+    # 12 full key tiles, the 192x128 / 192x256 / 256x256 GEMM families and the fused DPT tail on the halo kernel are paths the
+    # 224x224 goldens never take), and two more full-depth sharp seeds at the SLAM resolution (smooth + noisy frames)
+    "stress512": [
+        dict(name="full_384x512_b1_sharp", cfg=W.FULL, H=384, W_=512, B=1, sub=16, qk_gain=3.0),
+        dict(name="full_384x512_b1_outlier", cfg=W.FULL, H=384, W_=512, B=1, sub=16, outlier=1),
+    ],
+    "stress224": [
+        dict(name="full_224_b1_sharp_s44_smooth", cfg=W.FULL, H=224, W_=224, B=1, sub=8, qk_gain=3.0, seed=44, smooth=True),
+        dict(name="full_224_b1_sharp_s45", cfg=W.FULL, H=224, W_=224, B=1, sub=8, qk_gain=3.0, seed=45),
     ],
     # two DIFFERENT pairs at the benchmark resolution: the batch-8 parity test fills every batch slot with one of them
     "full512b2": [

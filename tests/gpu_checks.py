@@ -345,6 +345,12 @@ def run_golden_case(name, precision, taps=True, variant=0):
     d1, d2 = m._decode_stereo(fa, fb, pa, pb)
     torch.cuda.synchronize()
     tsub = max(1, sub)
+    # the integer output of _encode_image (PositionGetter, sta_blocks.py:241-247; slam.py:144 stores it per keyframe and feeds it
+    # back at :162): bit-exact - dtype, shape and every entry (0.0 = identical, 1.0 = not; the callers compare with a tolerance)
+    for key, got in (("pos_a", pa), ("pos_b", pb)):
+        want = g[key]
+        gotn = got.cpu().numpy()
+        res[key] = 0.0 if (got.dtype == torch.int64 and gotn.shape == want.shape and want.dtype == np.int64 and np.array_equal(gotn, want)) else 1.0
     res["enc_feat_a"] = rel_l2(fa.cpu().numpy()[:, ::tsub], g["enc_feat_a"])
     res["enc_feat_b"] = rel_l2(fb.cpu().numpy()[:, ::tsub], g["enc_feat_b"])
     for hk in cfg.hooks[1:]:

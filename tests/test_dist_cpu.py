@@ -136,3 +136,73 @@ def test_pack_edges_portrait_views_round_trip_and_reject_mismatched_dims():
     out = P.gather_edges(P.pack_edges(edges, Wi, Hi, device="cpu"), 2, Wi, Hi)
     for e, d in zip(edges, out):
         assert torch.equal(d["depths"], e.depths) and torch.equal(d["confs"], e.confs)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# bench.py's own step / timing / reporting code under two ranks (the driver's --gpus N run is the first time it meets more
+# than one RCCL rank: everything but the backend and the device is exercised here, on gloo + CPU tensors).
+def _bench_worker(rank, world, port, ret):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    env = {"WORLD_SIZE": str(world), "RANK": str(rank), "LOCAL_RANK": str(rank), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}
+    os.environ.update(env)
+    w, r, local, use_dist = bench.rank_env()
+    assert (w, r, local, use_dist) == (world, rank, rank, True)
+    dist.init_process_group("gloo", rank=r, world_size=w)
+    try:
+        B = 3
+        ids = list(range(r * B, (r + 1) * B))                 # rank r owns pairs [r*B, (r+1)*B): weak scaling, B pairs per rank
+        calls = [0]
+
+        def forward():
+            calls[0] += 1
+            return fake_outputs(ids)
+        runner = bench.StepRunner(forward, B, H, W_, w, use_dist, "cpu", model=None)
+        for _ in range(2):
+            runner.step()                                      # warm-up, untimed
+        steps = 5
+        dt, step_ms, out = bench.timed_region(runner, steps)
+        assert calls[0] == 2 + steps and len(step_ms) == steps and dt > 0       # EXACTLY K timed steps
+        dt_max, fields = bench.distributed_fields(runner, dt, steps)
+        ok = dt_max >= dt and len(fields["per_rank_pairs_per_s"]) == world and fields["all_gather_ms_median"] is not None
+        ok &= fields["all_gather_bytes_per_rank"] == B * P.compact_elems_per_pair(H, W_) * 4
+        # the last step's receive buffer holds every rank's records in global pair order
+        gm, gs = P.unpack_compact(runner.last_gathered(), H, W_)
+        rm, rs = fake_outputs(list(range(world * B)))
+        for got, ref in ((gm, rm), (gs, rs)):
+            ok &= torch.equal(got["relative_pose"], ref["relative_pose"]) and torch.equal(got["depth"], ref["pts3d_pred"][..., 2])
+            ok &= torch.equal(got["conf"], ref["conf"]) and torch.equal(got["relative_pose_conf"], ref["relative_pose_conf"])
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_step_runner_two_ranks_gloo():
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_bench_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_bench_rank_env_and_local_device(monkeypatch):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    assert bench.rank_env({}) == (1, 0, 0, False)                                   # bare `python bench.py`
+    assert bench.rank_env({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}) == (1, 0, 0, True)    # one rank under a launcher: RCCL path
+    assert bench.rank_env({"WORLD_SIZE": "8", "RANK": "5", "LOCAL_RANK": "5"}) == (8, 5, 5, True)
+    with pytest.raises(AssertionError):
+        bench.rank_env({"WORLD_SIZE": "2", "RANK": "2", "LOCAL_RANK": "0"})
+    assert bench.local_device(3, 8) == "cuda:3"                                       # sta_create(device = LOCAL_RANK)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")
+    with pytest.raises(AssertionError, match="HIP_VISIBLE_DEVICES=0"):
+        bench.local_device(1, 1)                                                      # a launcher narrowed the devices but kept LOCAL_RANK
+
+
+def test_pack_compact_into_a_given_buffer_cpu():
+    main, supp = fake_outputs([4, 7])
+    want = P.pack_compact(main, supp)
+    out = torch.full_like(want, -1.0)
+    got = P.pack_compact(main, supp, model=None, out=out)
+    assert got.data_ptr() == out.data_ptr() and torch.equal(out, want)

@@ -76,6 +76,10 @@ def test_forward_vs_reference_golden(case):
         errs[f"{side}_pose"] = rel_l2(r[side]["pose"], g[f"{side}_pose"])
         errs[f"{side}_pose_conf"] = rel_l2(r[side]["pose_conf"], g[f"{side}_pose_conf"])
     errs["enc_feat_a"] = rel_l2(r["enc_feat_a"], g["enc_feat_a"])
+    # integer positions of _encode_image (PositionGetter, sta_blocks.py:241-247): bit-exact
+    hp, wp = H // 16, W_ // 16
+    pos = O.positions(B, hp, wp)
+    assert pos.dtype == np.int64 and np.array_equal(pos, g["pos_a"]) and np.array_equal(pos, g["pos_b"])
     for hk in W.TINY.hooks[1:]:
         errs[f"dec1_hook{hk - 1}"] = rel_l2(r["dec1"][hk - 1], g[f"dec1_hook{hk - 1}"])
         errs[f"dec2_hook{hk - 1}"] = rel_l2(r["dec2"][hk - 1], g[f"dec2_hook{hk - 1}"])

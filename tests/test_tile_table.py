@@ -56,7 +56,11 @@ def test_table_covers_the_survey_shapes():
 
 
 def test_picked_family_is_current_and_within_3_percent_of_best():
+    """(Needs the built library - pick_family is a host function inside it - but no GPU.  When the cost-model constants are
+    retuned the table must be re-measured with tools/tile_table.py on an MI355X and committed; `stale` below says so.)"""
     from vista_slam_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libsta_mi355.so not built here (python -m vista_slam_amd.build)")
     lib = _lib.load()
     stale, slow = [], []
     for x in rows():

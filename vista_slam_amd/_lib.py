@@ -31,7 +31,6 @@ SIGNATURES = {
     "sta_create": (_i, [C.POINTER(StaConfig), _i, C.POINTER(_vp)]),
     "sta_destroy": (_i, [_vp]),
     "sta_set_precision": (_i, [_vp, _i]),
-    "sta_set_concurrency": (_i, [_vp, _i]),
     "sta_set_deterministic": (_i, [_vp, _i]),
     "sta_num_expected_tensors": (_i, [_vp]),
     "sta_num_loaded_tensors": (_i, [_vp]),
@@ -55,6 +54,9 @@ SIGNATURES = {
     "sta_mat_to_se3": (_i, [_vp, _fp, _i, _fp, _vp]),
     "sta_regress_views": (_i, [_vp, _fp, C.POINTER(_vp), _i, C.c_char_p, _f, _i, _i, _fp, C.POINTER(C.c_float),
                                C.POINTER(_i), C.POINTER(_i), _fp, _fp, _fp, _fp, _vp]),
+    "sta_regress_views_begin": (_i, [_vp, _fp, C.POINTER(_vp), _i, _i, _i, _fp, _vp]),
+    "sta_regress_views_finish": (_i, [_vp, C.c_char_p, _f, C.POINTER(C.c_float), C.POINTER(_i), C.POINTER(_i), _fp, _fp, _fp, _fp, _vp]),
+    "sta_pack_compact": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _fp, _i64, _vp]),
     "sta_rope2d_inplace": (_i, [_fp, _i64, _i64, _vp, _i, _i, _i, _i, _f, _f, _vp]),
     "sta_rope2d_inplace_dtype": (_i, [_vp, _i, _i64, _i64, _vp, _i, _i, _i, _i, _f, _f, _vp]),
     "sta_flops_per_pair": (C.c_double, [_vp, _i, _i]),

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)p.C + p.eps);
-    if (lane == 0 && !(fabsf(mean) <= 3.0e38f && rstd <= 3.0e38f)) atomicAdd(&g_sta_range[0], 1ull);   // non-finite row (range report)
+    if (lane == 0 && !(fabsf(mean) <= 3.0e38f && rstd <= 3.0e38f && rstd > 0.f)) atomicAdd(&g_sta_range[0], 1ull);   // non-finite row, or a variance that overflowed fp32 (rstd == 0: the row would silently become pure bias)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int idx = (i * 64 + lane) * 4;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void resid_ln_kernel(const LnParams p) {
     if (lane == 0) red[1][wave] = sq;
     __syncthreads();
     const float rstd = 1.0f / sqrtf(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)p.C + p.eps);
-    if (threadIdx.x == 0 && !(fabsf(mean) <= 3.0e38f && rstd <= 3.0e38f)) atomicAdd(&g_sta_range[0], 1ull);   // non-finite row (range report)
+    if (threadIdx.x == 0 && !(fabsf(mean) <= 3.0e38f && rstd <= 3.0e38f && rstd > 0.f)) atomicAdd(&g_sta_range[0], 1ull);   // non-finite row, or a variance that overflowed fp32 (rstd == 0: the row would silently become pure bias)
     if (on) {
         float n[4] = {(v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd};
         ln_store4<SPLIT>(p, row, idx, n, af);
@@ -679,6 +679,21 @@ __global__ __launch_bounds__(256) void gather_chunks_kernel(GatherChunks g) {
     uint4* d = g.dst[blockIdx.y];
     const int64_t n = g.n16[blockIdx.y];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = s[i];
+}
+
+// Row (e): the compact per-pair record a SLAM consumer reads (slam.py:165-185) - per view pose 4x4, pose confidence,
+// depth = pts[..., 2], confidence map - packed for the one all-gather of a step (vista_slam_amd/parallel.py).
+// Row b of out = [view 0: pose16 | pose_conf | depth HW | conf HW][view 1: the same]; blockIdx.y = b * 2 + view.
+struct PackCompact { const float* pts[2]; const float* conf[2]; const float* pose[2]; const float* pose_conf[2]; float* out; int64_t hw; int64_t row_stride; };
+__global__ __launch_bounds__(256) void pack_compact_kernel(PackCompact g) {
+    const int b = blockIdx.y >> 1, v = blockIdx.y & 1;
+    float* o = g.out + (size_t)b * g.row_stride + (size_t)v * (17 + 2 * g.hw);
+    const float* pts = g.pts[v] + (size_t)b * g.hw * 3;
+    const float* cf = g.conf[v] + (size_t)b * g.hw;
+    if (blockIdx.x == 0 && threadIdx.x < 17) o[threadIdx.x] = threadIdx.x < 16 ? g.pose[v][(size_t)b * 16 + threadIdx.x] : g.pose_conf[v][b];
+    o += 17;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * g.hw; i += (int64_t)gridDim.x * blockDim.x)
+        o[i] = i < g.hw ? pts[i * 3 + 2] : cf[i - g.hw];
 }
 
 // ---------------------------------------------------------------------------------------------------------

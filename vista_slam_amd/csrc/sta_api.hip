@@ -80,7 +80,21 @@ struct Slot {
 };
 
 static const int64_t SKBUF_ELEMS = (int64_t)4 << 20;   // 16 MiB: M*N of the largest split-K plane-epilogue GEMM
-static const int SKBUF_SLOTS = 5;                      // caller's stream + the 4 internal slice streams: concurrent slices must not share it
+// Execution context of ONE caller stream: everything a call writes between its kernels.  The handle keeps one context per
+// stream it has been called on (stream_ctx), so calls enqueued on DIFFERENT streams never share scratch memory and may run
+// concurrently on the GPU - e.g. sta_encode of keyframe i+1 on a second stream under sta_regress_views of keyframe i
+// (independent in OnlineSLAM.step: slam.py:258 vs :263-277).  Weights, tables and the zero page are read-only and shared.
+static const int MAX_STREAM_CTX = 8;
+struct StreamCtx {
+    hipStream_t st = nullptr;
+    char* ws = nullptr; int64_t ws_cap = 0;   // bump-allocated workspace, sized by the dry planning pass of the call
+    float* skbuf = nullptr;   // fp32 partial sums of split-K GEMMs with the plane / QKV epilogue (SKBUF_ELEMS floats)
+    float* slab = nullptr;    // slab split-K of the small-M in-place residual GEMMs (GemmParams::slab), same size
+    // split-phase keyframe scheduler (sta_regress_views_begin / _finish): the call pending on this stream
+    bool rv_open = false; int rv_k = 0, rv_H = 0, rv_W = 0;
+    float* rv_conf = nullptr;         // pinned host copy of the k pose confidences (async D2H in begin, read in finish)
+    hipEvent_t rv_ev = nullptr;       // recorded behind that copy
+};
 
 struct sta_handle {
     sta_config cfg;
@@ -102,10 +116,9 @@ struct sta_handle {
     F32Lin pm0, pm1, pm2, pt, pr, pc;
     // staging + workspace
     float* stage = nullptr; int64_t stage_elems = 0;
-    char* ws = nullptr; int64_t ws_cap = 0;
+    std::vector<StreamCtx> ctx; StreamCtx* cur = nullptr;     // per-stream scratch (stream_ctx); cur = the context of the running call
     f16* zero_page = nullptr;
-    float* skbuf = nullptr;   // fp32 partial sums of split-K GEMMs with the plane epilogue (SKBUF_SLOTS x SKBUF_ELEMS floats)
-    float* slab = nullptr;    // slab split-K of the small-M in-place residual GEMMs (GemmParams::slab), same slots and size as skbuf
+    int small_grid_mode = 0;  // tools/tile_table.py only (sta_set_gemm_variant 10 / 11): 1 = never the small-grid family, 2 = 4x the product threshold
     int opt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // experiment switches (sta_debug_set_option; 0 = product behaviour)
     int tail_hint = 0;      // decode_impl: the last tail_hint rows of every dense GEMM are pose-token rows (GemmParams::m_tail)
     int gemm_variant = 0;   // tests / tools: 0 auto, 1..4 forced GEMM families, 8 = conv3h wherever legal, 9 = auto WITHOUT conv3h (A/B)
@@ -118,8 +131,6 @@ struct sta_handle {
     bool ktime = false; std::vector<hipEvent_t> kev; int kn = 0; std::vector<double> kflops, kbytes; std::vector<int> kvar;
     int kfilter[4] = {-1, -1, -1, -1};    // mode 3: {epilogue, A-loader, tile family, mx} of the one kernel symbol that is timed
     bool ktime_all = false; std::vector<int> kshape;   // sta_kernel_timing(h, 2): every GEMM / conv launch is timed; {M, N, K, EPI, AMODE, mx} per record
-    // optional two-slice concurrency (sta_set_concurrency)
-    int n_streams = 1; hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     // f3 input-step tables (one cached geometry)
     int pre_key[6] = {0, 0, 0, 0, 0, 0}; int* pre_tab = nullptr; int64_t pre_cap = 0; int pre_meta[12] = {0};
     bool dry = false;   // planning pass: run the orchestration without launching to size the workspace
@@ -154,26 +165,32 @@ struct Bump {
     }
 };
 
-static int ensure_streams(sta_handle* h) {
-    if (h->aux[0]) return 0;
-    HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    for (int i = 0; i < 4; ++i) {
-        HIPCHK(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
-    }
+// The context of stream `st` becomes the current one (created on the first call on that stream: 2 x 16 MiB of split-K scratch;
+// the workspace grows with the first call of a shape).  At most MAX_STREAM_CTX streams per handle.
+static int stream_ctx(sta_handle* h, hipStream_t st) {
+    for (auto& c : h->ctx) if (c.st == st) { h->cur = &c; return 0; }
+    REQUIRE((int)h->ctx.size() < MAX_STREAM_CTX, "this handle has already been used on %d different streams (one scratch context per stream)", MAX_STREAM_CTX);
+    StreamCtx c; c.st = st;
+    HIPCHK(hipMalloc((void**)&c.skbuf, (size_t)SKBUF_ELEMS * 4));
+    if (hipMalloc((void**)&c.slab, (size_t)SKBUF_ELEMS * 4) != hipSuccess) { hipFree(c.skbuf); return set_err("split-K slab alloc failed"); }
+    h->ctx.push_back(c);          // (reserve()d in sta_create: pointers into the vector stay valid)
+    h->cur = &h->ctx.back();
+    return 0;
+}
+static int ensure_ws(sta_handle* h, int64_t bytes, hipStream_t st) {
+    CHK(stream_ctx(h, st));
+    StreamCtx& c = *h->cur;
+    if (bytes <= c.ws_cap) return 0;
+    HIPCHK(hipDeviceSynchronize());
+    if (c.ws) HIPCHK(hipFree(c.ws));
+    c.ws = nullptr; c.ws_cap = 0;
+    int64_t want = bytes + (bytes >> 3) + (1 << 20);
+    HIPCHK(hipMalloc((void**)&c.ws, (size_t)want));
+    c.ws_cap = want;
     return 0;
 }
 
-static int ensure_ws(sta_handle* h, int64_t bytes) {
-    if (bytes <= h->ws_cap) return 0;
-    HIPCHK(hipDeviceSynchronize());
-    if (h->ws) HIPCHK(hipFree(h->ws));
-    h->ws = nullptr; h->ws_cap = 0;
-    int64_t want = bytes + (bytes >> 3) + (1 << 20);
-    HIPCHK(hipMalloc((void**)&h->ws, (size_t)want));
-    h->ws_cap = want;
-    return 0;
-}
+static Bump cur_bump(sta_handle* h) { return Bump{h->cur->ws, h->cur->ws_cap}; }
 
 // ------------------------------------------------------------------------------------------ schema
 static int make_lin(sta_handle* h, Lin& L, int N, int K, bool bias = true, bool mx = false) {
@@ -350,17 +367,18 @@ extern "C" int sta_create(const sta_config* cfg, int device, sta_handle** out) {
     REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, "this library is built for gfx950 only, device reports %s", prop.gcnArchName);
     sta_handle* h = new sta_handle();
     h->cfg = *cfg; h->device = device; h->prec = cfg->precision; h->mx_mask = mask_of_precision(cfg->precision);
-    for (int i = 0; i < 8; ++i) {            // experiment switches may also come from the environment (tools): STA_OPT0 .. STA_OPT7
+#ifdef STA_BENCH_EXPERIMENTS
+    for (int i = 0; i < 8; ++i) {            // experiment builds only (never shipped): switches from the environment, STA_OPT0 .. STA_OPT7
         char nm[16]; snprintf(nm, sizeof nm, "STA_OPT%d", i);
         if (const char* v = getenv(nm)) h->opt[i] = atoi(v);
     }
+#endif
+    h->ctx.reserve(MAX_STREAM_CTX);
     if (build_schema(h) != 0) { sta_destroy(h); return -1; }
     h->stage_elems = (int64_t)cfg->mlp_ratio * cfg->enc_embed_dim * cfg->enc_embed_dim;
     int64_t big = (int64_t)768 * 768 * 9;
     if (big > h->stage_elems) h->stage_elems = big;
     if (hipMalloc((void**)&h->stage, (size_t)h->stage_elems * 4) != hipSuccess) { sta_destroy(h); return set_err("staging alloc failed"); }
-    if (hipMalloc((void**)&h->skbuf, (size_t)SKBUF_SLOTS * SKBUF_ELEMS * 4) != hipSuccess) { sta_destroy(h); return set_err("split-K buffer alloc failed"); }
-    if (hipMalloc((void**)&h->slab, (size_t)SKBUF_SLOTS * SKBUF_ELEMS * 4) != hipSuccess) { sta_destroy(h); return set_err("split-K slab alloc failed"); }
     if (hipMalloc((void**)&h->zero_page, 256) != hipSuccess || hipMemset(h->zero_page, 0, 256) != hipSuccess) { sta_destroy(h); return set_err("zero page alloc failed"); }
     *out = h;
     return 0;
@@ -372,19 +390,16 @@ extern "C" int sta_destroy(sta_handle* h) {
     hipDeviceSynchronize();
     for (void* p : h->allocs) hipFree(p);
     if (h->stage) hipFree(h->stage);
-    if (h->ws) hipFree(h->ws);
+    for (auto& c : h->ctx) {
+        if (c.ws) hipFree(c.ws); if (c.skbuf) hipFree(c.skbuf); if (c.slab) hipFree(c.slab);
+        if (c.rv_conf) hipHostFree(c.rv_conf); if (c.rv_ev) hipEventDestroy(c.rv_ev);
+    }
     if (h->rope_tab) hipFree(h->rope_tab);
     if (h->zero_page) hipFree(h->zero_page);
-    if (h->skbuf) hipFree(h->skbuf);
-    if (h->slab) hipFree(h->slab);
     if (h->pre_tab) hipFree(h->pre_tab);
     if (h->clk_buf) hipFree(h->clk_buf);
     if (h->ev_ok) for (auto& e : h->ev) hipEventDestroy(e);
     for (auto& e : h->kev) hipEventDestroy(e);
-    if (h->aux[0]) {
-        hipEventDestroy(h->ev_fork);
-        for (int i = 0; i < 4; ++i) { hipStreamDestroy(h->aux[i]); hipEventDestroy(h->ev_join[i]); }
-    }
     delete h;
     return 0;
 }
@@ -400,16 +415,9 @@ extern "C" int sta_set_deterministic(sta_handle* h, int on) {
     h->deterministic = on != 0;
     return 0;
 }
-extern "C" int sta_set_concurrency(sta_handle* h, int n_slices) {
-    REQUIRE(h, "null handle");
-    REQUIRE(n_slices >= 1 && n_slices <= 4, "n_slices must be 1..4");
-    h->n_streams = n_slices;
-    return 0;
-}
-static int g_small_grid_mode = 0;        // tools/tile_table.py only (sta_set_gemm_variant 10 / 11): 1 = never, 2 = 4x the product threshold
 extern "C" int sta_set_gemm_variant(sta_handle* h, int variant) {
     REQUIRE(h && ((variant >= 0 && variant <= 4) || (variant >= 8 && variant <= 11)), "bad gemm variant");
-    g_small_grid_mode = variant == 10 ? 1 : (variant == 11 ? 2 : 0);      // process-wide: measurement tool only
+    h->small_grid_mode = variant == 10 ? 1 : (variant == 11 ? 2 : 0);     // measurement tool only; per handle
     h->gemm_variant = variant >= 10 ? 0 : variant;
     return 0;
 }
@@ -426,7 +434,12 @@ extern "C" int sta_range_report(sta_handle* h, unsigned long long counts[2], int
 }
 extern "C" int sta_num_expected_tensors(const sta_handle* h) { return h ? (int)h->slots.size() : -1; }
 extern "C" int sta_num_loaded_tensors(const sta_handle* h) { return h ? h->n_loaded : -1; }
-extern "C" int64_t sta_workspace_bytes(const sta_handle* h) { return h ? h->ws_cap : -1; }
+extern "C" int64_t sta_workspace_bytes(const sta_handle* h) {
+    if (!h) return -1;
+    int64_t b = 0;
+    for (const auto& c : h->ctx) b += c.ws_cap;
+    return b;
+}
 extern "C" int64_t sta_weight_bytes(const sta_handle* h) { return h ? h->weight_bytes : -1; }
 
 extern "C" int sta_load_tensor(sta_handle* h, const char* name, const void* host_ptr,
@@ -517,12 +530,13 @@ static inline bool auto_family(const sta_handle* h) { return h->gemm_variant == 
 // resid_ln_kernel (gemm_resid_ln), and the specialised throughput epilogues / the paired launch are not used (gemm_f32,
 // gemm_qkv_pair).  Threshold measured (profiles/r03_tile_table.txt): with fewer than 192 tiles of 192x128 the 128x64 family is
 // 15-40 % faster (162 tiles: 36 vs 45 us; 136: 113 vs 144 us; 128: 113 vs 133 us), from 216 tiles on it is slower.
-static inline bool small_grid(int64_t M, int N) {
-    if (g_small_grid_mode == 1) return false;
+static inline bool small_grid_m(int mode, int64_t M, int N) {
+    if (mode == 1) return false;
     const int64_t t = ((M + 191) / 192) * (int64_t)((N + 127) / 128);
-    if (g_small_grid_mode == 2) return M <= 2560 || t < 512;
+    if (mode == 2) return M <= 2560 || t < 512;
     return M <= 640 || t < 192;
 }
+static inline bool small_grid(const sta_handle* h, int64_t M, int N) { return small_grid_m(h->small_grid_mode, M, N); }
 
 // Tile-family choice = a quantisation-aware cost model calibrated on profiles/r03_tile_table.txt (tools/tile_table.py: every
 // GEMM / convolution shape of the forward at B in {1,2,4,8} x {224x224, 384x512}, in-model HIP-event durations under every forced
@@ -540,9 +554,9 @@ static inline bool small_grid(int64_t M, int N) {
 //      (head.0: ties go to the halo form, which moves 1.3x instead of 6.5x the algorithmic bytes), -2.5 % with the fused head epilogue below 2M pixels, equal from there on (the benchmark's 3.1M: 1.25x instead of 6.6x the bytes);
 //   6: small-grid family (predicate above);  1: 128x128 register-staged kernel: N not a multiple of 128;
 //   7 (paired 192x128 launch) is chosen by gemm_qkv_pair.
-struct FamilyQuery { int amode, epi; int64_t M; int N, K; int split, cstride, Ho, Wo; };
+struct FamilyQuery { int amode, epi; int64_t M; int N, K; int split, cstride, Ho, Wo; int sg_mode; };
 static int pick_family(const FamilyQuery& q) {
-    const bool sg = small_grid(q.M, q.N) && q.N % 64 == 0;
+    const bool sg = small_grid_m(q.sg_mode, q.M, q.N) && q.N % 64 == 0;
     if (q.N % 128 != 0) return sg ? 6 : 1;
     if (sg) return 6;
     auto cost = [](int64_t tiles, int area, double rate, double pen) {
@@ -579,7 +593,7 @@ static int pick_family(const FamilyQuery& q) {
     return best;
 }
 extern "C" int sta_debug_pick_family(int amode, int epi, long long M, int N, int K, int split, int cstride, int Ho, int Wo) {
-    FamilyQuery q{amode, epi, M, N, K, split, cstride, Ho, Wo};
+    FamilyQuery q{amode, epi, M, N, K, split, cstride, Ho, Wo, 0};
     return pick_family(q);
 }
 
@@ -602,13 +616,13 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st, in
     // patch rows; the tail is kept only where a gemm2 family tiles them exactly (checked after the family is chosen).
     p.m_tail = 0;
     if (AMODE == A_DENSE && h->tail_hint > 0 && h->tail_hint <= 32 && p.M > h->tail_hint && !p.mx && p.N % 128 == 0 && h->gemm_variant != 1) {
-        if (!small_grid(p.M - h->tail_hint, p.N)) p.m_tail = h->tail_hint;   // throughput scale only (the small-grid family splits K instead)
+        if (!small_grid(h, p.M - h->tail_hint, p.N)) p.m_tail = h->tail_hint;   // throughput scale only (the small-grid family splits K instead)
     }
     const int M_all = p.M;
     p.M -= p.m_tail;
     // Tile family (pick_family above: cost model calibrated on the measured table); a forced family never displaces the
     // small-grid one, whose split-K plumbing the callers rely on
-    const FamilyQuery fq{AMODE, EPI, p.M, p.N, p.K, split ? 1 : 0, p.cstride, p.Ho, p.Wo};
+    const FamilyQuery fq{AMODE, EPI, p.M, p.N, p.K, split ? 1 : 0, p.cstride, p.Ho, p.Wo, h->small_grid_mode};
     int variant = pick_family(fq);
     if (h->gemm_variant == 9 && variant == 8) { FamilyQuery f2 = fq; f2.Wo = 0; variant = pick_family(f2); }     // A/B: no halo kernel
     // Small grids (SLAM scale: 224x224, batch 1..8 -> M = 196..3200 rows; the coarse DPT levels at any scale): 128x64 tiles,
@@ -643,11 +657,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st, in
             const int max_ks = p.K / 256;                 // keep >= 8 K tiles per slice
             if (ks > max_ks) ks = max_ks;
             while (ks > 1 && (int64_t)ks * p.M * p.N > SKBUF_ELEMS) --ks;
-            if (ks > 1) {
-                int slot = 0;
-                for (int q = 0; q < 4; ++q) if (h->aux[q] && st == h->aux[q]) slot = q + 1;
-                p.ksplit = ks; p.skbuf = h->skbuf + (size_t)slot * SKBUF_ELEMS;
-            }
+            if (ks > 1) { p.ksplit = ks; p.skbuf = h->cur->skbuf; }
         }
         // plane-epilogue GEMMs / convs on tiny grids (DPT levels at SLAM scale: 16-64 workgroups looping over K = 2304 ..
         // 6912): split K into fp32 partial sums, a finishing kernel applies bias / activation / residuals.  Worth two
@@ -659,11 +669,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st, in
             const int max_ks = p.K / 256;                 // keep >= 8 K tiles per slice
             if (ks > max_ks) ks = max_ks;
             while (ks > 1 && (int64_t)ks * p.M * p.N > SKBUF_ELEMS) --ks;      // one slab per K slice
-            if (ks > 1) {
-                int slot = 0;                             // one scratch slot per stream the forward may be running on
-                for (int q = 0; q < 4; ++q) if (h->aux[q] && st == h->aux[q]) slot = q + 1;
-                p.ksplit = ks; p.skbuf = h->skbuf + (size_t)slot * SKBUF_ELEMS;
-            }
+            if (ks > 1) { p.ksplit = ks; p.skbuf = h->cur->skbuf; }
         }
     }
     // forced families (tests / tools): 1 = 128x128 register-staged, 2 = 256x256, 3 = 192x256 (both wherever N % 256 == 0 and
@@ -802,7 +808,7 @@ static int gemm_f32(sta_handle* h, const Planes& A, const Lin& W, int M, float* 
     p.C32 = out; p.ldc = ldc; p.resid = resid; p.ldr = ldc;
     p.rows_in = rows_in; p.rows_out = rows_out; p.row_off = row_off;
     // throughput-scale in-place residual GEMMs (attn.proj, mlp.fc2, cross_attn.proj): specialised epilogue
-    if (resid == out && rows_in == 0 && !small_grid(M, W.N))
+    if (resid == out && rows_in == 0 && !small_grid(h, M, W.N))
         return launch_gemm<A_DENSE, EPI_F32R>(h, p, st);
     return launch_gemm<A_DENSE, EPI_F32>(h, p, st);
 }
@@ -827,13 +833,11 @@ static int gemm_resid_ln(sta_handle* h, const Planes& A, const Lin& W, int M, fl
                          const LNp* lb, const Planes* ob, hipStream_t st) {
     static const LNp no_ln = {nullptr, nullptr};
     static const Planes no_planes;
-    const bool small = small_grid(M, W.N) && W.N % 64 == 0 && W.N <= 1024 && auto_family(h) && ld == W.N;
+    const bool small = small_grid(h, M, W.N) && W.N % 64 == 0 && W.N <= 1024 && auto_family(h) && ld == W.N;
     if (small) {
-        int slot = 0;
-        for (int q = 0; q < 4; ++q) if (h->aux[q] && st == h->aux[q]) slot = q + 1;
         GemmParams p = gp_dense(A, W.K, W, M, use_mx(h, W));
         p.C32 = x; p.ldc = ld; p.resid = x; p.ldr = ld; p.rows_in = 0; p.rows_out = 0; p.row_off = 0;
-        p.slab = h->slab + (size_t)slot * SKBUF_ELEMS;
+        p.slab = h->cur->slab;
         int ks = 0;
         CHK((launch_gemm<A_DENSE, EPI_F32>(h, p, st, &ks)));
         if (ks > 1) return run_ln(h, x, M, W.N, la ? *la : no_ln, oa ? *oa : no_planes, lb, ob, nullptr, st, p.slab, ks);
@@ -868,7 +872,7 @@ static int gemm_qkv(sta_handle* h, const Planes& A, const Lin& W, int M, int nq,
 static int gemm_qkv_pair(sta_handle* h, const GemmParams& pa_in, const GemmParams& pb_in, hipStream_t st) {
     GemmParams pa = pa_in, pb = pb_in;
     const bool split = h->prec != STA_PREC_F16;
-    auto big = [](const GemmParams& p) { return p.N % 128 == 0 && !small_grid(p.M, p.N); };
+    auto big = [h](const GemmParams& p) { return p.N % 128 == 0 && !small_grid(h, p.M, p.N); };
     if (h->dry) return 0;
     if (!split || pa.mx || pb.mx || !big(pa) || !big(pb) || pa.K != pb.K || pa.M != pb.M || !auto_family(h)) {
         CHK((launch_gemm<A_DENSE, EPI_QKV>(h, pa, st)));
@@ -878,7 +882,7 @@ static int gemm_qkv_pair(sta_handle* h, const GemmParams& pa_in, const GemmParam
     pa.ksplit = pb.ksplit = 1;
     // pose-token rows as skinny tail blocks (GemmParams::m_tail), same rule as launch_gemm
     pa.m_tail = pb.m_tail = (h->tail_hint > 0 && h->tail_hint <= 32 && pa.M > h->tail_hint && (pa.M - h->tail_hint) % 192 == 0 &&
-                             !small_grid(pa.M - h->tail_hint, pa.N) && !small_grid(pb.M - h->tail_hint, pb.N)) ? h->tail_hint : 0;
+                             !small_grid(h, pa.M - h->tail_hint, pa.N) && !small_grid(h, pb.M - h->tail_hint, pb.N)) ? h->tail_hint : 0;
     const int ta = ((pa.M - pa.m_tail + 191) / 192) * (pa.N / 128) + (pa.m_tail ? pa.N / 32 : 0);
     const int tb = ((pb.M - pb.m_tail + 191) / 192) * (pb.N / 128) + (pb.m_tail ? pb.N / 32 : 0);
     const bool timed = h->ktime && (h->ktime_all || (h->kfilter[0] == EPI_QKV && h->kfilter[1] == A_DENSE && h->kfilter[2] == 7 && h->kfilter[3] == 0));
@@ -935,7 +939,7 @@ static int conv3(sta_handle* h, const Planes& in, int nimg, int Hi, int Wi, int 
 // head.2 (3x3 conv 128 -> 128) + ReLU + head.4 (1x1 conv 128 -> 4) + point-map / confidence activations as ONE kernel
 // (EPI_HEAD): true when it was launched; false = the caller runs conv3 + head_final_kernel (small grids, forced tile families).
 static bool conv3_head_ok(sta_handle* h, const Lin& W, int64_t M) {
-    return W.N == 128 && ((auto_family(h) && !small_grid(M, W.N)) || h->gemm_variant == 8);
+    return W.N == 128 && ((auto_family(h) && !small_grid(h, M, W.N)) || h->gemm_variant == 8);
 }
 static int conv3_head(sta_handle* h, const Planes& in, int nimg, int Hi, int Wi, int Cin, const Lin& W, const F32Lin& W4,
                       float* ptsA, float* confA, int nA, float* ptsB, float* confB, hipStream_t st) {
@@ -1329,14 +1333,17 @@ static int check_ready(sta_handle* h, int B, int H, int W) {
 // Two-pass execution: a dry planning pass sizes the workspace exactly (same allocation sequence,
 // no launches), then the real pass runs.  Steady state: the plan fits, nothing is allocated.
 template <class F>
-static int plan_and_run(sta_handle* h, F&& body) {
+static int plan_and_run(sta_handle* h, hipStream_t st, F&& body) {
+    CHK(stream_ctx(h, st));          // this stream's scratch context (the dry pass already reads h->cur)
+    REQUIRE(!h->cur->rv_open, "a split-phase scheduler call (sta_regress_views_begin) is pending on this stream: its workspace is live "
+                              "until sta_regress_views_finish; run other calls on another stream");
     h->dry = true;
     Bump plan{nullptr, INT64_MAX};
     int r = body(plan);
     h->dry = false;
     if (r != 0) return r;
-    CHK(ensure_ws(h, plan.peak + 4096));
-    Bump ws{h->ws, h->ws_cap};
+    CHK(ensure_ws(h, plan.peak + 4096, st));
+    Bump ws = cur_bump(h);
     return body(ws);
 }
 
@@ -1349,7 +1356,7 @@ extern "C" int sta_encode(sta_handle* h, const float* img_dev, int B, int H, int
     const int hp = H / 16, wp = W / 16;
     CHK(ensure_rope(h, hp > wp ? hp : wp));
     const void* imgs[1] = {img_dev};
-    return plan_and_run(h, [&](Bump& ws) { return encode_impl(h, ws, imgs, false, 1, B, H, W, feat_dev, st); });
+    return plan_and_run(h, st, [&](Bump& ws) { return encode_impl(h, ws, imgs, false, 1, B, H, W, feat_dev, st); });
 }
 
 extern "C" int sta_encode_u8hwc(sta_handle* h, const uint8_t* img_dev, int B, int H, int W, float* feat_dev, void* stream) {
@@ -1362,7 +1369,7 @@ extern "C" int sta_encode_u8hwc(sta_handle* h, const uint8_t* img_dev, int B, in
     const int hp = H / 16, wp = W / 16;
     CHK(ensure_rope(h, hp > wp ? hp : wp));
     const void* imgs[1] = {img_dev};
-    return plan_and_run(h, [&](Bump& ws) { return encode_impl(h, ws, imgs, true, 1, B, H, W, feat_dev, st); });
+    return plan_and_run(h, st, [&](Bump& ws) { return encode_impl(h, ws, imgs, true, 1, B, H, W, feat_dev, st); });
 }
 
 extern "C" int sta_encoder_norm(sta_handle* h, const float* feat_dev, int64_t rows, float* out_dev, void* stream) {
@@ -1383,7 +1390,7 @@ extern "C" int sta_decode(sta_handle* h, const float* feat1, const float* feat2,
     CHK(ensure_rope(h, hp > wp ? hp : wp));
     const int N = hp * wp, D = h->cfg.dec_embed_dim;
     const int64_t xbytes = (int64_t)2 * B * (N + 1) * D * 4;
-    return plan_and_run(h, [&](Bump& ws) {
+    return plan_and_run(h, st, [&](Bump& ws) {
         float* x = (float*)ws.take(xbytes);
         return decode_impl(h, ws, feat1, feat2, B, hp, wp, x, out1, out2, true, st);
     });
@@ -1395,7 +1402,7 @@ extern "C" int sta_head_pose(sta_handle* h, const float* tok, int B, int64_t tok
     DEV_SCOPE(h->device);
     REQUIRE(tok_stride % 4 == 0, "tok_stride must be a multiple of 4 floats");
     hipStream_t st = (hipStream_t)stream;
-    return plan_and_run(h, [&](Bump& ws) { return pose_impl(h, ws, tok, B, tok_stride, pose, conf, st); });
+    return plan_and_run(h, st, [&](Bump& ws) { return pose_impl(h, ws, tok, B, tok_stride, pose, conf, st); });
 }
 
 extern "C" int sta_head_pts(sta_handle* h, const float* enc_feat, int64_t enc_bstride,
@@ -1407,7 +1414,7 @@ extern "C" int sta_head_pts(sta_handle* h, const float* enc_feat, int64_t enc_bs
     CHK(check_ready(h, B, H, W));
     REQUIRE(enc_feat && hook1 && hook2 && hook3 && pts && conf, "null device pointer");
     hipStream_t st = (hipStream_t)stream;
-    return plan_and_run(h, [&](Bump& ws) {
+    return plan_and_run(h, st, [&](Bump& ws) {
         return dpt_impl(h, ws, enc_feat, enc_bstride, hook1, hook1_bstride, hook2, hook2_bstride, hook3, hook3_bstride,
                         B, H, W, pts, conf, B, nullptr, nullptr, st);
     });
@@ -1427,7 +1434,7 @@ static int forward_pair_any(sta_handle* h, const void* img_a, const void* img_b,
     if (h->timing && !h->ev_ok) { for (auto& e : h->ev) HIPCHK(hipEventCreate(&e)); h->ev_ok = true; }
     const int dd = c.dec_depth;
     const int hidx[3] = {dd * 2 / 4, dd * 3 / 4, dd};   // hooks [d/2+1, 3d/4+1, d+1] - 1 (dpt_head.py:112)
-    // one batch slice of pairs, every launch on stream `st`
+    // the whole batch of pairs, every launch on stream `st`
     auto run_slice = [&](Bump& ws, const void* ia, const void* ib, int Bs, float* const p[2], float* const cf[2],
                          float* const po[2], float* const pc[2], hipStream_t st, bool rec) -> int {
         const int Ss = 2 * Bs;
@@ -1458,33 +1465,8 @@ static int forward_pair_any(sta_handle* h, const void* img_a, const void* img_b,
         if (rec) HIPCHK(hipEventRecord(h->ev[4], st));
         return 0;
     };
-    const int nsl = h->n_streams < B ? h->n_streams : B;
-    if (nsl == 1)
-        return plan_and_run(h, [&](Bump& ws) -> int {
-            return run_slice(ws, img_a, img_b, B, pts, conf, pose, pose_conf, st, h->timing && !h->dry);
-        });
-    // Batch slices on internal streams: the hardware interleaves their workgroups, so the tail round of one
-    // slice's GEMM and its HBM-bound kernels overlap the other slice's MFMA-bound main loops.  Fork/join by events;
-    // the caller's stream sees one asynchronous operation.
-    CHK(ensure_streams(h));
-    const int64_t img_el = (int64_t)3 * H * W * (u8hwc ? 1 : 4), px = (int64_t)H * W;
-    return plan_and_run(h, [&](Bump& ws) -> int {
-        if (!h->dry) HIPCHK(hipEventRecord(h->ev_fork, st));
-        int b0 = 0;
-        for (int s = 0; s < nsl; ++s) {
-            const int Bs = (B * (s + 1)) / nsl - (B * s) / nsl;
-            hipStream_t ss = h->aux[s];
-            if (!h->dry) HIPCHK(hipStreamWaitEvent(ss, h->ev_fork, 0));
-            float* p[2] = {pts[0] + b0 * px * 3, pts[1] + b0 * px * 3};
-            float* cf[2] = {conf[0] + b0 * px, conf[1] + b0 * px};
-            float* po[2] = {pose[0] + b0 * 16, pose[1] + b0 * 16};
-            float* pc[2] = {pose_conf[0] + b0, pose_conf[1] + b0};
-            ws.off = ws.peak;    // slices own disjoint workspace regions
-            CHK(run_slice(ws, (const char*)img_a + b0 * img_el, (const char*)img_b + b0 * img_el, Bs, p, cf, po, pc, ss, false));
-            if (!h->dry) { HIPCHK(hipEventRecord(h->ev_join[s], ss)); HIPCHK(hipStreamWaitEvent(st, h->ev_join[s], 0)); }
-            b0 += Bs;
-        }
-        return 0;
+    return plan_and_run(h, st, [&](Bump& ws) -> int {
+        return run_slice(ws, img_a, img_b, B, pts, conf, pose, pose_conf, st, h->timing && !h->dry);
     });
 }
 

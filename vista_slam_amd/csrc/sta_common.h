@@ -17,20 +17,25 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 // producing inf; a non-zero count says the result is no longer backed by the parity goldens.  Rare path: one compare per value.
 // A writer tracks the largest magnitude it stored in a RangeAcc (ONE v_max_f32 per value, no compare, no branch) and
 // flushes once per tile / row / call: the counters count (lane, flush) events with at least one out-of-range value, not values.
-// (NaNs are dropped by the max; a non-finite row of a residual stream is counted by the LayerNorm kernels.)
+// The running maximum is kept on the BIT PATTERN of |x| (v_and + v_max_u32): as unsigned integers NaN (0x7fc00000) > inf
+// (0x7f800000) > every finite value, so a NaN is sticky and counts as a range event too (a float max would drop it, and the
+// clamp below turns it into -65504: silent).  A non-finite ROW of a residual stream is also counted by the LayerNorm kernels.
 __device__ unsigned long long g_sta_range[2];
+#define STA_F16_MAX_BITS 0x477fe000u      // bits of 65504.0f
+#define STA_E5M2_MAX_BITS 0x47600000u     // bits of 57344.0f
 struct RangeAcc {
-    float amax = 0.f;       // largest |x| written as an fp16 (hi, residual) pair
-    float amax8 = 0.f;      // largest |x| whose fp8 (e5m2) copy was written (f16mx activation rows: saturates beyond 57344)
+    unsigned amax = 0u;     // bits of the largest |x| written as an fp16 (hi, residual) pair
+    unsigned amax8 = 0u;    // the same for values whose fp8 (e5m2) copy was written (f16mx activation rows: saturates beyond 57344)
     bool w8 = false;        // a WEIGHT e4m3 byte saturated (packing at load time: exact check)
     __device__ __forceinline__ void flush() {
-        if (__builtin_expect(amax > STA_F16_MAX, 0)) atomicAdd(&g_sta_range[0], 1ull);
-        if (__builtin_expect(amax8 > 57344.f || w8, 0)) atomicAdd(&g_sta_range[1], 1ull);
-        amax = amax8 = 0.f; w8 = false;
+        if (__builtin_expect(amax > STA_F16_MAX_BITS, 0)) atomicAdd(&g_sta_range[0], 1ull);
+        if (__builtin_expect(amax8 > STA_E5M2_MAX_BITS || w8, 0)) atomicAdd(&g_sta_range[1], 1ull);
+        amax = amax8 = 0u; w8 = false;
     }
 };
 __device__ __forceinline__ float sat_f16_range(float x, RangeAcc& a) {
-    a.amax = fmaxf(a.amax, fabsf(x));
+    const unsigned ax = __float_as_uint(x) & 0x7fffffffu;
+    a.amax = ax > a.amax ? ax : a.amax;
     return fminf(fmaxf(x, -STA_F16_MAX), STA_F16_MAX);
 }
 
@@ -40,17 +45,6 @@ __device__ __forceinline__ void split_f16(float x, f16& hi, f16& lo, RangeAcc& r
     x = sat_f16_range(x, ra);
     hi = (f16)x;
     lo = (f16)(x - (float)hi);
-#ifdef STA_EMU_LO_MANT
-    // experiment only (never defined in the product build): keep STA_EMU_LO_MANT explicit mantissa bits of the
-    // residual plane, i.e. emulate an fp8-class `lo` to measure what a 2-unit (f16 + MX-fp8 correction) scheme would cost
-    {
-        unsigned u = __float_as_uint(x - (float)hi);
-        const int drop = 23 - STA_EMU_LO_MANT;
-        u += 1u << (drop - 1);
-        u &= ~((1u << drop) - 1u);
-        lo = (f16)__uint_as_float(u);
-    }
-#endif
 }
 __device__ __forceinline__ void split_f16(float x, f16& hi, f16& lo) { RangeAcc ra; split_f16(x, hi, lo, ra); ra.flush(); }
 __device__ __forceinline__ f16 to_f16_sat(float x, RangeAcc& ra) { return (f16)sat_f16_range(x, ra); }

@@ -25,14 +25,34 @@ def compact_elems_per_pair(H: int, W: int) -> int:
     return 2 * (16 + 1 + 2 * H * W)
 
 
-def pack_compact(main: Dict[str, torch.Tensor], supp: Dict[str, torch.Tensor]) -> torch.Tensor:
-    """[B, compact_elems_per_pair] fp32: per pair (main then support) pose16, pose_conf, depth, conf."""
+def pack_compact(main: Dict[str, torch.Tensor], supp: Dict[str, torch.Tensor], model=None,
+                 out: torch.Tensor | None = None) -> torch.Tensor:
+    """[B, compact_elems_per_pair] fp32: per pair (main then support) pose16, pose_conf, depth, conf.
+    With `model` (an STAFrontend) and contiguous GPU outputs the record is written by ONE kernel (sta_pack_compact),
+    straight into `out` when given (e.g. the send buffer of the step's all-gather); otherwise a torch.cat of the slices."""
+    pts = main["pts3d_pred"]
+    if model is not None and pts.is_cuda and all(o[k].is_contiguous() for o in (main, supp)
+                                                for k in ("pts3d_pred", "conf", "relative_pose", "relative_pose_conf")):
+        import ctypes as C
+        from . import _lib
+        B, H, W = pts.shape[0], pts.shape[1], pts.shape[2]
+        if out is None:
+            out = torch.empty(B, compact_elems_per_pair(H, W), device=pts.device, dtype=torch.float32)
+        assert out.shape[0] == B and out.stride(1) == 1 and out.shape[1] == compact_elems_per_pair(H, W)
+        arr = [(C.c_void_p * 2)(main[k].data_ptr(), supp[k].data_ptr()) for k in ("pts3d_pred", "conf", "relative_pose", "relative_pose_conf")]
+        _lib.check(model.lib.sta_pack_compact(model._h, arr[0], arr[1], arr[2], arr[3], B, H, W, out.data_ptr(), out.stride(0),
+                                              torch.cuda.current_stream(pts.device).cuda_stream))
+        return out
     parts = []
     for o in (main, supp):
         B = o["relative_pose"].shape[0]
         parts += [o["relative_pose"].reshape(B, 16), o["relative_pose_conf"].reshape(B, 1),
                   o["pts3d_pred"][..., 2].reshape(B, -1), o["conf"].reshape(B, -1)]
-    return torch.cat(parts, dim=1).contiguous()
+    res = torch.cat(parts, dim=1).contiguous()
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
 
 
 def unpack_compact(buf: torch.Tensor, H: int, W: int) -> List[Dict[str, torch.Tensor]]:

@@ -33,12 +33,17 @@ class EdgeResult:
         return self.pose, self.rel_pose_conf, self.confs, self.intri, self.depths
 
 
-def regress_views(frontend: STAFrontend, enc_feat_i: torch.Tensor, enc_feats_j: Sequence[torch.Tensor],
-                  adjacent: Sequence[bool], rel_pose_thres: float, H: int, W: int) -> List[EdgeResult]:
-    """Edges (i, j_e), e < k, of one keyframe.  enc_feat_i / enc_feats_j[e]: [1,N,1024] encoder features as cached
-    by `add_view` (slam.py:142-151).  adjacent[e] = (i - j_e == 1).  Synchronises the current stream once."""
+class PendingEdges:
+    """A scheduler call between its two phases (sta_regress_views_begin / _finish): the output tensors, the inputs kept
+    alive, and the stream the call lives on."""
+    __slots__ = ("k", "H", "W", "stream", "pose", "pts", "conf", "K", "depth", "_keep")
+
+
+def regress_views_begin(frontend: STAFrontend, enc_feat_i: torch.Tensor, enc_feats_j: Sequence[torch.Tensor], H: int, W: int) -> PendingEdges:
+    """Phase 1 of `regress_views` on the CURRENT stream: gather + batched decode + pose heads, no host synchronisation.
+    Until `regress_views_finish` no other frontend call may run on this stream (calls on other streams are fine)."""
     k = len(enc_feats_j)
-    assert k == len(adjacent) and 1 <= k <= 16
+    assert 1 <= k <= 16
     frontend._check_hw(H, W)
     dev = frontend.device
     N, E = (H // 16) * (W // 16), frontend.cfg.enc_embed_dim
@@ -47,25 +52,45 @@ def regress_views(frontend: STAFrontend, enc_feat_i: torch.Tensor, enc_feats_j: 
     for f in [fi] + fj:
         assert f.numel() == N * E, f"encoder feature has {f.numel()} elements, expected {N}x{E}"
     ptrs = (C.c_void_p * k)(*[f.data_ptr() for f in fj])
+    p = PendingEdges()
+    p.k, p.H, p.W, p.stream = k, H, W, frontend._stream()
+    p.pose = torch.empty(k, 4, 4, device=dev, dtype=torch.float32)
+    p.pts = torch.empty(k, 2, H, W, 3, device=dev, dtype=torch.float32)
+    p.conf = torch.empty(k, 2, H, W, device=dev, dtype=torch.float32)
+    p.K = torch.empty(k, 3, 3, device=dev, dtype=torch.float32)
+    p.depth = torch.empty(k, 2, H, W, device=dev, dtype=torch.float32)
+    p._keep = (fi, fj)
+    _lib.check(frontend.lib.sta_regress_views_begin(frontend._h, fi.data_ptr(), ptrs, k, H, W, p.pose.data_ptr(), p.stream))
+    return p
+
+
+def regress_views_finish(frontend: STAFrontend, p: PendingEdges, adjacent: Sequence[bool], rel_pose_thres: float) -> List[EdgeResult]:
+    """Phase 2: waits for the k pose confidences, accepts / rejects (slam.py:169), enqueues the DPT heads + reductions of the
+    accepted edges on the stream `regress_views_begin` ran on."""
+    k, H, W = p.k, p.H, p.W
+    assert k == len(adjacent)
     adj = bytes(bytearray(1 if a else 0 for a in adjacent))
-    pose = torch.empty(k, 4, 4, device=dev, dtype=torch.float32)
-    pts = torch.empty(k, 2, H, W, 3, device=dev, dtype=torch.float32)
-    conf = torch.empty(k, 2, H, W, device=dev, dtype=torch.float32)
-    Kt = torch.empty(k, 3, 3, device=dev, dtype=torch.float32)
-    depth = torch.empty(k, 2, H, W, device=dev, dtype=torch.float32)
     pconf = (C.c_float * k)()
     slot = (C.c_int * k)()
     nacc = C.c_int(0)
-    _lib.check(frontend.lib.sta_regress_views(frontend._h, fi.data_ptr(), ptrs, k, adj, float(rel_pose_thres), H, W,
-                                              pose.data_ptr(), pconf, slot, C.byref(nacc), pts.data_ptr(), conf.data_ptr(),
-                                              Kt.data_ptr(), depth.data_ptr(), frontend._stream()))
+    _lib.check(frontend.lib.sta_regress_views_finish(frontend._h, adj, float(rel_pose_thres), pconf, slot, C.byref(nacc),
+                                                     p.pts.data_ptr(), p.conf.data_ptr(), p.K.data_ptr(), p.depth.data_ptr(), p.stream))
+    pts, conf, depth = p.pts, p.conf, p.depth
     if H > W:     # portrait: the reference sees transposed views of the same memory (utils/misc.py:60-61,81)
         pts, conf, depth = pts.swapaxes(2, 3), conf.swapaxes(2, 3), depth.swapaxes(2, 3)
     out = []
     for e in range(k):
         s = slot[e]
         if s < 0:
-            out.append(EdgeResult(pose[e], float(pconf[e]), False))
+            out.append(EdgeResult(p.pose[e], float(pconf[e]), False))
         else:
-            out.append(EdgeResult(pose[e], float(pconf[e]), True, conf[s], Kt[s], depth[s], pts[s]))
+            out.append(EdgeResult(p.pose[e], float(pconf[e]), True, conf[s], p.K[s], depth[s], pts[s]))
     return out
+
+
+def regress_views(frontend: STAFrontend, enc_feat_i: torch.Tensor, enc_feats_j: Sequence[torch.Tensor],
+                  adjacent: Sequence[bool], rel_pose_thres: float, H: int, W: int) -> List[EdgeResult]:
+    """Edges (i, j_e), e < k, of one keyframe.  enc_feat_i / enc_feats_j[e]: [1,N,1024] encoder features as cached
+    by `add_view` (slam.py:142-151).  adjacent[e] = (i - j_e == 1).  Synchronises once, on the k pose confidences."""
+    assert len(enc_feats_j) == len(adjacent)
+    return regress_views_finish(frontend, regress_views_begin(frontend, enc_feat_i, enc_feats_j, H, W), adjacent, rel_pose_thres)

@@ -113,10 +113,6 @@ class STAFrontend:
         """Bit-reproducible results (no split-K fp32 atomics at SLAM scale; include/sta_mi355.h)."""
         _lib.check(self.lib.sta_set_deterministic(self._h, int(on)))
 
-    def set_concurrency(self, n_slices):
-        """1 = single stream (default); 2 = two batch slices on two internal streams (sta_mi355.h)."""
-        _lib.check(self.lib.sta_set_concurrency(self._h, int(n_slices)))
-
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state: Dict[str, "torch.Tensor | np.ndarray"], strict: bool = True):
         if not strict:
