@@ -109,18 +109,26 @@ def slam_replay(model, dev, frames=120, warm=12, res=(224, 224), src_hw=(480, 64
     """Data-free stand-in for BASELINE configs[2] (TUM-RGBD through slam.py): `frames` synthetic 640x480 uint8 camera frames
     through the frontend's calls in `OnlineSLAM.step`'s order (slam.py:244-297) with a GROWING feature cache -
     f3 input step (crop / LANCZOS / ImgNorm, slam_images_only.py:19-33) -> add_view = encode (slam.py:142-151) -> the
-    <= neighbor_edge_num neighbour edges as one batched scheduler call, then <= loop_edge_num loop candidates (older views,
-    chosen by a hash; the reference's DBoW3 detector is a CPU stage and out of scope) as a second call (slam.py:263-277;
-    regress_two_views + early reject, slam.py:153-189) -> per accepted edge the node bookkeeping's device work: the scale
-    edge to the view's first node (estimate_scale_with_depth_and_confidence + the sqrt-mean confidence, slam.py:205-218) ->
-    at the end the f4 world point cloud over every view (save_data_all, slam.py:396-408).  The rejection threshold is the
-    40 % quantile of the non-adjacent pose confidences of the warm-up frames, so ~40 % of the non-adjacent edges skip the
-    DPT heads like rejected loop closures do.  No dataset, checkpoint, pypose, DBoW3: ATE cannot be produced here (said in
-    DESIGN.md); what is measured is keyframes/s of the frontend + its f1-f4 neighbours and the per-stage split."""
+    <= neighbor_edge_num neighbour edges and the <= loop_edge_num loop candidates (older views, chosen by a hash; the
+    reference's DBoW3 detector is a CPU stage, out of scope, and reads only the grey image - slam.py:267 - so its candidates
+    do not depend on the neighbour edges' results) as ONE batched scheduler call, edge order = the reference's
+    (slam.py:263-277; regress_two_views + early reject, slam.py:153-189) -> per accepted edge the node bookkeeping's device
+    work: the scale edge to the view's first node (estimate_scale_with_depth_and_confidence + the sqrt-mean confidence,
+    slam.py:205-218) -> at the end the f4 world point cloud over every view (save_data_all, slam.py:396-408).  The rejection
+    threshold is the 40 % quantile of the non-adjacent pose confidences of the warm-up frames, so ~40 % of the non-adjacent
+    edges skip the DPT heads like rejected loop closures do.  No dataset, checkpoint, pypose, DBoW3: ATE cannot be produced
+    here (said in DESIGN.md); what is measured is keyframes/s of the frontend + its f1-f4 neighbours and the per-stage split.
+
+    Two schedules of the SAME calls: `single_stream` (everything in order on one stream) and the pipelined one reported as
+    `keyframes_per_s`: three streams - f3 + encode of keyframe i+1; decode + pose heads of keyframe i's edges
+    (regress_views_begin); DPT heads + reductions + node bookkeeping of keyframe i-1's accepted edges (regress_views_finish) -
+    which only uses independence the SLAM loop itself has: add_view(i+1) needs no result of keyframe i (slam.py:258), and the
+    edges of keyframe i need encoder features only (slam.py:153-162).  At 224x224, batch 1 every chain is ~200 dependent
+    dispatches that each leave most of the chip idle; the library keeps one scratch context per stream."""
     import torch
     from vista_slam_amd import weights as Wt
     from vista_slam_amd.preprocess import process_image
-    from vista_slam_amd.slam_scheduler import regress_views
+    from vista_slam_amd.slam_scheduler import regress_views_begin, regress_views_finish
     from vista_slam_amd.post import estimate_scale_with_depth_and_confidence
     from vista_slam_amd.formats import world_pointcloud
     Hs, Ws = src_hw
@@ -129,18 +137,14 @@ def slam_replay(model, dev, frames=120, warm=12, res=(224, 224), src_hw=(480, 64
     distinct = [torch.from_numpy(Wt.synth_frames_u8(Hs, Ws, seed=43, tag=t)).to(dev) for t in range(16)]
     raw = [distinct[f % 16] for f in range(n_all)]                      # frames resident in HBM (16 distinct ones, cycled)
     torch.cuda.synchronize()
-
     main_stream = torch.cuda.current_stream(dev)
     enc_stream = torch.cuda.Stream(device=dev)
+    edge_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
 
     def run(nf, thres, pipelined):
-        """pipelined: the input step + encode of frame i+1 are enqueued on a SECOND stream before the edges of frame i are
-        processed on the first (add_view of the next keyframe does not depend on the current keyframe's edges: slam.py:258 vs
-        :263-277; the library keeps one scratch context per stream) - at 224x224, batch 1 either chain alone leaves most of the
-        chip idle between its dependent dispatches, and the scheduler's host synchronisation (slam.py:169) no longer idles the GPU."""
-        feats, rgbs, first = [], [], {}          # encoder feature cache; normalised frames; first node of every view: (depth, conf, K, pose)
+        feats, rgbs, first = [], [], {}          # encoder feature cache; normalised frames; first node of every view: (depth, conf, K)
         poses = {0: torch.eye(4, device=dev)}
-        ev = {k: [] for k in ("f3", "encode", "edges", "f1")}
+        ev = {k: [] for k in ("f3", "encode", "edges_decode", "edges_heads", "f1")}
         stats = {"edges": 0, "rejected": 0, "scale_edges": 0, "nonadj_conf": []}
 
         def mark():
@@ -154,53 +158,82 @@ def slam_replay(model, dev, frames=120, warm=12, res=(224, 224), src_hw=(480, 64
             t2 = mark()
             ev["f3"].append((t0, t1)); ev["encode"].append((t1, t2))
             return feat, pre["rgb"], t2
-        nxt = None
-        if pipelined:
+
+        def edge_list(i):                       # neighbours (slam.py:262-265), then loop candidates among the older views (:273-277)
+            far = max(0, i - neighbor_edge_num)
+            js = list(range(far, i))
+            if far >= 8:
+                js += sorted({(i * 7919 + 13) % far, (i * 104729 + 7) % far})[:loop_edge_num]
+            return js
+
+        def begin(i, feat):                     # on the CURRENT stream
+            js = edge_list(i)
+            if not js:
+                return None
+            t0 = mark()
+            pend = regress_views_begin(model, feat, [feats[j] for j in js], Hr, Wr)
+            ev["edges_decode"].append((t0, mark()))
+            return i, js, pend
+
+        def finish(job, after=None):            # on the CURRENT stream (the one begin(i) ran on)
+            if job is None:
+                return None
+            i, js, pend = job
+            t0 = mark()
+            res_e = regress_views_finish(model, pend, [i - j == 1 for j in js], thres)
+            t1 = mark()
+            ev["edges_heads"].append((t0, t1))
+            if after is not None:               # the previous keyframe's bookkeeping ran on the other edge stream
+                torch.cuda.current_stream(dev).wait_event(after)
+            for j, r in zip(js, res_e):
+                stats["edges"] += 1
+                if i - j != 1:
+                    stats["nonadj_conf"].append(r.rel_pose_conf)
+                if not r.accepted:
+                    stats["rejected"] += 1
+                    continue
+                for v, k in ((i, 0), (j, 1)):          # node bookkeeping (slam.py:203-218): scale edge to the view's first node
+                    if v in first:
+                        d0, c0 = first[v][0], first[v][1]
+                        estimate_scale_with_depth_and_confidence(model, r.depths[k], d0, r.confs[k], c0)
+                        (r.confs[k] * c0).sqrt().mean()
+                        stats["scale_edges"] += 1
+                    else:
+                        first[v] = (r.depths[k], r.confs[k], r.intri)
+                if i not in poses and j in poses:
+                    poses[i] = poses[j] @ r.pose
+            t2 = mark()
+            ev["f1"].append((t1, t2))
+            return t2
+
+        if not pipelined:
+            for i in range(nf):
+                feat, rgb, _done = add_view(i)
+                feats.append(feat); rgbs.append(rgb)
+                finish(begin(i, feat))
+        else:
             with torch.cuda.stream(enc_stream):
                 nxt = add_view(0)
-        for i in range(nf):
-            if pipelined:
+            job, last_fin = None, None
+            for i in range(nf):
                 feat, rgb, done = nxt
+                feats.append(feat); rgbs.append(rgb)
                 if i + 1 < nf:
                     with torch.cuda.stream(enc_stream):
                         nxt = add_view(i + 1)
-                main_stream.wait_event(done)
-            else:
-                feat, rgb, done = add_view(i)
-            t2 = mark()
-            feats.append(feat); rgbs.append(rgb)
-            far = max(0, i - neighbor_edge_num)
-            calls = [list(range(far, i))]
-            if far >= 8:                     # loop candidates among the views older than the neighbour window
-                cand = sorted({(i * 7919 + 13) % far, (i * 104729 + 7) % far})[:loop_edge_num]
-                calls.append(cand)
-            t_f1 = 0
-            for js in calls:
-                if not js:
-                    continue
-                res_e = regress_views(model, feat, [feats[j] for j in js], [i - j == 1 for j in js], thres, Hr, Wr)
-                for j, r in zip(js, res_e):
-                    stats["edges"] += 1
-                    if i - j != 1:
-                        stats["nonadj_conf"].append(r.rel_pose_conf)
-                    if not r.accepted:
-                        stats["rejected"] += 1
-                        continue
-                    f0 = mark()
-                    for v, k in ((i, 0), (j, 1)):          # node bookkeeping (slam.py:203-218): scale edge to the view's first node
-                        if v in first:
-                            d0, c0 = first[v][0], first[v][1]
-                            estimate_scale_with_depth_and_confidence(model, r.depths[k], d0, r.confs[k], c0)
-                            (r.confs[k] * c0).sqrt().mean()
-                            stats["scale_edges"] += 1
-                        else:
-                            first[v] = (r.depths[k], r.confs[k], r.intri, None)
-                    if i not in poses and j in poses:
-                        poses[i] = poses[j] @ r.pose
-                    f1 = mark()
-                    ev["f1"].append((f0, f1))
-            t3 = mark()
-            ev["edges"].append((t2, t3))
+                with torch.cuda.stream(edge_streams[i & 1]):
+                    edge_streams[i & 1].wait_event(done)
+                    new_job = begin(i, feat)
+                if job is not None:
+                    with torch.cuda.stream(edge_streams[(i - 1) & 1]):
+                        last_fin = finish(job, last_fin)
+                job = new_job
+            if job is not None:
+                with torch.cuda.stream(edge_streams[(nf - 1) & 1]):
+                    last_fin = finish(job, last_fin)
+            if last_fin is not None:
+                main_stream.wait_event(last_fin)
+            main_stream.wait_stream(enc_stream)
         # f4: world point cloud of every view that has a node (slam.py:396-408)
         t4 = mark()
         ids = sorted(v for v in first if v in poses)
@@ -214,12 +247,11 @@ def slam_replay(model, dev, frames=120, warm=12, res=(224, 224), src_hw=(480, 64
         t5 = mark()
         torch.cuda.synchronize()
         ms = {k: sum(a.elapsed_time(b) for a, b in v) for k, v in ev.items()}
-        ms["edges"] -= ms["f1"]
         ms["f4"] = t4.elapsed_time(t5)
         return ms, stats, npts, len(ids)
 
     _, st_w, _, _ = run(warm, -1.0, False)                               # warm-up: workspace, tables, threshold
-    run(warm, -1.0, True)                                                # ... and the second stream's scratch context
+    run(warm, -1.0, True)                                                # ... and the other streams' scratch contexts
     conf = sorted(st_w["nonadj_conf"])
     thres = conf[int(0.4 * len(conf))] if conf else -1.0
     torch.cuda.synchronize()
@@ -233,8 +265,10 @@ def slam_replay(model, dev, frames=120, warm=12, res=(224, 224), src_hw=(480, 64
     nonadj = len(st["nonadj_conf"])
     return {"frames": frames, "keyframes_per_s": round(frames / dt, 2), "ms_per_keyframe": round(dt / frames * 1e3, 3),
             "same_result_as_single_stream": bool(npts == npts_s and st["rejected"] == st_s["rejected"] and st["edges"] == st_s["edges"]),
-            "schedule": "two streams: f3 + encode of keyframe i+1 under the edges of keyframe i (one library scratch context per stream)",
+            "schedule": "three streams: f3 + encode of keyframe i+1 | decode + pose heads of keyframe i's edges (regress_views_begin) | DPT heads, "
+                        "reductions and node bookkeeping of keyframe i-1 (regress_views_finish); one library scratch context per stream",
             "stage_ms_per_keyframe": {k: round(v / frames, 3) for k, v in ms.items()},
+            "stage_note": "per-stage event intervals on each stage's own stream; under the pipelined schedule they overlap and do not add up",
             "single_stream": {"keyframes_per_s": round(frames / dt_s, 2), "ms_per_keyframe": round(dt_s / frames * 1e3, 3),
                               "stage_ms_per_keyframe": {k: round(v / frames, 3) for k, v in ms_s.items()}},
             "edges_per_keyframe": round(st["edges"] / frames, 2), "rejected_frac_of_non_adjacent": round(st["rejected"] / max(1, nonadj), 3),

@@ -473,6 +473,53 @@ def test_calls_on_two_streams_overlap_safely(G, prec):
     assert m.range_report() == (0, 0)
 
 
+def test_split_phase_scheduler_pipelines_two_keyframes(G):
+    """sta_regress_views_begin / _finish: decode + pose heads of keyframe B's edges enqueued (second stream) BEFORE keyframe A's
+    accept / reject + DPT heads run (first stream) - the pipelined schedule of bench.slam_replay - gives bit for bit what the
+    two plain regress_views calls give; a second call on a stream with a pending begin fails loudly, and so does a finish
+    without a begin."""
+    import torch
+    from vista_slam_amd import _lib, weights as W
+    from vista_slam_amd.slam_scheduler import regress_views, regress_views_begin, regress_views_finish
+    m = G.model("full", 1.0, DEFAULT)
+    G.set_variant(m, 0)
+    H = Wd = 224
+    imgs = torch.from_numpy(W.synth_images(6, H, Wd, seed=43, tag=19)).cuda()
+    feats = [m._encode_image(imgs[v:v + 1], None, normalize=False)[0] for v in range(6)]
+    ref_a = regress_views(m, feats[4], feats[1:4], [False, False, True], -1.0, H, Wd)
+    confs = sorted(r.rel_pose_conf for r in ref_a[:2])
+    thres = 0.5 * (confs[0] + confs[1])                       # rejects one of the two non-adjacent edges
+    ref_a = regress_views(m, feats[4], feats[1:4], [False, False, True], thres, H, Wd)
+    ref_b = regress_views(m, feats[5], feats[2:5], [False, False, True], -1.0, H, Wd)
+    torch.cuda.synchronize()
+    assert [r.accepted for r in ref_a].count(False) == 1
+    keep = [(r.accepted, r.pose.clone(), None if not r.accepted else (r.depths.clone(), r.confs.clone(), r.intri.clone())) for r in ref_a + ref_b]
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(2):
+        with torch.cuda.stream(s1):
+            pa = regress_views_begin(m, feats[4], feats[1:4], H, Wd)
+        with torch.cuda.stream(s2):
+            pb = regress_views_begin(m, feats[5], feats[2:5], H, Wd)
+        with torch.cuda.stream(s1):
+            with pytest.raises(_lib.StaError, match="pending"):
+                m._encode_image(imgs[:1], None, normalize=False)           # this stream's scratch context is live
+            with pytest.raises(_lib.StaError, match="not been finished"):
+                regress_views_begin(m, feats[5], feats[2:5], H, Wd)
+            got_a = regress_views_finish(m, pa, [False, False, True], thres)
+        with torch.cuda.stream(s2):
+            got_b = regress_views_finish(m, pb, [False, False, True], -1.0)
+        torch.cuda.synchronize()
+        for r, (acc, pose, rest) in zip(got_a + got_b, keep):
+            assert r.accepted == acc and torch.equal(r.pose, pose)
+            if acc:
+                assert torch.equal(r.depths, rest[0]) and torch.equal(r.confs, rest[1]) and torch.equal(r.intri, rest[2])
+    with torch.cuda.stream(s1):
+        with pytest.raises(_lib.StaError, match="no scheduler call was begun"):
+            regress_views_finish(m, pa, [False, False, True], thres)
+        m._encode_image(imgs[:1], None, normalize=False)                   # and the stream is usable again
+    torch.cuda.synchronize()
+
+
 def _pre_goldens():
     import glob
     import os
