@@ -98,6 +98,13 @@ int sta_kernel_timing_dump_shapes(sta_handle* h, int cap, int* shape6, float* ms
  * sta_kernel_timing(h, 3) times only its launches (bench.py: the dominant kernel inside the timed region). */
 int sta_kernel_timing_filter(sta_handle* h, int epilogue, int a_mode, int family, int mx);
 
+/* In-kernel timeline of ONE launch of the product's GEMM for M x N x K (tools/gemm_stamps.py): every workgroup stores four
+ * 100 MHz stamps (entry, first K tile landed, main loop done, epilogue acknowledged).  resid != 0: the in-place residual form
+ * (at SLAM scale: K slices to slabs).  out[10] (us): workgroups, kernel span (first entry -> last exit), median entry -> first
+ * tile, median main loop, median epilogue, spread of the entries, spread of the exits, HIP-event duration of the same launch,
+ * K slices, median lifetime of a workgroup. */
+int sta_bench_gemm_stamps(sta_handle* h, int M, int N, int K, int resid, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

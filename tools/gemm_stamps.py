@@ -1,0 +1,18 @@
+"""Where does a SLAM-scale GEMM spend its ~14 us?  In-kernel 100 MHz stamps of every workgroup (sta_bench_gemm_stamps)
+against the HIP-event duration of the same launch.      python tools/gemm_stamps.py"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import torch
+from vista_slam_amd import weights as W, _lib
+from vista_slam_amd.sta_frontend import STAFrontend
+m = STAFrontend(W.TINY, "cuda:0", precision="f16x3").load_procedural()
+st = torch.cuda.current_stream().cuda_stream
+print(f"{'shape (M N K, r = in-place residual)':40s} {'WGs':>5s} {'ks':>3s} {'event':>7s} {'span':>7s} {'WG med':>7s} {'->tile0':>7s} {'loop':>7s} {'epilog':>7s} {'entries':>8s} {'exits':>7s}   (us)")
+for M, N, K, r in ((196, 3072, 1024, 0), (196, 1024, 1024, 1), (196, 4096, 1024, 0), (196, 1024, 4096, 1),
+                   (1970, 2304, 768, 0), (1970, 768, 768, 1), (1970, 3072, 768, 0), (1970, 768, 3072, 1),
+                   (12288, 1024, 4096, 1)):
+    for rep in range(2):
+        out = (C.c_double * 10)()
+        _lib.check(m.lib.sta_bench_gemm_stamps(m._h, M, N, K, r, out, st))
+    o = list(out)
+    print(f"{M:6d} {N:5d} {K:5d} {'r' if r else ' ':24s} {int(o[0]):5d} {int(o[8]):3d} {o[7]:7.2f} {o[1]:7.2f} {o[9]:7.2f} {o[2]:7.2f} {o[3]:7.2f} {o[4]:7.2f} {o[5]:8.2f} {o[6]:7.2f}", flush=True)

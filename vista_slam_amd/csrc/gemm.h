@@ -45,7 +45,6 @@ struct GemmParams {
     int mx;                                              // A and B are f16mx rows (sta_common.h); dense GEMMs only
     // ---- EPI_F32
     float* C32; int ldc; const float* resid; int ldr;
-    int rows_in, rows_out, row_off;                      // out_row = (m/rows_in)*rows_out + row_off + m%rows_in
     int ksplit;                                          // >1: split-K, every slice atomically adds into C32 (which already
                                                          //     holds the residual); bias is added by slice 0 only
     float* slab = nullptr;                               // split-K without atomics: slice s stores its partial tile (slice 0 with
@@ -75,6 +74,8 @@ struct GemmParams {
     // ---- misc
     const f16* zero_page;                                // >= 64 B of zeros (OOB taps of the direct-to-LDS conv loader)
     unsigned long long* clk_dbg = nullptr;               // bench only: block 0 stores {shader cycles, 100 MHz ticks} of its lifetime
+    unsigned long long* stamps = nullptr;                // bench only (sta_bench_gemm_stamps): every workgroup stores 4 x s_memrealtime (100 MHz):
+                                                         // kernel entry, first K tile landed, main loop done, epilogue done
 };
 
 #define GEMM_BM 128
@@ -305,15 +306,27 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
     if (EPI == EPI_QKV && p.ksplit <= 1) { epilogue_qkv_tile<SPLIT>(p, acc, row0, col, lane, wave_lds); return; }
     const int lhi = lane >> 5;
     const bool col_ok = col < p.N;
-    if (EPI == EPI_QKV) {          // split-K (small-M regime): raw partial tile to the slab of this slice; qkv_finish_kernel does the rest
+    const float bv = (p.bias != nullptr && col_ok && first_slice) ? p.bias[col] : 0.f;
+    // Split-K partial tile (small-M regime) -> the fp32 slab of this K slice, straight-line: qkv_finish_kernel / splitk_finish_kernel /
+    // resid_ln_kernel sum the slices.  (Left in the generic per-element loop below, the slab store sat behind ~40 scalar
+    // instructions and three uniform branches PER ELEMENT - row remap division, activation / residual / format flags -: stamps
+    // inside the kernel showed 4.5 us of epilogue in an 8-us workgroup for a 32-KB store that takes 1.1 us by itself,
+    // tools/gemm_stamps.py, tools/probes/store_probe.hip.)
+    if ((EPI == EPI_QKV || EPI == EPI_F16 || EPI == EPI_F32) && p.ksplit > 1 && (EPI != EPI_F32 || p.slab != nullptr)) {
+        float* const o = (EPI == EPI_F32 ? p.slab : p.skbuf) + ((size_t)kslice * p.M + row0 + 4 * lhi) * p.N + col;
+        const float b = EPI == EPI_F32 ? bv : 0.f;              // slice 0 of an in-place residual GEMM carries the bias; the finishers add theirs
+        if (row0 + 32 <= p.M && __all(col_ok)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            if (col_ok && row < p.M) p.skbuf[((size_t)kslice * p.M + row) * p.N + col] = acc[r];
+            for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * p.N] = acc[r] + b;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int roff = (r & 3) + 8 * (r >> 2);
+                if (col_ok && row0 + 4 * lhi + roff < p.M) o[(size_t)roff * p.N] = acc[r] + b;
+            }
         }
         return;
     }
-    const float bv = (p.bias != nullptr && col_ok && first_slice) ? p.bias[col] : 0.f;
     if (EPI == EPI_F32R && row0 + 32 <= M_ && __all(col_ok)) {
         // interior tile of the in-place residual epilogue.  ALL 16 residual loads first, then the 16 stores: written as
         // `*c = v + *c` per element the compiler must keep load r+1 behind store r (it cannot prove ldc != 0), and on gfx9 loads
@@ -362,10 +375,44 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
         }
         return;
     }
+    // ---- generic tile.  Written as PHASES over the 16 accumulator rows of the lane, with every wave-uniform flag (activation,
+    // residual planes, output format) tested once per phase: left inside one per-element loop those flags compiled to three
+    // uniform branches and ~40 scalar instructions around EVERY store (stamps: 4.5 - 7 us of epilogue per workgroup).
+    // Everything the epilogue READS from global memory (residual stream, residual planes) is loaded before its first store:
+    // interleaved, every load would wait for the acknowledgement of the store before it (in-order vmcnt, see above).
+    if (EPI == EPI_F32R || EPI == EPI_F32) {
+        const bool interior = row0 + 32 <= M_ && __all(col_ok);
+        bool ok[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ok[r] = interior || (col_ok && row0 + 4 * lhi + (r & 3) + 8 * (r >> 2) < M_);
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[r] + bv;
+        float* const c = p.C32 + (size_t)(row0 + 4 * lhi) * p.ldc + col;
+        if (EPI == EPI_F32 && p.ksplit > 1) {           // atomic split-K (forced tile families only: the product path uses slabs)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) if (ok[r]) unsafeAtomicAdd(c + (size_t)((r & 3) + 8 * (r >> 2)) * p.ldc, v[r]);       // hardware global_atomic_add_f32
+            return;
+        }
+        const float* const rs = EPI == EPI_F32R ? c : (p.resid ? p.resid + (size_t)(row0 + 4 * lhi) * p.ldr + col : nullptr);
+        if (rs) {
+            float pre[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pre[r] = ok[r] ? rs[(size_t)((r & 3) + 8 * (r >> 2)) * (EPI == EPI_F32R ? p.ldc : p.ldr)] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += pre[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) if (ok[r]) c[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = v[r];
+        return;
+    }
+    // ---- plane epilogues (DPT head, mlp.fc1 edge tiles, ConvT scatter): the per-element loop.  (Measured in round 4: the same
+    // phase form as above costs these kernels 50+ VGPRs - hipcc overlaps the phases of a wave's MT x NT tiles - which takes the
+    // second resident workgroup from the 192x128 family and spills in the 16-wave kernels; kept as it was.)
     // Everything this epilogue READS from global memory (residual stream, residual planes) is loaded before its first store:
     // interleaved, every load would wait for the acknowledgement of the store before it (in-order vmcnt, see above).
     float pre1[16], pre2[16];
-    const bool rd32 = EPI == EPI_F32R || (EPI == EPI_F32 && p.resid != nullptr && p.ksplit <= 1);
+    const bool rd32 = false;        // (EPI_F32 / EPI_F32R returned above)
     const bool rd16 = EPI == EPI_F16 && p.ksplit <= 1 && (p.R1_hi != nullptr || p.R2_hi != nullptr);
     if (rd32 || rd16) {
 #pragma unroll
@@ -375,8 +422,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
             if (!(col_ok && row < M_)) continue;
             if (EPI == EPI_F32R) pre1[r] = p.C32[(size_t)row * p.ldc + col];
             else if (EPI == EPI_F32) {
-                int orow = row;
-                if (p.rows_in > 0) orow = (row / p.rows_in) * p.rows_out + p.row_off + row % p.rows_in;
+                const int orow = row;
                 pre1[r] = p.resid[(size_t)orow * p.ldr + col];
             } else {
                 const size_t o = blk_off<SPLIT>(row, col, p.c_rp);
@@ -399,8 +445,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
             if (ok) p.C32[(size_t)row * p.ldc + col] = v + pre1[r];
         } else if (EPI == EPI_F32) {
             if (ok) {
-                int orow = row;
-                if (p.rows_in > 0) orow = (row / p.rows_in) * p.rows_out + p.row_off + row % p.rows_in;
+                const int orow = row;
                 if (p.ksplit > 1 && p.slab) {
                     p.slab[((size_t)kslice * p.M + row) * p.N + col] = v;
                 } else if (p.ksplit > 1) {

@@ -211,6 +211,8 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
     const int l31 = lane & 31, lhi = lane >> 5;
     unsigned long long clk0 = 0, rt0 = 0;
     if (p.clk_dbg) { clk0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    if (p.stamps) st0 = __builtin_amdgcn_s_memrealtime();
 
     // ---- block id -> (tile, K slice) (XCD-aware, band-major; the slices of one tile are consecutive ids)
     const int tiles_m = (p.M - (HAS_TAIL ? p.m_tail : 0) + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
@@ -323,6 +325,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
         issue_tile(kt0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (p.stamps) st1 = __builtin_amdgcn_s_memrealtime();
     }
 
     // STAGGER (ABL bit 3, experiment): the two waves that share a SIMD (w and w + NW/2) issue their DMA at
@@ -339,6 +342,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
             else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GPW) : "memory");
             else if (rem == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * GPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * GPW) : "memory");
+            if (p.stamps && kt == 0) st1 = __builtin_amdgcn_s_memrealtime();
             // the barrier also says every wave finished tile kt-1: its stage is free for tile kt+NSTG-1
             if (kt + NSTG - 1 < nkt) issue_tile(kt0 + kt + NSTG - 1, (kt + NSTG - 1) % NSTG);
         } else if (kt + 1 < nkt && !(ABL & 1) && !late_dma) issue_tile(kt0 + kt + 1, cur ^ 1);
@@ -492,6 +496,10 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
         }
     }
 
+    if (p.stamps) {      // after the LAST MFMA has delivered (the stamp is scalar code: without the data dependence it is scheduled early)
+        asm volatile("" ::"v"(acc[MT - 1][NT - 1][15]), "v"(acc[0][0][0]) : "memory");
+        st2 = __builtin_amdgcn_s_memrealtime();
+    }
     if constexpr (EPI == EPI_HEAD) {
         if constexpr (BN == 128) head_epilogue<BM, MT, NT, WM, WAVES_N>(p, acc, m0, 32, BM / 32, 32, wm, wn, tid, smem);
     } else {
@@ -503,6 +511,13 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
 #pragma unroll
             for (int i = 0; i < MT; ++i)
                 epilogue_tile<SPLIT, EPI>(p, acc[i][j], m0 + wm * WM + i * 32, n0 + wn * WN + j * 32 + l31, lane, kslice, -1, wave_lds);
+    }
+    if (p.stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the epilogue's stores acknowledged
+        if (tid == 0) {
+            unsigned long long* o = p.stamps + (size_t)block_id_in * 4;
+            o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memrealtime();
+        }
     }
     if (p.clk_dbg && tid == 0 && (block_id & 63) == 0) {      // effective shader clock = cycles / (ticks / 100 MHz)
         atomicAdd(p.clk_dbg, __builtin_readcyclecounter() - clk0);

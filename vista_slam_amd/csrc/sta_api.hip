@@ -8,6 +8,7 @@
 #include "attention.h"
 #include "elementwise.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -633,7 +634,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st, in
     if (variant == 6) {
         const int tiles_r = ((p.M + 127) / 128) * (p.N / 64);
         const int tiles = h->deterministic ? (1 << 30) : tiles_r;    // deterministic: no ATOMIC split-K (the slab forms below have a fixed order)
-        if (AMODE == A_DENSE && EPI == EPI_F32 && p.resid == p.C32 && p.rows_in == 0 && p.slab) {
+        if (AMODE == A_DENSE && EPI == EPI_F32 && p.resid == p.C32 && p.slab) {
             // the caller finishes the GEMM in the LayerNorm kernel that follows (gemm_resid_ln): slices store partial tiles
             // to slabs instead of atomically adding to the residual stream (the device-scope fp32 atomics of 256 workgroups
             // cost more than the 4-32 K tiles of a slice); fixed summation order -> also taken in deterministic mode
@@ -644,7 +645,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st, in
             if (ks > max_ks) ks = max_ks;
             while (ks > 1 && (int64_t)ks * p.M * p.N > SKBUF_ELEMS) --ks;
             if (ks > 1) { p.ksplit = ks; slab_ks = ks; } else p.slab = nullptr;
-        } else if (AMODE == A_DENSE && EPI == EPI_F32 && p.resid == p.C32 && p.rows_in == 0 && tiles < 256) {
+        } else if (AMODE == A_DENSE && EPI == EPI_F32 && p.resid == p.C32 && tiles < 256) {
             int ks = (256 + tiles - 1) / tiles;
             const int max_ks = p.K / 128;                 // keep >= 4 K tiles per slice
             if (ks > max_ks) ks = max_ks;
@@ -803,12 +804,11 @@ static GemmParams gp_dense(const Planes& A, int lda, const Lin& W, int M, bool m
 static bool use_mx(const sta_handle* h, const Lin& W) { return (h->mx_mask & W.cls) != 0 && W.wmx.hi != nullptr && W.N % 64 == 0; }
 
 static int gemm_f32(sta_handle* h, const Planes& A, const Lin& W, int M, float* out, int ldc,
-                    const float* resid, hipStream_t st, int rows_in = 0, int rows_out = 0, int row_off = 0) {
+                    const float* resid, hipStream_t st) {
     GemmParams p = gp_dense(A, W.K, W, M, use_mx(h, W));
     p.C32 = out; p.ldc = ldc; p.resid = resid; p.ldr = ldc;
-    p.rows_in = rows_in; p.rows_out = rows_out; p.row_off = row_off;
     // throughput-scale in-place residual GEMMs (attn.proj, mlp.fc2, cross_attn.proj): specialised epilogue
-    if (resid == out && rows_in == 0 && !small_grid(h, M, W.N))
+    if (resid == out && !small_grid(h, M, W.N))
         return launch_gemm<A_DENSE, EPI_F32R>(h, p, st);
     return launch_gemm<A_DENSE, EPI_F32>(h, p, st);
 }
@@ -836,7 +836,7 @@ static int gemm_resid_ln(sta_handle* h, const Planes& A, const Lin& W, int M, fl
     const bool small = small_grid(h, M, W.N) && W.N % 64 == 0 && W.N <= 1024 && auto_family(h) && ld == W.N;
     if (small) {
         GemmParams p = gp_dense(A, W.K, W, M, use_mx(h, W));
-        p.C32 = x; p.ldc = ld; p.resid = x; p.ldr = ld; p.rows_in = 0; p.rows_out = 0; p.row_off = 0;
+        p.C32 = x; p.ldc = ld; p.resid = x; p.ldr = ld;
         p.slab = h->cur->slab;
         int ks = 0;
         CHK((launch_gemm<A_DENSE, EPI_F32>(h, p, st, &ks)));
