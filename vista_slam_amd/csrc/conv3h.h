@@ -253,7 +253,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3h_kernel(const Gem
             for (int i = 0; i < MT; ++i) {
                 const int yy = y0 + wm * MT + i;
                 const int row0 = (img * p.Ho + yy) * p.Wo + x0;
-                epilogue_tile<SPLIT, EPI>(p, acc[i][j], row0, n0 + wn * WN + j * 32 + l31, lane, 0, yy < p.Ho ? row0 + cols_valid : row0);
+                { epilogue_tile<SPLIT, EPI>(p, acc[i][j], row0, n0 + wn * WN + j * 32 + l31, lane, 0, yy < p.Ho ? row0 + cols_valid : row0); STA_EPI_TILE_FENCE(); }
             }
     }
 }

@@ -406,92 +406,75 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
         for (int r = 0; r < 16; ++r) if (ok[r]) c[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldc] = v[r];
         return;
     }
-    // ---- plane epilogues (DPT head, mlp.fc1 edge tiles, ConvT scatter): the per-element loop.  (Measured in round 4: the same
-    // phase form as above costs these kernels 50+ VGPRs - hipcc overlaps the phases of a wave's MT x NT tiles - which takes the
-    // second resident workgroup from the 192x128 family and spills in the 16-wave kernels; kept as it was.)
-    // Everything this epilogue READS from global memory (residual stream, residual planes) is loaded before its first store:
-    // interleaved, every load would wait for the acknowledgement of the store before it (in-order vmcnt, see above).
-    float pre1[16], pre2[16];
-    const bool rd32 = false;        // (EPI_F32 / EPI_F32R returned above)
-    const bool rd16 = EPI == EPI_F16 && p.ksplit <= 1 && (p.R1_hi != nullptr || p.R2_hi != nullptr);
-    if (rd32 || rd16) {
+    // ---- plane epilogues (DPT head, mlp.fc1 edge tiles) and the ConvT scatter: one loop over the lane's 16 rows with the flags
+    // made branch-free where that is free (ReLU as a floor that is -inf otherwise; absent residual planes read as 0) and the
+    // output format tested once, outside the loop.  The callers put a scheduling barrier between a wave's tiles
+    // (STA_EPI_TILE_FENCE): left free, hipcc overlaps the tiles' phases and the kernel needs 50+ more VGPRs.
+    const bool interior = row0 + 32 <= M_ && __all(col_ok);
+    bool ok[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ok[r] = interior || (col_ok && row0 + 4 * lhi + (r & 3) + 8 * (r >> 2) < M_);
+    float pre[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pre[r] = 0.f;
+    if (EPI == EPI_F16 && (p.R1_hi != nullptr || p.R2_hi != nullptr)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            pre1[r] = 0.f; pre2[r] = 0.f;
-            if (!(col_ok && row < M_)) continue;
-            if (EPI == EPI_F32R) pre1[r] = p.C32[(size_t)row * p.ldc + col];
-            else if (EPI == EPI_F32) {
-                const int orow = row;
-                pre1[r] = p.resid[(size_t)orow * p.ldr + col];
+            if (!ok[r]) continue;
+            const size_t o = blk_off<SPLIT>(row0 + 4 * lhi + (r & 3) + 8 * (r >> 2), col, p.c_rp);
+            if (SPLIT && p.r_mx) {
+                if (p.R1_hi) pre[r] = load_mx_act(p.R1_hi, o);
+                if (p.R2_hi) pre[r] += load_mx_act(p.R2_hi, o);
             } else {
-                const size_t o = blk_off<SPLIT>(row, col, p.c_rp);
-                if (SPLIT && p.r_mx) {
-                    if (p.R1_hi) pre1[r] = load_mx_act(p.R1_hi, o);
-                    if (p.R2_hi) pre2[r] = load_mx_act(p.R2_hi, o);
-                } else {
-                    if (p.R1_hi) pre1[r] = (float)p.R1_hi[o] + (SPLIT ? (float)p.R1_hi[o + 32] : 0.f);
-                    if (p.R2_hi) pre2[r] = (float)p.R2_hi[o] + (SPLIT ? (float)p.R2_hi[o + 32] : 0.f);
-                }
+                if (p.R1_hi) pre[r] = (float)p.R1_hi[o] + (SPLIT ? (float)p.R1_hi[o + 32] : 0.f);
+                if (p.R2_hi) pre[r] += (float)p.R2_hi[o] + (SPLIT ? (float)p.R2_hi[o + 32] : 0.f);
             }
         }
     }
+    const float floor_ = (EPI != EPI_GELU && p.act == ACT_RELU) ? 0.f : -INFINITY;
+    const bool gelu = EPI == EPI_GELU || p.act == ACT_GELU;
+    auto value = [&](int r) {
+        float x = acc[r] + bv;
+        if (gelu) x = gelu_erf(x);            // (EPI_F16 with GELU: un-split mlp.fc1 of tiny test shapes only)
+        return fmaxf(x, floor_) + pre[r];
+    };
+    if (EPI == EPI_GELU || EPI == EPI_F16) {
+        if (SPLIT && EPI == EPI_F16 && p.c_mx) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        const bool ok = col_ok && row < M_;
-        float v = acc[r] + bv;
-        if (EPI == EPI_F32R) {
-            if (ok) p.C32[(size_t)row * p.ldc + col] = v + pre1[r];
-        } else if (EPI == EPI_F32) {
-            if (ok) {
-                const int orow = row;
-                if (p.ksplit > 1 && p.slab) {
-                    p.slab[((size_t)kslice * p.M + row) * p.N + col] = v;
-                } else if (p.ksplit > 1) {
-                    unsafeAtomicAdd(p.C32 + (size_t)orow * p.ldc + col, v);       // hardware global_atomic_add_f32
-                } else {
-                    if (p.resid) v += pre1[r];
-                    p.C32[(size_t)orow * p.ldc + col] = v;
-                }
+            for (int r = 0; r < 16; ++r)
+                if (ok[r]) store_mx1<false>(p.C_hi, blk_off<SPLIT>(row0 + 4 * lhi + (r & 3) + 8 * (r >> 2), col, p.c_rp), value(r), ra);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (!ok[r]) continue;
+                const size_t o = blk_off<SPLIT>(row0 + 4 * lhi + (r & 3) + 8 * (r >> 2), col, p.c_rp);
+                const float x = value(r);
+                if (SPLIT) { f16 h, l; split_f16(x, h, l, ra); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
+                else p.C_hi[o] = to_f16_sat(x, ra);
             }
-        } else if (EPI == EPI_GELU) {       // the one hot plane epilogue (fc1): no per-element flag branches
-            if (ok) {
-                v = gelu_erf(v);
-                const size_t o = blk_off<SPLIT>(row, col, p.c_rp);
-                if (SPLIT) { f16 h, l; split_f16(v, h, l, ra); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
-                else p.C_hi[o] = to_f16_sat(v, ra);
-            }
-        } else if (EPI == EPI_F16) {
-            if (ok && p.ksplit > 1) {
-                p.skbuf[((size_t)kslice * p.M + row) * p.N + col] = acc[r];       // slab of this K slice; splitk_finish_kernel sums them
-            } else if (ok) {
-                if (p.act == ACT_GELU) v = gelu_erf(v);
-                else if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-                const size_t o = blk_off<SPLIT>(row, col, p.c_rp);
-                if (p.R1_hi) v += pre1[r];
-                if (p.R2_hi) v += pre2[r];
-                if (SPLIT && p.c_mx) store_mx1<false>(p.C_hi, o, v, ra);
-                else if (SPLIT) { f16 h, l; split_f16(v, h, l, ra); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
-                else p.C_hi[o] = to_f16_sat(v, ra);
-            }
-        } else {  // EPI_CONVT
-            if (ok) {
-                int g = col / p.ct_cout, co = col - g * p.ct_cout;
-                int dy = g / p.ct_k, dx = g - dy * p.ct_k;
-                int hw = p.ct_h * p.ct_w;
-                int img = row / hw, rem = row - img * hw;
-                int y = rem / p.ct_w, x = rem - y * p.ct_w;
-                const size_t opix = ((size_t)img * (p.ct_h * p.ct_k) + (y * p.ct_k + dy)) * (p.ct_w * p.ct_k) + (x * p.ct_k + dx);
-                const size_t o = blk_off<SPLIT>(opix, co, p.c_rp);
-                if (SPLIT && p.c_mx) store_mx1<false>(p.C_hi, o, v, ra);
-                else if (SPLIT) { f16 h, l; split_f16(v, h, l, ra); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
-                else p.C_hi[o] = to_f16_sat(v, ra);
-            }
+        }
+    } else {  // EPI_CONVT: pixel scatter
+        const int g = col / p.ct_cout, co = col - g * p.ct_cout;
+        const int dy = g / p.ct_k, dx = g - dy * p.ct_k;
+        const int hw = p.ct_h * p.ct_w;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (!ok[r]) continue;
+            const int row = row0 + 4 * lhi + (r & 3) + 8 * (r >> 2);
+            const int img = row / hw, rem = row - img * hw;
+            const int y = rem / p.ct_w, x = rem - y * p.ct_w;
+            const size_t opix = ((size_t)img * (p.ct_h * p.ct_k) + (y * p.ct_k + dy)) * (p.ct_w * p.ct_k) + (x * p.ct_k + dx);
+            const size_t o = blk_off<SPLIT>(opix, co, p.c_rp);
+            const float v = acc[r] + bv;
+            if (SPLIT && p.c_mx) store_mx1<false>(p.C_hi, o, v, ra);
+            else if (SPLIT) { f16 h, l; split_f16(v, h, l, ra); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
+            else p.C_hi[o] = to_f16_sat(v, ra);
         }
     }
     if (EPI != EPI_GELU) ra.flush();
 }
+// between the tiles of one wave's epilogue: nothing moves across (keeps ONE tile's temporaries live; see epilogue_tile)
+#define STA_EPI_TILE_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // Second half of a split-K GEMM with the QKV epilogue (small-M regime): sums the K-slice slabs skbuf[s][M,N], adds the
 // bias, rotates Q / K (RoPE pairs (d, d+16) sit in lanes l and l^16 of a wave: a wave is one 64-column head of one row) and
@@ -709,5 +692,5 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            epilogue_tile<SPLIT, EPI>(p, acc[i][j], m0 + wm * 64 + i * 32, n0 + wn * 64 + j * 32 + l31, lane);
+            { epilogue_tile<SPLIT, EPI>(p, acc[i][j], m0 + wm * 64 + i * 32, n0 + wn * 64 + j * 32 + l31, lane); STA_EPI_TILE_FENCE(); }
 }

@@ -510,7 +510,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
-                epilogue_tile<SPLIT, EPI>(p, acc[i][j], m0 + wm * WM + i * 32, n0 + wn * WN + j * 32 + l31, lane, kslice, -1, wave_lds);
+                { epilogue_tile<SPLIT, EPI>(p, acc[i][j], m0 + wm * WM + i * 32, n0 + wn * WN + j * 32 + l31, lane, kslice, -1, wave_lds); if (EPI == EPI_F16 || EPI == EPI_CONVT) STA_EPI_TILE_FENCE(); }
     }
     if (p.stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the epilogue's stores acknowledged
