@@ -102,8 +102,9 @@ int sta_kernel_timing_filter(sta_handle* h, int epilogue, int a_mode, int family
  * 100 MHz stamps (entry, first K tile landed, main loop done, epilogue acknowledged).  resid != 0: the in-place residual form
  * (at SLAM scale: K slices to slabs).  out[10] (us): workgroups, kernel span (first entry -> last exit), median entry -> first
  * tile, median main loop, median epilogue, spread of the entries, spread of the exits, HIP-event duration of the same launch,
- * K slices, median lifetime of a workgroup. */
-int sta_bench_gemm_stamps(sta_handle* h, int M, int N, int K, int resid, double* out, void* stream);
+ * K slices, median lifetime of a workgroup.  resid == 2: the specialised in-place residual epilogue of the throughput families.
+ * raw_host (may be NULL): the four stamps of the first raw_cap workgroups (block id order; block b runs on XCD b % 8). */
+int sta_bench_gemm_stamps(sta_handle* h, int M, int N, int K, int resid, double* out, unsigned long long* raw_host, int raw_cap, void* stream);
 
 #ifdef __cplusplus
 }

@@ -97,10 +97,13 @@ def shapes(variants, steps=3):
     for key, per in table.items():
         M, N, K, e, a, mx = key
         gf = 2.0 * M * N * K / 1e9
-        cnt = len(per[variants[0]]) // steps
+        cnt = max(len(per[v]) for v in variants) // steps
         row = f"{M:8d} {N:5d} {K:5d} {epi[e]:>5s} {'conv' if a else 'dns':>4s}{'*' if mx else ' '} {cnt:5d} {gf:8.2f} |"
         for v in variants:
             ts = [t for t, _ in per[v]]
+            if not ts:
+                row += "        -              |"
+                continue
             avg = sum(ts) / len(ts)
             tot[v] += sum(ts) / steps
             row += f" {avg:8.1f} ({gf / avg * 1e3:5.0f}) [{per[v][0][1]}] |"
