@@ -29,9 +29,19 @@ def main(paths):
         ev = sorted(db.execute(f"select start, end, {namecol} from kernels"))[-tail:]
         busy = sum(e - s for s, e, _ in ev) / 1e3
         gaps = [max(0, ev[i + 1][0] - ev[i][1]) / 1e3 for i in range(len(ev) - 1)]
-        span = (ev[-1][1] - ev[0][0]) / 1e3
+        span = (max(e for _, e, _ in ev) - ev[0][0]) / 1e3
+        # several streams: kernels overlap - the time at least one kernel is running (union of the intervals) and the average
+        # number of kernels in flight while the GPU is busy
+        union, cur_s, cur_e = 0, ev[0][0], ev[0][1]
+        for s_, e_, _ in ev[1:]:
+            if s_ > cur_e:
+                union += cur_e - cur_s; cur_s, cur_e = s_, e_
+            else:
+                cur_e = max(cur_e, e_)
+        union = (union + cur_e - cur_s) / 1e3
         print(f"last {len(ev)} dispatches: span {span:.1f} us, sum of kernel durations {busy:.1f} us, idle between kernels {sum(gaps):.1f} us "
-              f"({len([g for g in gaps if g > 0])} gaps, median {sorted(gaps)[len(gaps) // 2]:.2f} us, max {max(gaps):.1f} us)")
+              f"({len([g for g in gaps if g > 0])} gaps, median {sorted(gaps)[len(gaps) // 2]:.2f} us, max {max(gaps):.1f} us); "
+              f"at least one kernel running {union:.1f} us ({100 * union / span:.1f} % of the span), {busy / union:.2f} kernels in flight on average while busy")
         for s_, e_, n_ in ev:
             r = rows.setdefault(short(n_)[:88], [0, 0.0, 1e30, 0.0]); d = (e_ - s_) / 1e3
             r[0] += 1; r[1] += d; r[2] = min(r[2], d); r[3] = max(r[3], d)

@@ -240,7 +240,11 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
     const int row_in = lane / CPR, c_lds = lane % CPR;
     unsigned a_src[SA], b_src[SB];         // BYTE offsets of this lane's 16 B within K tile 0 (32-bit: the K-tile base is
                                            // wave-uniform, so the DMA uses the SGPR-base + VGPR-offset address form)
-    int cv_img[SA], cv_y[SA], cv_x[SA], cv_chunk[SA]; bool cv_ok[SA];
+    // 3x3 taps: per slot the pixel index of tap (0,0) (may lie outside the image), a 9-bit mask of the taps that fall inside it,
+    // and the lane's byte offset inside a row block - tap t of channel block cb is then ONE 32-bit add away (round 4: the
+    // address of every tap used to be rebuilt from (image, y, x) with two exec-masked bounds branches and 64-bit multiplies per
+    // slot plus a scalar division per K tile: ~400 issue cycles per K tile next to 512 cycles of f16mx MFMAs)
+    int cv_pix0[SA]; unsigned cv_mask[SA], cv_coff[SA];
 #pragma unroll
     for (int s = 0; s < SA; ++s) {
         const int row = RPS * (wave + NW * s) + row_in;                      // tile row
@@ -251,14 +255,21 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
             const int gmc = gm < p.M ? gm : p.M - 1;
             a_src[s] = ((unsigned)gmc * A_ES + chunk * 8) * 2u;
         } else {
-            cv_ok[s] = gm < p.M;
-            const int gmc = cv_ok[s] ? gm : 0;
+            const bool rok = gm < p.M;
+            const int gmc = rok ? gm : 0;
             const int hw = p.Ho * p.Wo;
-            cv_img[s] = gmc / hw;
-            const int rem = gmc - cv_img[s] * hw;
-            cv_y[s] = (rem / p.Wo) * p.cstride - 1;
-            cv_x[s] = (rem % p.Wo) * p.cstride - 1;
-            cv_chunk[s] = chunk;
+            const int img = gmc / hw;
+            const int rem = gmc - img * hw;
+            const int y0 = (rem / p.Wo) * p.cstride - 1, x0 = (rem % p.Wo) * p.cstride - 1;
+            cv_pix0[s] = (img * p.Hi + y0) * p.Wi + x0;
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yi = y0 + t / 3, xi = x0 + t % 3;
+                if (rok && yi >= 0 && yi < p.Hi && xi >= 0 && xi < p.Wi) mk |= 1u << t;
+            }
+            cv_mask[s] = mk;
+            cv_coff[s] = (unsigned)chunk * 16u;
             a_src[s] = 0;
         }
     }
@@ -272,11 +283,18 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
     }
     const size_t a_kstride = (size_t)p.a_rp * A_ES, b_kstride = (size_t)p.N * 64;
 
+    int cv_tap = 0, cv_cb = 0;             // conv: (tap, channel block) of the NEXT K tile to be issued (set below, once kt0 is known)
     auto issue_tile = [&](int kt, int stage) {
         char* sA = smem + stage * STAGE;
         char* sB = sA + A_TILE;
-        int tap = 0, cb = 0, ky = 0, kx = 0;
-        if (AMODE == A_CONV3) { const int cblocks = p.Cin >> 5; tap = kt / cblocks; cb = kt - tap * cblocks; ky = tap / 3; kx = tap - ky * 3; }
+        // conv: K tile kt = (tap, channel block); the tiles are issued in increasing kt, so the pair is carried as a counter
+        // (cv_tap / cv_cb, set for kt0 before the first call) instead of being re-derived by a division per call
+        int tap_off = 0; const char* a_cb = nullptr;
+        if (AMODE == A_CONV3) {
+            const int ky = cv_tap >= 6 ? 2 : (cv_tap >= 3 ? 1 : 0), kx = cv_tap - 3 * ky;
+            tap_off = ky * p.Wi + kx;
+            a_cb = reinterpret_cast<const char*>(p.A_hi) + (size_t)cv_cb * p.a_rp * (A_ES * 2);
+        }
 #pragma unroll
         for (int s = 0; s < SA; ++s) {
             if (NSA % NW != 0 && wave + NW * s >= NSA) continue;
@@ -286,12 +304,12 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
                 asm volatile("" : "+v"(o));      // opaque: keeps the 32-bit offset form (hipcc would hoist base + offset into a VGPR pair)
                 glds16(reinterpret_cast<const char*>(p.A_hi + kt * a_kstride) + o, dst);
             } else {
-                const int yi = cv_y[s] + ky, xi = cv_x[s] + kx;
-                const bool ok = cv_ok[s] && yi >= 0 && yi < p.Hi && xi >= 0 && xi < p.Wi;
-                const size_t pix = (size_t)(cv_img[s] * p.Hi + yi) * p.Wi + xi;
-                glds16(ok ? p.A_hi + ((size_t)cb * p.a_rp + pix) * A_ES + cv_chunk[s] * 8 : p.zero_page, dst);
+                const unsigned off = (unsigned)(cv_pix0[s] + tap_off) * (unsigned)(A_ES * 2) + cv_coff[s];     // (pixels x 128 B < 2^32: checked by the launcher)
+                const bool ok = (cv_mask[s] >> cv_tap) & 1u;
+                glds16(ok ? static_cast<const void*>(a_cb + off) : static_cast<const void*>(p.zero_page), dst);
             }
         }
+        if (AMODE == A_CONV3) { if (++cv_cb == (p.Cin >> 5)) { cv_cb = 0; ++cv_tap; } }
 #pragma unroll
         for (int s = 0; s < SB; ++s) {
             if (NSB % NW != 0 && wave + NW * s >= NSB) continue;
@@ -313,6 +331,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
     const int nkt_all = p.K / GEMM_BK;
     const int kt0 = (int)((int64_t)kslice * nkt_all / ksplit);
     const int nkt = (int)((int64_t)(kslice + 1) * nkt_all / ksplit) - kt0;
+    if (AMODE == A_CONV3) { const int cblocks = p.Cin >> 5; cv_tap = kt0 / cblocks; cv_cb = kt0 - cv_tap * cblocks; }
     constexpr bool RING = NSTG > 2;
     constexpr int GPW = SA + SB;                   // DMA instructions per wave per K tile
     static_assert(!RING || (NSA % NW == 0 && NSB % NW == 0), "ring needs the same DMA count in every wave");

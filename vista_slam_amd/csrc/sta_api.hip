@@ -611,6 +611,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st, in
     // the LDS-DMA loaders address a K tile with 32-bit byte offsets (128 B per row of a row block)
     REQUIRE((AMODE != A_DENSE || (int64_t)p.M * 128 < ((int64_t)1 << 32)) && (int64_t)p.N * 128 < ((int64_t)1 << 32),
             "GEMM with M=%d, N=%d exceeds the 32-bit row-offset range of the DMA loaders", p.M, p.N);
+    if (AMODE == A_CONV3) REQUIRE((int64_t)p.a_rp * 128 < ((int64_t)1 << 32), "convolution input of %lld pixels exceeds the 32-bit offset range of the tap loader", (long long)p.a_rp);
     if (h->dry) return 0;
     const bool split = h->prec != STA_PREC_F16;
     // Row tail hint (decode_impl: the 2B pose-token rows after the 2B x N patch rows).  Tile rules below look at the
