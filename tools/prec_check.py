@@ -10,6 +10,8 @@ if "--stress" in sys.argv:
     CASES = ["tiny_48x64_b2_sharp", "tiny_48x80_smooth_sharp"] + STRESS
 if "--outlier" in sys.argv:
     CASES = OUTLIER
+if "--fullstress" in sys.argv:      # round 4: peaky attention / checkpoint-like ranges on the FULL architecture, incl. the headline resolution
+    CASES = ["full_384x512_b1_sharp", "full_384x512_b1_outlier", "full_224_b1_sharp", "full_224_b1_sharp_s44_smooth", "full_224_b1_sharp_s45", "full_224_b1_outlier"]
 precs = [p_ for p_ in precs if p_ != "--outlier"]
 for prec in precs:
     for case in CASES:

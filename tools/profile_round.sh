@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/round; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 280 python $R/bench.py > $O/bench_1gpu.json 2> $O/bench.err
-timeout 280 rocprofv3 --kernel-trace -d $O/trace_bench -o t -- python $R/bench.py --no-cpu-baseline --no-slam-probe --slam-frames 0 --no-alt-precision > $O/bench_traced.json 2> $O/trace_bench.err
+timeout 280 rocprofv3 --kernel-trace -d $O/trace_bench -o t -- python $R/bench.py --no-cpu-baseline --no-slam-probe --slam-frames 0 > $O/bench_traced.json 2> $O/trace_bench.err
 timeout 200 rocprofv3 --kernel-trace -d $O/trace_steps -o t -- python $R/tools/model_steps.py 0 6 f16x3h > /dev/null 2> $O/trace_steps.err
 timeout 200 python $R/tools/gemm_tiles.py shapes 0 > $O/gemm_shapes.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
