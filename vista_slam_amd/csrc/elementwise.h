@@ -289,29 +289,47 @@ __global__ void emit_tokens_kernel(const float* x, int s0, int B, int N, int D, 
 // ---------------------------------------------------------------------------------------------
 // Bilinear x2 upsample, align_corners=True (dpt_block.py:215-216,320), NHWC fp16 planes.
 // Output may be cropped to (Hc,Wc) <= (2Hi,2Wi) (dpt_head.py:58); interpolation ratios always use
-// the full (2Hi,2Wi) grid.  One workgroup = one output row (b, y): the row's taps / weights are block-uniform and the
-// per-element index math is 32-bit; one thread = 8 channels of one output pixel per step.
-template <bool SPLIT>
+// the full (2Hi,2Wi) grid.  One workgroup = NR consecutive output rows of one image: the rows' taps / weights are block-uniform
+// and the per-element index math is 32-bit; one thread = 8 channels of one output COLUMN, for all NR rows, per step.
+// NR = 4 (round 4): four consecutive output rows read four consecutive input rows (align_corners x2: rows 2m .. 2m+3 <- m-1 .. m+2),
+// so a thread fetches 4 rows x 2 columns of taps ONCE for 4 outputs - 16 tap loads instead of 32 - and an input row is
+// fetched from L2 by ~1.5 workgroups instead of 4.  The kernel was bound by exactly that traffic: 1.6 GB of (re-)fetched
+// input + 1.6 GB of output through the L2 <-> CU fabric in 720 us = 4.4 TB/s, the copy rate of this chip; its loads cost
+// 40 us alone and 250 us next to the stores (round-3 ablation), and re-ordering them around the stores (software pipeline,
+// round 4) changed nothing.
+template <bool SPLIT, int NR>
 __global__ __launch_bounds__(256) void bilinear_up2_kernel(const f16* i_hi, const f16* i_lo, int n, int Hi, int Wi, int C,
                                                            int Hc, int Wc, f16* o_hi, f16* o_lo, int mx = 0 /* input and output are f16mx rows */) {
     const int c8 = C / 8;
     const float ry = Hi > 1 ? (float)(Hi - 1) / (float)(2 * Hi - 1) : 0.f;
     const float rx = Wi > 1 ? (float)(Wi - 1) / (float)(2 * Wi - 1) : 0.f;
-    // XCD-aware row order: consecutive workgroups run on different XCDs (block b -> XCD b % 8), and two neighbouring output
-    // rows read the same two input rows - so give every XCD a contiguous band of output rows (its L2 then fetches an input
+    // XCD-aware row order: consecutive workgroups run on different XCDs (block b -> XCD b % 8), and neighbouring output
+    // rows read the same input rows - so give every XCD a contiguous band of output rows (its L2 then fetches an input
     // row once instead of once per XCD: the counters showed 5x the algorithmic read bytes with the plain order)
     int bid;
     {
         const int nwg = gridDim.x, q = nwg / 8, r = nwg % 8, xcd = blockIdx.x % 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + blockIdx.x / 8;
     }
-    const int b = bid / Hc, y = bid - b * Hc;
-    const float sy = ry * y;
-    const int y0 = (int)sy, y1 = y0 + (y0 < Hi - 1);
-    const float fy = sy - y0;
+    const int groups = (Hc + NR - 1) / NR;
+    const int b = bid / groups, yg = (bid - b * groups) * NR;
+    // input rows of the group: [ybase, ybase + NR] at most (NR + 1 rows: the regular x2 pattern needs NR, a crop / tiny image may differ)
+    int y0r[NR], y1r[NR]; float fyr[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int y = yg + k < Hc ? yg + k : Hc - 1;
+        const float sy = ry * y;
+        y0r[k] = (int)sy; y1r[k] = y0r[k] + (y0r[k] < Hi - 1); fyr[k] = sy - y0r[k];
+    }
+    const int ybase = y0r[0];
+    bool regular = NR == 4 && yg + 3 < Hc;                   // the interior pairing (0,1) (1,2) (1,2) (2,3)
+    if (NR == 4) {
+        const int pa[4] = {0, 1, 1, 2}, pb[4] = {1, 2, 2, 3};
+#pragma unroll
+        for (int k = 0; k < NR; ++k) regular = regular && y0r[k] - ybase == pa[k & 3] && y1r[k] - ybase == pb[k & 3];
+    }
+    constexpr int NIN = NR + 1;                              // rows ybase .. ybase + NR cover every tap of the group
     const int64_t irows = (int64_t)n * Hi * Wi, orows = (int64_t)n * Hc * Wc;
-    const size_t r0 = (size_t)b * Hi * Wi + (size_t)y0 * Wi, r1 = (size_t)b * Hi * Wi + (size_t)y1 * Wi;
-    const size_t orow = ((size_t)b * Hc + y) * Wc;
     const bool pow2 = (c8 & (c8 - 1)) == 0;
     const int sh = __ffs(c8) - 1;
     const int per_row = Wc * c8;
@@ -321,44 +339,75 @@ __global__ __launch_bounds__(256) void bilinear_up2_kernel(const f16* i_hi, cons
         const float sx = rx * x;
         const int x0 = (int)sx, x1 = x0 + (x0 < Wi - 1);
         const float fx = sx - x0;
-        const size_t o00 = blk_off<SPLIT>(r0 + x0, c, irows), o01 = blk_off<SPLIT>(r0 + x1, c, irows);
-        const size_t o10 = blk_off<SPLIT>(r1 + x0, c, irows), o11 = blk_off<SPLIT>(r1 + x1, c, irows);
-        H8 a, b_, c_, d; a.u = ldg16(i_hi + o00); b_.u = ldg16(i_hi + o01); c_.u = ldg16(i_hi + o10); d.u = ldg16(i_hi + o11);
-        H8 al, bl, cl, dl;
-        if (SPLIT) { al.u = ldg16(i_hi + o00 + 32); bl.u = ldg16(i_hi + o01 + 32); cl.u = ldg16(i_hi + o10 + 32); dl.u = ldg16(i_hi + o11 + 32); }
-        H8 oh, ol;
-        float vout[8];
-        RangeAcc ra;
+        // taps of the NIN input rows (rows past the last one the group uses are not loaded)
+        float row_top[NIN][8];                               // (1 - fx) * v(x0) + fx * v(x1) of every input row: the horizontal lerp is shared by the output rows
+        const int last_in = y1r[NR - 1] - ybase;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float v00 = (float)a.e[e], v01 = (float)b_.e[e], v10 = (float)c_.e[e], v11 = (float)d.e[e];
-            if (SPLIT && mx) {       // the second field holds (hi8, lo8) byte pairs: value = hi + lo8 * 2^-11
-                constexpr float KL = 1.0f / (float)(1 << STA_MX_A_SLO);
-                v00 += __builtin_amdgcn_cvt_f32_bf8(reinterpret_cast<const unsigned short*>(&al)[e], 1) * KL;
-                v01 += __builtin_amdgcn_cvt_f32_bf8(reinterpret_cast<const unsigned short*>(&bl)[e], 1) * KL;
-                v10 += __builtin_amdgcn_cvt_f32_bf8(reinterpret_cast<const unsigned short*>(&cl)[e], 1) * KL;
-                v11 += __builtin_amdgcn_cvt_f32_bf8(reinterpret_cast<const unsigned short*>(&dl)[e], 1) * KL;
-            } else
-            if (SPLIT) { v00 += (float)al.e[e]; v01 += (float)bl.e[e]; v10 += (float)cl.e[e]; v11 += (float)dl.e[e]; }
-            // same association as ATen upsample_bilinear2d: h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)
-            float top = (1.f - fx) * v00 + fx * v01;
-            float bot = (1.f - fx) * v10 + fx * v11;
-            float v = (1.f - fy) * top + fy * bot;
-            vout[e] = v;
-            if (SPLIT && mx) continue;
-            if (SPLIT) split_f16(v, oh.e[e], ol.e[e], ra); else oh.e[e] = to_f16_sat(v, ra);
+        for (int r = 0; r < NIN; ++r) {
+            if (r > last_in) continue;
+            const int yr = ybase + r < Hi ? ybase + r : Hi - 1;
+            const size_t rb = ((size_t)b * Hi + yr) * Wi;
+            const size_t oa = blk_off<SPLIT>(rb + x0, c, irows), ob = blk_off<SPLIT>(rb + x1, c, irows);
+            H8 a, b_, al, bl;
+            a.u = ldg16(i_hi + oa); b_.u = ldg16(i_hi + ob);
+            if (SPLIT) { al.u = ldg16(i_hi + oa + 32); bl.u = ldg16(i_hi + ob + 32); }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v0 = (float)a.e[e], v1 = (float)b_.e[e];
+                if (SPLIT && mx) {       // the second field holds (hi8, lo8) byte pairs: value = hi + lo8 * 2^-11
+                    constexpr float KL = 1.0f / (float)(1 << STA_MX_A_SLO);
+                    v0 += __builtin_amdgcn_cvt_f32_bf8(reinterpret_cast<const unsigned short*>(&al)[e], 1) * KL;
+                    v1 += __builtin_amdgcn_cvt_f32_bf8(reinterpret_cast<const unsigned short*>(&bl)[e], 1) * KL;
+                } else if (SPLIT) { v0 += (float)al.e[e]; v1 += (float)bl.e[e]; }
+                row_top[r][e] = (1.f - fx) * v0 + fx * v1;   // same association as ATen upsample_bilinear2d: w0*v00 + w1*v01
+            }
         }
-        const size_t o = blk_off<SPLIT>(orow + x, c, orows);
-        if (SPLIT && mx) {
-            const MX4 m0 = split_mx4<false>(vout, ra), m1 = split_mx4<false>(vout + 4, ra);     // two 16-B stores per lane
-            *reinterpret_cast<uint4*>(o_hi + o) = make_uint4(m0.hi.x, m0.hi.y, m1.hi.x, m1.hi.y);
-            *reinterpret_cast<uint4*>(o_hi + o + 32) = make_uint4(m0.pairs.x, m0.pairs.y, m1.pairs.x, m1.pairs.y);
+        // output row k = lerp of input rows (ra, rb) of the group.  Interior groups of the x2 pattern pair them as
+        // (0,1) (1,2) (1,2) (2,3) - compile-time register indices; any other group (first rows of an image, crops) selects by value.
+        auto emit = [&](int k, const float (&top)[8], const float (&bot)[8]) {
+            const float fy = fyr[k];
+            H8 oh, ol;
+            float vout[8];
+            RangeAcc ra;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = (1.f - fy) * top[e] + fy * bot[e];          // h0*(...) + h1*(...)
+                vout[e] = v;
+                if (SPLIT && mx) continue;
+                if (SPLIT) split_f16(v, oh.e[e], ol.e[e], ra); else oh.e[e] = to_f16_sat(v, ra);
+            }
+            const size_t o = blk_off<SPLIT>(((size_t)b * Hc + yg + k) * Wc + x, c, orows);
+            if (SPLIT && mx) {
+                const MX4 m0 = split_mx4<false>(vout, ra), m1 = split_mx4<false>(vout + 4, ra);     // two 16-B stores per lane
+                *reinterpret_cast<uint4*>(o_hi + o) = make_uint4(m0.hi.x, m0.hi.y, m1.hi.x, m1.hi.y);
+                *reinterpret_cast<uint4*>(o_hi + o + 32) = make_uint4(m0.pairs.x, m0.pairs.y, m1.pairs.x, m1.pairs.y);
+                ra.flush();
+                return;
+            }
             ra.flush();
-            continue;
+            *reinterpret_cast<uint4*>(o_hi + o) = oh.u;
+            if (SPLIT) *reinterpret_cast<uint4*>(o_hi + o + 32) = ol.u;
+        };
+        if (NR == 4 && regular) {
+            emit(0, row_top[0], row_top[1]);
+            emit(1, row_top[1], row_top[NR >= 2 ? 2 : 0]);
+            emit(2, row_top[1], row_top[NR >= 2 ? 2 : 0]);
+            emit(3, row_top[NR >= 2 ? 2 : 0], row_top[NR >= 3 ? 3 : 0]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                if (yg + k >= Hc) continue;
+                const int ra_ = y0r[k] - ybase, rb_ = y1r[k] - ybase;
+                float top[8], bot[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    top[e] = 0.f; bot[e] = 0.f;
+#pragma unroll
+                    for (int r = 0; r < NIN; ++r) { if (r == ra_) top[e] = row_top[r][e]; if (r == rb_) bot[e] = row_top[r][e]; }
+                }
+                emit(k, top, bot);
+            }
         }
-        ra.flush();
-        *reinterpret_cast<uint4*>(o_hi + o) = oh.u;
-        if (SPLIT) *reinterpret_cast<uint4*>(o_hi + o + 32) = ol.u;
     }
 }
 

@@ -1024,10 +1024,17 @@ static int run_rows_to_planes(sta_handle* h, const float* x, int64_t bstride, in
 
 static int run_up2(sta_handle* h, const Planes& in, int n, int Hi, int Wi, int C, int Hc, int Wc, const Planes& out, hipStream_t st) {
     if (h->dry) return 0;
-    const int blocks = n * Hc;            // one workgroup per output row
     REQUIRE(in.mx == out.mx && C % 8 == 0, "internal: bilinear format mismatch");
-    if (h->prec != STA_PREC_F16) hipLaunchKernelGGL(bilinear_up2_kernel<true>, dim3(blocks), dim3(256), 0, st, in.hi, in.lo, n, Hi, Wi, C, Hc, Wc, out.hi, out.lo, in.mx ? 1 : 0);
-    else hipLaunchKernelGGL(bilinear_up2_kernel<false>, dim3(blocks), dim3(256), 0, st, in.hi, in.lo, n, Hi, Wi, C, Hc, Wc, out.hi, out.lo, 0);
+    // four output rows per workgroup from 64 rows on (shared taps: half the tap loads, a third of the L2 fetches); one row per
+    // workgroup below that, where the grid would no longer fill the chip
+    const bool quad = Hc >= 64 && (int64_t)n * ((Hc + 3) / 4) >= 512 && h->opt[7] != 1;
+    const int blocks = quad ? n * ((Hc + 3) / 4) : n * Hc;
+    if (h->prec != STA_PREC_F16) {
+        if (quad) hipLaunchKernelGGL((bilinear_up2_kernel<true, 4>), dim3(blocks), dim3(256), 0, st, in.hi, in.lo, n, Hi, Wi, C, Hc, Wc, out.hi, out.lo, in.mx ? 1 : 0);
+        else hipLaunchKernelGGL((bilinear_up2_kernel<true, 1>), dim3(blocks), dim3(256), 0, st, in.hi, in.lo, n, Hi, Wi, C, Hc, Wc, out.hi, out.lo, in.mx ? 1 : 0);
+    } else {
+        STA_F16ONLY(hipLaunchKernelGGL((bilinear_up2_kernel<false, 1>), dim3(blocks), dim3(256), 0, st, in.hi, in.lo, n, Hi, Wi, C, Hc, Wc, out.hi, out.lo, 0));
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }
