@@ -1,5 +1,5 @@
 """Whole-path A/B on one box: (precision, forced GEMM family) configurations, two interleaved passes.
-    python tools/model_ab.py f16x3:0 f16x3:4 f16x3h:0 f16x3h:0:S2     (third field: S<n> = n concurrent batch slices, else an env switch)"""
+    python tools/model_ab.py f16x3:0 f16x3:4 f16x3h:0     (optional third field: an STA_EXPERIMENT_<name> environment switch to set)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
@@ -13,8 +13,7 @@ for rep in range(2):
     for prec, v, envv in cfgs:
         for k in [k for k in os.environ if k.startswith("STA_EXPERIMENT_")]:
             del os.environ[k]
-        m.set_concurrency(int(envv[1:]) if envv[:1] == "S" and envv[1:].isdigit() else 1)
-        if envv and not (envv[:1] == "S" and envv[1:].isdigit()):
+        if envv:
             os.environ["STA_EXPERIMENT_" + envv] = "1"
         m.set_precision(prec)
         _lib.check(m.lib.sta_set_gemm_variant(m._h, v))
