@@ -98,6 +98,11 @@ int sta_kernel_timing_dump_shapes(sta_handle* h, int cap, int* shape6, float* ms
  * sta_kernel_timing(h, 3) times only its launches (bench.py: the dominant kernel inside the timed region). */
 int sta_kernel_timing_filter(sta_handle* h, int epilogue, int a_mode, int family, int mx);
 
+/* In-kernel stamps of EVERY GEMM / convolution launch of the calls made since sta_kernel_timing(h, 4) (= mode 2 + stamps; the
+ * first 512 launches, 2048 workgroups each): per launch out6 = {workgroups, span, median entry -> first K tile, median main loop,
+ * median epilogue, spread of the exits} in us; pairs with sta_kernel_timing_dump_shapes (same launch order). */
+int sta_kernel_stamps_dump(sta_handle* h, int cap, double* out6, int* n_out);
+
 /* In-kernel timeline of ONE launch of the product's GEMM for M x N x K (tools/gemm_stamps.py): every workgroup stores four
  * 100 MHz stamps (entry, first K tile landed, main loop done, epilogue acknowledged).  resid != 0: the in-place residual form
  * (at SLAM scale: K slices to slabs).  out[10] (us): workgroups, kernel span (first entry -> last exit), median entry -> first

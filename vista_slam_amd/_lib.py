@@ -56,6 +56,7 @@ SIGNATURES = {
                                C.POINTER(_i), C.POINTER(_i), _fp, _fp, _fp, _fp, _vp]),
     "sta_regress_views_begin": (_i, [_vp, _fp, C.POINTER(_vp), _i, _i, _i, _fp, _vp]),
     "sta_regress_views_finish": (_i, [_vp, C.c_char_p, _f, C.POINTER(C.c_float), C.POINTER(_i), C.POINTER(_i), _fp, _fp, _fp, _fp, _vp]),
+    "sta_kernel_stamps_dump": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(_i)]),
     "sta_bench_gemm_stamps": (_i, [_vp, _i, _i, _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong), _i, _vp]),
     "sta_pack_compact": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _fp, _i64, _vp]),
     "sta_rope2d_inplace": (_i, [_fp, _i64, _i64, _vp, _i, _i, _i, _i, _f, _f, _vp]),

@@ -47,6 +47,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3h_kernel(const Gem
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int l31 = lane & 31, lhi = lane >> 5;
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;        // tools only (GemmParams::stamps, as in gemm2_body)
+    if (p.stamps) st0 = __builtin_amdgcn_s_memrealtime();
 
     // ---- block id -> (pixel tile, N tile): XCD-contiguous ranges, bands of 4 pixel tiles x all N tiles (as gemm2.h)
     const int tiles_x = (p.Wo + 31) >> 5, tiles_y = (p.Ho + TR - 1) / TR;
@@ -121,6 +123,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3h_kernel(const Gem
     issue_b(0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (p.stamps) st1 = __builtin_amdgcn_s_memrealtime();
 
     int cb = 0, tap = 0;
     for (int kt = 0; kt < nkt; ++kt) {
@@ -239,6 +242,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3h_kernel(const Gem
         tap = ntap; cb = ncb;
     }
 
+    if (p.stamps) { asm volatile("" ::"v"(acc[MT - 1][NT - 1][15]), "v"(acc[0][0][0]) : "memory"); st2 = __builtin_amdgcn_s_memrealtime(); }
     // ---- epilogue: MFMA tile (i, j) of this wave = the 32 pixels (y0 + wm*MT + i, x0 .. x0 + 31) x 32 channels
     const int cols_valid = p.Wo - x0 < 32 ? p.Wo - x0 : 32;
     if constexpr (EPI == EPI_HEAD) {
@@ -253,7 +257,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3h_kernel(const Gem
             for (int i = 0; i < MT; ++i) {
                 const int yy = y0 + wm * MT + i;
                 const int row0 = (img * p.Ho + yy) * p.Wo + x0;
-                { epilogue_tile<SPLIT, EPI>(p, acc[i][j], row0, n0 + wn * WN + j * 32 + l31, lane, 0, yy < p.Ho ? row0 + cols_valid : row0); STA_EPI_TILE_FENCE(); }
+                // (the stages are free: every wave is past the last barrier of the K loop - 4 KiB of LDS scratch per wave)
+                { epilogue_tile<SPLIT, EPI>(p, acc[i][j], row0, n0 + wn * WN + j * 32 + l31, lane, 0, yy < p.Ho ? row0 + cols_valid : row0, smem + wave * 4096); STA_EPI_TILE_FENCE(); }
             }
+    }
+    if (p.stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0 && blockIdx.x < 2048) {
+            unsigned long long* o = p.stamps + (size_t)blockIdx.x * 4;
+            o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memrealtime();
+        }
     }
 }

@@ -411,6 +411,73 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
     // output format tested once, outside the loop.  The callers put a scheduling barrier between a wave's tiles
     // (STA_EPI_TILE_FENCE): left free, hipcc overlaps the tiles' phases and the kernel needs 50+ more VGPRs.
     const bool interior = row0 + 32 <= M_ && __all(col_ok);
+    if (EPI == EPI_F16 && SPLIT && wave_lds != nullptr && interior) {
+        // Interior tile of a plane epilogue (DPT head) through the wave's LDS scratch (round 4).  A lane owns ONE column and 16
+        // rows, so straight from the accumulators the tile left as 32 store instructions of 2 B per lane and every residual
+        // plane arrived as 32 loads of 2 B per lane - in-kernel stamps: 33 - 44 us of epilogue per workgroup next to 118 - 126 us
+        // of main loop in the 256-channel convolutions.  The tile's 32 rows are consecutive rows of the blocked planes: one
+        // row block = [hi 64 B | lo / pair 64 B], i.e. the tile is ONE contiguous 4-KiB piece of the output and of each residual
+        // plane.  Phase 1 (column domain): act(acc + bias) as fp32 into LDS [row][32].  Phase 2 (row domain, two tasks per lane =
+        // 8 channels of one row each): 2 x ds_read_b128, the residual planes as 16-B loads, the adds, the split, 16-B stores.
+        float* const L = reinterpret_cast<float*>(wave_lds);              // [32][32] fp32 = 4 KiB
+        const float floor_ = p.act == ACT_RELU ? 0.f : -INFINITY;
+        const int c = lane & 31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float x = acc[r] + bv;
+            if (p.act == ACT_GELU) x = gelu_erf(x);
+            L[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 32 + c] = fmaxf(x, floor_);
+        }
+        // first element of the tile's first row block (64 elements per row); the tile's column origin is wave-uniform
+        const size_t o0 = blk_off<true>(row0, __builtin_amdgcn_readfirstlane(col - c), p.c_rp);
+        // every residual load of the tile before its first store (a load issued behind a store waits for that store's
+        // acknowledgement); the two residual planes one after the other, so that only one of them occupies registers at a time
+        float v[2][8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int task = lane + 64 * t, row = task >> 2, q = task & 3;
+            const float4 a = *reinterpret_cast<const float4*>(L + row * 32 + q * 8), b = *reinterpret_cast<const float4*>(L + row * 32 + q * 8 + 4);
+            v[t][0] = a.x; v[t][1] = a.y; v[t][2] = a.z; v[t][3] = a.w; v[t][4] = b.x; v[t][5] = b.y; v[t][6] = b.z; v[t][7] = b.w;
+        }
+        auto add_plane = [&](const f16* R) {
+            uint4 hh[2], ll[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int task = lane + 64 * t;
+                const size_t o = o0 + (size_t)(task >> 2) * 64 + (task & 3) * 8;
+                hh[t] = ldg16(R + o); ll[t] = ldg16(R + o + 32);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                H8 h8, l8; h8.u = hh[t]; l8.u = ll[t];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (p.r_mx) v[t][e] += (float)h8.e[e] + __builtin_amdgcn_cvt_f32_bf8(reinterpret_cast<const unsigned short*>(&l8)[e], 1) * (1.0f / (float)(1 << STA_MX_A_SLO));
+                    else v[t][e] += (float)h8.e[e] + (float)l8.e[e];
+                }
+            }
+        };
+        if (p.R1_hi) add_plane(p.R1_hi);
+        if (p.R2_hi) add_plane(p.R2_hi);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int task = lane + 64 * t;
+            const size_t o = o0 + (size_t)(task >> 2) * 64 + (task & 3) * 8;
+            if (p.c_mx) {
+                const MX4 m0 = split_mx4<false>(v[t], ra), m1 = split_mx4<false>(v[t] + 4, ra);
+                *reinterpret_cast<uint4*>(p.C_hi + o) = make_uint4(m0.hi.x, m0.hi.y, m1.hi.x, m1.hi.y);
+                *reinterpret_cast<uint4*>(p.C_hi + o + 32) = make_uint4(m0.pairs.x, m0.pairs.y, m1.pairs.x, m1.pairs.y);
+            } else {
+                H8 oh, ol;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) split_f16(v[t][e], oh.e[e], ol.e[e], ra);
+                *reinterpret_cast<uint4*>(p.C_hi + o) = oh.u;
+                *reinterpret_cast<uint4*>(p.C_hi + o + 32) = ol.u;
+            }
+        }
+        ra.flush();
+        return;
+    }
     bool ok[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) ok[r] = interior || (col_ok && row0 + 4 * lhi + (r & 3) + 8 * (r >> 2) < M_);

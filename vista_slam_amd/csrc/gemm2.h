@@ -524,7 +524,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
     } else {
         // EPI_QKV / EPI_GELU: a private LDS scratch per wave for the epilogue's transposes (the stage buffers are free: with two stages every wave
         // is past the last barrier of the main loop; the ring form, used for QKV only with split K, goes without)
-        char* const wave_lds = ((EPI == EPI_QKV || EPI == EPI_GELU) && !RING && NW * EPI_LDS_BYTES <= NSTG * STAGE) ? smem + wave * EPI_LDS_BYTES : nullptr;
+        char* const wave_lds = ((EPI == EPI_QKV || EPI == EPI_GELU || EPI == EPI_F16) && !RING && NW * EPI_LDS_BYTES <= NSTG * STAGE) ? smem + wave * EPI_LDS_BYTES : nullptr;
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -533,7 +533,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
     }
     if (p.stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the epilogue's stores acknowledged
-        if (tid == 0) {
+        if (tid == 0 && block_id_in < 2048) {            // (the in-model dump keeps 2048 workgroups per launch)
             unsigned long long* o = p.stamps + (size_t)block_id_in * 4;
             o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memrealtime();
         }

@@ -80,6 +80,7 @@ struct Slot {
     bool loaded = false;
 };
 
+static const int KSTAMP_WG = 2048, KSTAMP_LAUNCHES = 512;      // in-model stamps (tools/model_stamps.py): workgroups kept per launch, launches per dump
 static const int64_t SKBUF_ELEMS = (int64_t)4 << 20;   // 16 MiB: M*N of the largest split-K plane-epilogue GEMM
 // Execution context of ONE caller stream: everything a call writes between its kernels.  The handle keeps one context per
 // stream it has been called on (stream_ctx), so calls enqueued on DIFFERENT streams never share scratch memory and may run
@@ -132,6 +133,7 @@ struct sta_handle {
     bool ktime = false; std::vector<hipEvent_t> kev; int kn = 0; std::vector<double> kflops, kbytes; std::vector<int> kvar;
     int kfilter[4] = {-1, -1, -1, -1};    // mode 3: {epilogue, A-loader, tile family, mx} of the one kernel symbol that is timed
     bool ktime_all = false; std::vector<int> kshape;   // sta_kernel_timing(h, 2): every GEMM / conv launch is timed; {M, N, K, EPI, AMODE, mx} per record
+    unsigned long long* kstamp = nullptr; bool kstamp_on = false;   // sta_kernel_timing(h, 4): mode 2 + in-kernel stamps (GemmParams::stamps) of every launch, KSTAMP_WG workgroups x 4 per record
     // f3 input-step tables (one cached geometry)
     int pre_key[6] = {0, 0, 0, 0, 0, 0}; int* pre_tab = nullptr; int64_t pre_cap = 0; int pre_meta[12] = {0};
     bool dry = false;   // planning pass: run the orchestration without launching to size the workspace
@@ -399,6 +401,7 @@ extern "C" int sta_destroy(sta_handle* h) {
     if (h->zero_page) hipFree(h->zero_page);
     if (h->pre_tab) hipFree(h->pre_tab);
     if (h->clk_buf) hipFree(h->clk_buf);
+    if (h->kstamp) hipFree(h->kstamp);
     if (h->ev_ok) for (auto& e : h->ev) hipEventDestroy(e);
     for (auto& e : h->kev) hipEventDestroy(e);
     delete h;
@@ -714,6 +717,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st, in
         h->kn++;
     }
     if (timed && variant == 5) p.clk_dbg = h->clk_buf;   // effective-clock probe (bench only)
+    if (timed && h->kstamp_on && h->kn <= KSTAMP_LAUNCHES) p.stamps = h->kstamp + (size_t)(h->kn - 1) * KSTAMP_WG * 4;
     if constexpr (AMODE == A_CONV3 && (EPI == EPI_F16 || EPI == EPI_HEAD)) {
         if (variant == 8) {
             REQUIRE((int64_t)p.Ho * p.Wo > 0 && p.M % (p.Ho * p.Wo) == 0, "internal: conv3h needs whole images");
@@ -900,6 +904,9 @@ static int gemm_qkv_pair(sta_handle* h, const GemmParams& pa_in, const GemmParam
         h->kbytes[h->kn] = 4.0 * (2.0 * pa.M * pa.K + (double)(pa.N + pb.N) * pa.K) + 4.0 * pa.M * (pa.N + pb.N);
         HIPCHK(hipEventRecord(h->kev[2 * h->kn], st));
         h->kn++;
+        if (h->kstamp_on && h->kn <= KSTAMP_LAUNCHES && ta + tb <= KSTAMP_WG) {
+            pa.stamps = h->kstamp + (size_t)(h->kn - 1) * KSTAMP_WG * 4; pb.stamps = pa.stamps + (size_t)ta * 4;
+        }
     }
     static unsigned attr_done = 0;      // one bit per device
     constexpr int smem = gemm2_smem_bytes<true, 192, 128>(2);
@@ -1497,7 +1504,12 @@ extern "C" int sta_kernel_timing(sta_handle* h, int enable) {
     DEV_SCOPE(h->device);
     if (enable && !h->clk_buf) { HIPCHK(hipMalloc((void**)&h->clk_buf, 16)); }
     if (h->clk_buf) HIPCHK(hipMemset(h->clk_buf, 0, 16));
-    h->ktime = enable != 0; h->ktime_all = enable == 2; h->kn = 0;
+    if (enable == 4) {            // mode 2 + in-kernel stamps of every GEMM / convolution launch
+        if (!h->kstamp) HIPCHK(hipMalloc((void**)&h->kstamp, (size_t)KSTAMP_LAUNCHES * KSTAMP_WG * 32));
+        HIPCHK(hipMemset(h->kstamp, 0, (size_t)KSTAMP_LAUNCHES * KSTAMP_WG * 32));
+    }
+    h->kstamp_on = enable == 4;
+    h->ktime = enable != 0; h->ktime_all = enable == 2 || enable == 4; h->kn = 0;
     if (enable != 3) h->kfilter[0] = h->kfilter[1] = h->kfilter[2] = h->kfilter[3] = -1;
     return 0;
 }
@@ -1554,6 +1566,33 @@ extern "C" int sta_kernel_timing_dump_shapes(sta_handle* h, int cap, int* shape6
         HIPCHK(hipEventElapsedTime(&ms[n], h->kev[2 * i], h->kev[2 * i + 1]));
         for (int q = 0; q < 6; ++q) shape6[6 * n + q] = h->kshape[6 * i + q];
         variant[n] = h->kvar[i];
+    }
+    *n_out = n;
+    return 0;
+}
+
+// In-kernel stamps of the launches recorded since sta_kernel_timing(h, 4): per launch out6 = {workgroups, span us, median entry ->
+// first K tile, median main loop, median epilogue, spread of the exits} (100-MHz stamps of every workgroup, GemmParams::stamps).
+extern "C" int sta_kernel_stamps_dump(sta_handle* h, int cap, double* out6, int* n_out) {
+    REQUIRE(h && out6 && n_out && h->kstamp, "stamps were never enabled (sta_kernel_timing(h, 4))");
+    DEV_SCOPE(h->device);
+    HIPCHK(hipDeviceSynchronize());
+    const int n = h->kn < cap ? (h->kn < KSTAMP_LAUNCHES ? h->kn : KSTAMP_LAUNCHES) : cap;
+    std::vector<unsigned long long> hs((size_t)KSTAMP_WG * 4);
+    for (int i = 0; i < n; ++i) {
+        HIPCHK(hipMemcpy(hs.data(), h->kstamp + (size_t)i * KSTAMP_WG * 4, (size_t)KSTAMP_WG * 32, hipMemcpyDeviceToHost));
+        std::vector<double> pro, loop, epi;
+        unsigned long long t0min = ~0ull, t3min = ~0ull, t3max = 0;
+        for (int b = 0; b < KSTAMP_WG; ++b) {
+            const unsigned long long* q = &hs[(size_t)b * 4];
+            if (!q[3] || !q[0]) continue;
+            pro.push_back((double)(q[1] - q[0]) * 0.01); loop.push_back((double)(q[2] - q[1]) * 0.01); epi.push_back((double)(q[3] - q[2]) * 0.01);
+            if (q[0] < t0min) t0min = q[0]; if (q[3] < t3min) t3min = q[3]; if (q[3] > t3max) t3max = q[3];
+        }
+        double* o = out6 + (size_t)i * 6;
+        if (pro.empty()) { for (int k = 0; k < 6; ++k) o[k] = 0; continue; }
+        auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+        o[0] = (double)pro.size(); o[1] = (double)(t3max - t0min) * 0.01; o[2] = med(pro); o[3] = med(loop); o[4] = med(epi); o[5] = (double)(t3max - t3min) * 0.01;
     }
     *n_out = n;
     return 0;
