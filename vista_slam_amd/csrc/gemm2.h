@@ -522,9 +522,11 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
     if constexpr (EPI == EPI_HEAD) {
         if constexpr (BN == 128) head_epilogue<BM, MT, NT, WM, WAVES_N>(p, acc, m0, 32, BM / 32, 32, wm, wn, tid, smem);
     } else {
-        // EPI_QKV / EPI_GELU: a private LDS scratch per wave for the epilogue's transposes (the stage buffers are free: with two stages every wave
-        // is past the last barrier of the main loop; the ring form, used for QKV only with split K, goes without)
-        char* const wave_lds = ((EPI == EPI_QKV || EPI == EPI_GELU || EPI == EPI_F16) && !RING && NW * EPI_LDS_BYTES <= NSTG * STAGE) ? smem + wave * EPI_LDS_BYTES : nullptr;
+        // EPI_QKV / EPI_GELU / EPI_F16: a private LDS scratch per wave for the epilogue's transposes (the stage buffers are free)
+        // (two stages: every wave is past the last barrier of the main loop.  The ring form has no barrier behind its last K tile:
+        //  one here, so that no wave still reads fragments from the memory another wave's epilogue is about to reuse)
+        char* const wave_lds = ((EPI == EPI_QKV || EPI == EPI_GELU || EPI == EPI_F16) && NW * EPI_LDS_BYTES <= NSTG * STAGE) ? smem + wave * EPI_LDS_BYTES : nullptr;
+        if (RING && wave_lds != nullptr) __syncthreads();
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
