@@ -473,6 +473,39 @@ def test_calls_on_two_streams_overlap_safely(G, prec):
     assert m.range_report() == (0, 0)
 
 
+@pytest.mark.parametrize("prec", [DEFAULT, "f16x3"])
+def test_dpt_side_lane_is_bit_identical(G, prec):
+    """dpt_impl's side lane (the branch kernels of the DPT head on an internal second stream, SLAM-scale calls only) runs the
+    same kernels with the same split-K slices as the one-lane order: outputs bit for bit equal with the lane switched off
+    (sta_debug_set_option 6 = 1), for forward_pair and for a scheduler call, repeatedly (races would show as flakiness)."""
+    import torch
+    from vista_slam_amd import weights as W, _lib
+    from vista_slam_amd.slam_scheduler import regress_views
+    m = G.model("full", 1.0, prec)
+    G.set_variant(m, 0)
+    H = Wd = 224
+    imgs = torch.from_numpy(W.synth_images(6, H, Wd, seed=43, tag=23)).cuda()
+    feats = [m._encode_image(imgs[v:v + 1], None, normalize=False)[0] for v in range(4)]
+    try:
+        _lib.check(m.lib.sta_debug_set_option(m._h, 6, 1))
+        ref = m.forward_pair(imgs[4:5], imgs[5:6])
+        ref_pts, ref_conf = ref[0]["pts3d_pred"].clone(), ref[1]["conf"].clone()
+        ref_e = regress_views(m, feats[3], feats[:3], [False, False, True], -1.0, H, Wd)
+        ref_d = [r.depths.clone() for r in ref_e]
+        torch.cuda.synchronize()
+        _lib.check(m.lib.sta_debug_set_option(m._h, 6, 0))
+        for it in range(5):
+            out = m.forward_pair(imgs[4:5], imgs[5:6])
+            e = regress_views(m, feats[3], feats[:3], [False, False, True], -1.0, H, Wd)
+            torch.cuda.synchronize()
+            assert torch.equal(out[0]["pts3d_pred"], ref_pts) and torch.equal(out[1]["conf"], ref_conf), f"forward_pair differs with the side lane (iteration {it})"
+            for r, d in zip(e, ref_d):
+                assert torch.equal(r.depths, d), f"scheduler differs with the side lane (iteration {it})"
+    finally:
+        _lib.check(m.lib.sta_debug_set_option(m._h, 6, 0))
+    assert m.range_report() == (0, 0)
+
+
 def test_split_phase_scheduler_pipelines_two_keyframes(G):
     """sta_regress_views_begin / _finish: decode + pose heads of keyframe B's edges enqueued (second stream) BEFORE keyframe A's
     accept / reject + DPT heads run (first stream) - the pipelined schedule of bench.slam_replay - gives bit for bit what the

@@ -1,4 +1,5 @@
-"""Same-process A/B of one experiment switch (sta_debug_set_option idx) on the benchmark workload (8 pairs @512x384):
+"""Same-process A/B of one experiment switch (sta_debug_set_option idx) on the benchmark workload (8 pairs @512x384; AB_B / AB_H / AB_W
+in the environment pick another):
     python tools/ab_option.py idx v0 v1 [v2 ...] [--rounds R] [--prec P]
 One model, the values alternate round-robin (box drift hits all arms equally); prints pairs/s per arm and the relative
 difference of every arm's pts3d to arm 0's."""
@@ -13,7 +14,7 @@ rounds, prec = 3, "f16x3h"
 if "--rounds" in args: i = args.index("--rounds"); rounds = int(args[i + 1]); del args[i:i + 2]
 if "--prec" in args: i = args.index("--prec"); prec = args[i + 1]; del args[i:i + 2]
 idx, vals = int(args[0]), [int(v) for v in args[1:]]
-B, H, Wd = 8, 384, 512
+B, H, Wd = int(os.environ.get("AB_B", 8)), int(os.environ.get("AB_H", 384)), int(os.environ.get("AB_W", 512))     # workload (default: the benchmark's)
 m = STAFrontend(W.FULL, "cuda:0", precision=prec).load_procedural(seed=43)
 imgs = torch.from_numpy(W.synth_images(2 * B, H, Wd, seed=43, tag=0)).cuda()
 tot = {v: [] for v in vals}

@@ -96,6 +96,9 @@ struct StreamCtx {
     bool rv_open = false; int rv_k = 0, rv_H = 0, rv_W = 0;
     float* rv_conf = nullptr;         // pinned host copy of the k pose confidences (async D2H in begin, read in finish)
     hipEvent_t rv_ev = nullptr;       // recorded behind that copy
+    // side lane of the DPT head (dpt_impl): an internal second stream for the branches of the head that do not lie on its
+    // critical chain, with its own split-K scratch; forked from and joined back into `st` inside the call
+    hipStream_t side = nullptr; float* side_skbuf = nullptr; hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 struct sta_handle {
@@ -137,6 +140,7 @@ struct sta_handle {
     // f3 input-step tables (one cached geometry)
     int pre_key[6] = {0, 0, 0, 0, 0, 0}; int* pre_tab = nullptr; int64_t pre_cap = 0; int pre_meta[12] = {0};
     bool dry = false;   // planning pass: run the orchestration without launching to size the workspace
+    int lane = 0;       // 1 while dpt_impl enqueues on the context's side stream (launch_gemm then hands out the side lane's split-K scratch)
 };
 
 static int dalloc(sta_handle* h, void** p, int64_t bytes) {
@@ -194,6 +198,17 @@ static int ensure_ws(sta_handle* h, int64_t bytes, hipStream_t st) {
 }
 
 static Bump cur_bump(sta_handle* h) { return Bump{h->cur->ws, h->cur->ws_cap}; }
+
+// side lane of the current context (created on first use: one stream, 16 MiB of split-K scratch, four events)
+static int ensure_side(sta_handle* h) {
+    StreamCtx& c = *h->cur;
+    if (c.side) return 0;
+    HIPCHK(hipMalloc((void**)&c.side_skbuf, (size_t)SKBUF_ELEMS * 4));
+    for (auto& e : c.side_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+    return 0;
+}
+static inline float* lane_skbuf(sta_handle* h) { return h->lane ? h->cur->side_skbuf : h->cur->skbuf; }
 
 // ------------------------------------------------------------------------------------------ schema
 static int make_lin(sta_handle* h, Lin& L, int N, int K, bool bias = true, bool mx = false) {
@@ -396,6 +411,8 @@ extern "C" int sta_destroy(sta_handle* h) {
     for (auto& c : h->ctx) {
         if (c.ws) hipFree(c.ws); if (c.skbuf) hipFree(c.skbuf); if (c.slab) hipFree(c.slab);
         if (c.rv_conf) hipHostFree(c.rv_conf); if (c.rv_ev) hipEventDestroy(c.rv_ev);
+        if (c.side) hipStreamDestroy(c.side); if (c.side_skbuf) hipFree(c.side_skbuf);
+        for (auto& e : c.side_ev) if (e) hipEventDestroy(e);
     }
     if (h->rope_tab) hipFree(h->rope_tab);
     if (h->zero_page) hipFree(h->zero_page);
@@ -662,7 +679,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st, in
             const int max_ks = p.K / 256;                 // keep >= 8 K tiles per slice
             if (ks > max_ks) ks = max_ks;
             while (ks > 1 && (int64_t)ks * p.M * p.N > SKBUF_ELEMS) --ks;
-            if (ks > 1) { p.ksplit = ks; p.skbuf = h->cur->skbuf; }
+            if (ks > 1) { p.ksplit = ks; p.skbuf = lane_skbuf(h); }
         }
         // plane-epilogue GEMMs / convs on tiny grids (DPT levels at SLAM scale: 16-64 workgroups looping over K = 2304 ..
         // 6912): split K into fp32 partial sums, a finishing kernel applies bias / activation / residuals.  Worth two
@@ -674,7 +691,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st, in
             const int max_ks = p.K / 256;                 // keep >= 8 K tiles per slice
             if (ks > max_ks) ks = max_ks;
             while (ks > 1 && (int64_t)ks * p.M * p.N > SKBUF_ELEMS) --ks;      // one slab per K slice
-            if (ks > 1) { p.ksplit = ks; p.skbuf = h->cur->skbuf; }
+            if (ks > 1) { p.ksplit = ks; p.skbuf = lane_skbuf(h); }
         }
     }
     // forced families (tests / tools): 1 = 128x128 register-staged, 2 = 256x256, 3 = 192x256 (both wherever N % 256 == 0 and
@@ -874,12 +891,19 @@ static int gemm_qkv(sta_handle* h, const Planes& A, const Lin& W, int M, int nq,
 }
 // Two QKV-epilogue GEMMs that do not depend on each other as ONE launch (gemm2_pair_kernel) when both run on the 192x128
 // family at throughput scale; otherwise two launches.  Decoder: attn.qkv on norm1(x) + cross_attn.projk|projv on norm_y.
+static bool qkv_pair_one_launch(const sta_handle* h, const GemmParams& pa, const GemmParams& pb) {
+    auto big = [h](const GemmParams& p) { return p.N % 128 == 0 && !small_grid(h, p.M, p.N); };
+    return h->prec != STA_PREC_F16 && !pa.mx && !pb.mx && big(pa) && big(pb) && pa.K == pb.K && pa.M == pb.M && auto_family(h);
+}
+// side lane of the current context (dpt_impl, decode_impl): usable unless switched off or a timing mode wants one stream
+static bool lanes_on(const sta_handle* h) {
+    return !h->dry && h->opt[6] != 1 && !h->timing && !h->ktime && !h->ktime_all && !h->kstamp_on;
+}
+struct Lane { sta_handle* h; int v; Lane(sta_handle* h_, int v_) : h(h_), v(h_->lane) { h->lane = v_; } ~Lane() { h->lane = v; } };
 static int gemm_qkv_pair(sta_handle* h, const GemmParams& pa_in, const GemmParams& pb_in, hipStream_t st) {
     GemmParams pa = pa_in, pb = pb_in;
-    const bool split = h->prec != STA_PREC_F16;
-    auto big = [h](const GemmParams& p) { return p.N % 128 == 0 && !small_grid(h, p.M, p.N); };
     if (h->dry) return 0;
-    if (!split || pa.mx || pb.mx || !big(pa) || !big(pb) || pa.K != pb.K || pa.M != pb.M || !auto_family(h)) {
+    if (!qkv_pair_one_launch(h, pa, pb)) {
         CHK((launch_gemm<A_DENSE, EPI_QKV>(h, pa, st)));
         return launch_gemm<A_DENSE, EPI_QKV>(h, pb, st);
     }
@@ -1180,15 +1204,33 @@ static int decode_impl(sta_handle* h, Bump& ws, const float* feat1, const float*
         const DecBlk& b = h->dec[i];
         // self-attention q,k,v and the cross-attention k,v of the OTHER side depend only on the layer input: one launch.
         // (They write disjoint buffers: qkv / ckv_out.)
+        // Below the paired launch's scale (two launches + two split-K finishers) the cross-attention K / V run on the context's
+        // SIDE stream under the self-attention chain (qkv, attention, proj + norm2, cross q) and join before the cross attention.
+        bool forked = false;
         {
             GemmParams pq, pkv;
             CHK(gp_qkv(h, pq, a1, b.qkv, M, D, D, D, qkv, N, Hh, wp, 0, Mp));
             CHK(gp_qkv(h, pkv, ay, b.ckv, M, 0, D, D, cqkv, N, Hh, wp, 0, Mp));
-            CHK(gemm_qkv_pair(h, pq, pkv, st));
+            if (lanes_on(h) && !qkv_pair_one_launch(h, pq, pkv)) {
+                CHK(ensure_side(h));
+                hipEvent_t* ev = h->cur->side_ev + 2 * (i & 1);
+                HIPCHK(hipEventRecord(ev[0], st));
+                HIPCHK(hipStreamWaitEvent(h->cur->side, ev[0], 0));
+                {
+                    Lane lane(h, 1);
+                    CHK((launch_gemm<A_DENSE, EPI_QKV>(h, pkv, h->cur->side)));
+                }
+                HIPCHK(hipEventRecord(ev[1], h->cur->side));
+                CHK((launch_gemm<A_DENSE, EPI_QKV>(h, pq, st)));
+                forked = true;
+            } else {
+                CHK(gemm_qkv_pair(h, pq, pkv, st));
+            }
         }
         CHK(run_attn(h, qkv, ao, D, S, Hh, N, N, 0, st, true));
         CHK(gemm_resid_ln(h, ao, b.proj, M, x, D, &b.n2, &a1, nullptr, nullptr, st));
         CHK(gemm_qkv(h, a1, b.cq, M, D, 0, 0, cqkv, N, Hh, wp, 0, st, Mp));
+        if (forked) HIPCHK(hipStreamWaitEvent(st, h->cur->side_ev[2 * (i & 1) + 1], 0));
         CHK(run_attn(h, cqkv, ao, D, S, Hh, N, N, B, st, true));
         CHK(gemm_resid_ln(h, ao, b.cproj, M, x, D, &b.n3, &a1, nullptr, nullptr, st));
         CHK(gemm_f16(h, a1, b.fc1, M, f1, ACT_GELU, st));
@@ -1253,12 +1295,25 @@ static int dpt_impl(sta_handle* h, Bump& ws, const float* enc, int64_t enc_bs,
     // (N = 96: no f16mx kernel for that one GEMM, it reads f16x3 rows and WRITES f16mx rows)
     const bool dmx = (h->mx_mask & CLS_HEAD) != 0;
     auto act = [&](int64_t rows, int64_t cols, bool mx) { Planes q = ws.act(rows, cols, split); q.mx = mx; return q; };
+    // Two lanes (round 4).  The head is a chain - level 3 (1/32 scale) -> refinenet4 -> refinenet3 -> refinenet2 -> refinenet1 -> head -
+    // with three side branches feeding it: the reassembly of levels 2, 1, 0 (rows -> planes, act_postprocess, layer_rn) and the first
+    // convolution of each refinenet's resConfUnit1, which reads only that level.  The 14 side-branch launches run on the context's
+    // SIDE stream under the chain: fork at entry, one event per level (2, 1, 0) that the chain waits on right before it consumes
+    // that level.  At SLAM scale every kernel of the head is a fraction of a round of workgroups and a launch costs as much as the
+    // kernel (tools/model_stamps.py: 10 - 25 us of event time around 5 - 17 us of work): 5-edge scheduler call -5.8 %, one pair
+    // @512x384 +2.3 %; at the benchmark's 8 pairs the side kernels fill the chain's partial rounds (+0.8 %).  Same kernels, same
+    // split-K slices (the side lane has its own scratch): bit-identical to the one-lane order (tests/test_gpu_parity.py).
+    // sta_debug_set_option(h, 6, 1) switches the lane off (A/B: tools/ab_option.py 6 1 0); the timing modes run one lane.
+    const bool two = lanes_on(h);
+    hipStream_t sb = st;                                                  // the side branches' stream
+    if (two) {
+        CHK(ensure_side(h));
+        sb = h->cur->side;
+        HIPCHK(hipEventRecord(h->cur->side_ev[3], st));
+        HIPCHK(hipStreamWaitEvent(sb, h->cur->side_ev[3], 0));
+    }
     Planes t0 = act(M, E, use_mx(h, h->act0_0)), t1 = act(M, D, dmx);
     Planes t2 = act(M, D, dmx), t3 = act(M, D, dmx);
-    CHK(run_rows_to_planes(h, enc, enc_bs, n, N, E, t0, st, 0, t0.mx));
-    CHK(run_rows_to_planes(h, h1, h1_bs, n, N, D, t1, st, 0, t1.mx));
-    CHK(run_rows_to_planes(h, h2, h2_bs, n, N, D, t2, st, 0, t2.mx));
-    CHK(run_rows_to_planes(h, h3, h3_bs, n, N, D, t3, st, 0, t3.mx));
     // act_postprocess (dpt_block.py:356-410)
     Planes a0 = act(M, 96, dmx), l0 = act((int64_t)M * 16, 96, dmx);
     Planes a1 = act(M, 192, dmx), l1 = act((int64_t)M * 4, 192, dmx);
@@ -1266,22 +1321,40 @@ static int dpt_impl(sta_handle* h, Bump& ws, const float* enc, int64_t enc_bs,
     Planes a3 = act(M, 768, dmx);
     const int h3s = (hp - 1) / 2 + 1, w3s = (wp - 1) / 2 + 1;
     Planes l3 = act((int64_t)n * h3s * w3s, 768, dmx);
-    REQUIRE(!ws.overflow, "internal: dpt workspace overflow (stage 1)");
-    CHK(gemm_f16(h, t0, h->act0_0, M, a0, ACT_NONE, st, a0.mx));
-    CHK(gemm_convt(h, a0, h->act0_1, n, hp, wp, 4, 96, l0, st));
-    CHK(gemm_f16(h, t1, h->act1_0, M, a1, ACT_NONE, st, a1.mx));
-    CHK(gemm_convt(h, a1, h->act1_1, n, hp, wp, 2, 192, l1, st));
-    CHK(gemm_f16(h, t2, h->act2_0, M, l2, ACT_NONE, st, l2.mx));
-    CHK(gemm_f16(h, t3, h->act3_0, M, a3, ACT_NONE, st, a3.mx));
-    CHK(conv3(h, a3, n, hp, wp, 768, h->act3_1, 2, false, ACT_NONE, l3, nullptr, nullptr, st));
     // layer_rn (3x3, no bias) -> 256 channels at 4x, 2x, 1x, 1/2x
     const int Hs[4] = {4 * hp, 2 * hp, hp, h3s}, Ws[4] = {4 * wp, 2 * wp, wp, w3s};
     const int Cs[4] = {96, 192, 384, 768};
-    Planes lin[4] = {l0, l1, l2, l3}, r[4];
+    Planes lin[4] = {l0, l1, l2, l3}, r[4], c1o[4];          // c1o[k]: relu(conv1(relu(r[k]))) of refinenet k's resConfUnit1 (k < 3)
     for (int k = 0; k < 4; ++k) {
         r[k] = act((int64_t)n * Hs[k] * Ws[k], 256, dmx);
-        REQUIRE(!ws.overflow, "internal: dpt workspace overflow (rn)");
-        CHK(conv3(h, lin[k], n, Hs[k], Ws[k], Cs[k], h->rn[k], 1, false, ACT_NONE, r[k], nullptr, nullptr, st));
+        if (k < 3) c1o[k] = act((int64_t)n * Hs[k] * Ws[k], 256, dmx);
+    }
+    REQUIRE(!ws.overflow, "internal: dpt workspace overflow (stage 1)");
+    {   // level 3 opens the chain
+        CHK(run_rows_to_planes(h, h3, h3_bs, n, N, D, t3, st, 0, t3.mx));
+        CHK(gemm_f16(h, t3, h->act3_0, M, a3, ACT_NONE, st, a3.mx));
+        CHK(conv3(h, a3, n, hp, wp, 768, h->act3_1, 2, false, ACT_NONE, l3, nullptr, nullptr, st));
+        CHK(conv3(h, l3, n, Hs[3], Ws[3], Cs[3], h->rn[3], 1, false, ACT_NONE, r[3], nullptr, nullptr, st));
+    }
+    {   // side branches, in the order the chain consumes them: level 2, 1, 0
+        Lane lane(h, two ? 1 : 0);
+        for (int k = 2; k >= 0; --k) {
+            if (k == 2) {
+                CHK(run_rows_to_planes(h, h2, h2_bs, n, N, D, t2, sb, 0, t2.mx));
+                CHK(gemm_f16(h, t2, h->act2_0, M, l2, ACT_NONE, sb, l2.mx));
+            } else if (k == 1) {
+                CHK(run_rows_to_planes(h, h1, h1_bs, n, N, D, t1, sb, 0, t1.mx));
+                CHK(gemm_f16(h, t1, h->act1_0, M, a1, ACT_NONE, sb, a1.mx));
+                CHK(gemm_convt(h, a1, h->act1_1, n, hp, wp, 2, 192, l1, sb));
+            } else {
+                CHK(run_rows_to_planes(h, enc, enc_bs, n, N, E, t0, sb, 0, t0.mx));
+                CHK(gemm_f16(h, t0, h->act0_0, M, a0, ACT_NONE, sb, a0.mx));
+                CHK(gemm_convt(h, a0, h->act0_1, n, hp, wp, 4, 96, l0, sb));
+            }
+            CHK(conv3(h, lin[k], n, Hs[k], Ws[k], Cs[k], h->rn[k], 1, false, ACT_NONE, r[k], nullptr, nullptr, sb));
+            CHK(conv3(h, r[k], n, Hs[k], Ws[k], 256, h->ref[k].u1.c1, 1, true, ACT_RELU, c1o[k], nullptr, nullptr, sb));
+            if (two) HIPCHK(hipEventRecord(h->cur->side_ev[k], sb));
+        }
     }
     // refinenet4 .. refinenet1.  out_conv (1x1) commutes with the bilinear upsample (both linear, the
     // interpolation weights sum to 1), so it runs BEFORE the x2 upsample at 1/4 of the FLOPs.
@@ -1296,7 +1369,9 @@ static int dpt_impl(sta_handle* h, Bump& ws, const float* enc, int64_t enc_bs,
             REQUIRE(ph == hh && pw == ww, "internal: refinenet size mismatch %dx%d vs %dx%d", ph, pw, hh, ww);
             Planes sum = act(el, 256, dmx);
             REQUIRE(!ws.overflow, "internal: dpt workspace overflow (fusion)");
-            CHK(run_rcu(h, r[k], n, hh, ww, rf.u1, tmp, sum, &path, st));   // path + RCU1(layer)
+            if (two) HIPCHK(hipStreamWaitEvent(st, h->cur->side_ev[k], 0));
+            // path + RCU1(layer) = path + r[k] + conv2(c1o[k])   (dpt_block.py:121-142, 196-204)
+            CHK(conv3(h, c1o[k], n, hh, ww, 256, rf.u1.c2, 1, false, ACT_NONE, sum, &r[k], &path, st));
             cur = sum;
         }
         Planes y = act(el, 256, dmx), z = act(el, 256, dmx);
