@@ -197,6 +197,21 @@ static int ensure_ws(sta_handle* h, int64_t bytes, hipStream_t st) {
     return 0;
 }
 
+// zero the padding of V^T buffers (keys >= ntok must contribute 0): one fill when the planes sit back to back in the workspace
+static int zero_planes(const Planes* const* pl, int n, int64_t elems, bool split, hipStream_t st) {
+    const int64_t each = elems * 2 * (split ? 2 : 1);
+    bool contiguous = true;
+    for (int i = 0; i < n; ++i) {
+        if (split && (char*)pl[i]->lo != (char*)pl[i]->hi + elems * 2) contiguous = false;
+        if (i > 0 && (char*)pl[i]->hi != (char*)pl[i - 1]->hi + each) contiguous = false;
+    }
+    if (contiguous) { HIPCHK(hipMemsetAsync(pl[0]->hi, 0, (size_t)(each * n), st)); return 0; }
+    for (int i = 0; i < n; ++i) {
+        HIPCHK(hipMemsetAsync(pl[i]->hi, 0, (size_t)elems * 2, st));
+        if (split) HIPCHK(hipMemsetAsync(pl[i]->lo, 0, (size_t)elems * 2, st));
+    }
+    return 0;
+}
 static Bump cur_bump(sta_handle* h) { return Bump{h->cur->ws, h->cur->ws_cap}; }
 
 // side lane of the current context (created on first use: one stream, 16 MiB of split-K scratch, four events)
@@ -1108,8 +1123,7 @@ static int encode_impl(sta_handle* h, Bump& ws, const void* const* imgs, bool u8
     qkv.q = ws.planes(hsz, split); qkv.k = ws.planes(hsz, split); qkv.vt = ws.planes(hsz, split);
     if (h->dry) return 0;
     REQUIRE(!ws.overflow, "internal: encode workspace overflow");
-    HIPCHK(hipMemsetAsync(qkv.vt.hi, 0, hsz * 2, st));
-    if (split) HIPCHK(hipMemsetAsync(qkv.vt.lo, 0, hsz * 2, st));
+    { const Planes* z[1] = {&qkv.vt}; CHK(zero_planes(z, 1, hsz, split, st)); }
     for (int sidx = 0; sidx < nsets; ++sidx) {
         int64_t total = (int64_t)B * N * 48;
         int blocks = (int)((total + 255) / 256);
@@ -1163,15 +1177,13 @@ static int decode_impl(sta_handle* h, Bump& ws, const float* feat1, const float*
     Planes f1 = ws.act(M, (int64_t)D * c.mlp_ratio, split);
     QKVOut qkv; qkv.npad = npad;
     int64_t hsz = (int64_t)S * Hh * npad * 64;
-    qkv.q = ws.planes(hsz, split); qkv.k = ws.planes(hsz, split); qkv.vt = ws.planes(hsz, split);
+    qkv.q = ws.planes(hsz, split); qkv.k = ws.planes(hsz, split);
     QKVOut cqkv; cqkv.npad = npad;          // cross attention: its K / V^T are produced while the self-attention set is live
-    cqkv.q = ws.planes(hsz, split); cqkv.k = ws.planes(hsz, split); cqkv.vt = ws.planes(hsz, split);
+    cqkv.q = ws.planes(hsz, split); cqkv.k = ws.planes(hsz, split);
+    qkv.vt = ws.planes(hsz, split); cqkv.vt = ws.planes(hsz, split);      // back to back: one fill zeroes both paddings
     if (h->dry) return 0;
     REQUIRE(!ws.overflow, "internal: decode workspace overflow");
-    HIPCHK(hipMemsetAsync(qkv.vt.hi, 0, hsz * 2, st));
-    if (split) HIPCHK(hipMemsetAsync(qkv.vt.lo, 0, hsz * 2, st));
-    HIPCHK(hipMemsetAsync(cqkv.vt.hi, 0, hsz * 2, st));
-    if (split) HIPCHK(hipMemsetAsync(cqkv.vt.lo, 0, hsz * 2, st));
+    { const Planes* z[2] = {&qkv.vt, &cqkv.vt}; CHK(zero_planes(z, 2, hsz, split, st)); }
 
     Planes fp2 = slice_rows(fp, (int64_t)B * N);
     CHK(run_rows_to_planes(h, feat1, (int64_t)N * E, B, N, E, fp, st));
