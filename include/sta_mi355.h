@@ -98,11 +98,16 @@ int sta_set_precision(sta_handle* h, int precision);
 int sta_set_deterministic(sta_handle* h, int on);
 
 /* Streams and concurrency.  Every call enqueues on the caller's stream; the handle keeps ONE scratch context (workspace +
- * split-K buffers) PER STREAM it has been called on (at most 8), created on the first call on that stream.  Calls on
+ * split-K buffers) PER STREAM it has been called on, created on the first call on that stream (at most 8 live contexts: a
+ * ninth stream takes over the least recently used one behind a device synchronisation).  Calls on
  * different streams therefore never share scratch memory and may overlap on the GPU - the intended use is the SLAM loop's
  * own independence: sta_encode of keyframe i+1 (add_view, slam.py:142-151, 258) on a second stream under
  * sta_regress_views of keyframe i (slam.py:263-277); at 224x224, batch 1 each of them alone leaves most of the chip idle
  * between its ~200 dependent dispatches.  Host-side the handle is still single-threaded (one call at a time).
+ * Inside one call the library forks an internal SIDE stream off the caller's stream for the branches that do not lie on the
+ * call's critical chain (DPT head: the reassembly of levels 0-2 under the level-3 / refinenet chain; decoder at SLAM scale:
+ * the cross-attention K / V under the self-attention) and joins it back before the call's last kernels: the caller sees
+ * ordinary stream order.  Same kernels, bit-identical results.
  * (Rounds 2-3 had sta_set_concurrency(h, n): batch slices of ONE forward on library-owned streams.  It stopped paying once
  * the epilogues no longer serialised - -1 % at the headline configuration in round 3 - and was removed in round 4.) */
 

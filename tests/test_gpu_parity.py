@@ -506,6 +506,24 @@ def test_dpt_side_lane_is_bit_identical(G, prec):
     assert m.range_report() == (0, 0)
 
 
+def test_stream_contexts_are_recycled(G):
+    """A handle keeps at most 8 scratch contexts; a call on one more stream takes over the least recently used context
+    (sta_mi355.h "Streams and concurrency") instead of failing - a long-lived process that keeps creating streams stays usable."""
+    import torch
+    from vista_slam_amd import weights as W
+    m = G.model("tiny", 1.0, DEFAULT)
+    G.set_variant(m, 0)
+    imgs = torch.from_numpy(W.synth_images(2, 64, 64, seed=43, tag=3)).cuda()
+    ref = m.forward_pair(imgs[:1], imgs[1:])[0]["pts3d_pred"].clone()
+    streams = [torch.cuda.Stream() for _ in range(12)]
+    assert len({s.cuda_stream for s in streams}) > 8, "the test needs more than 8 distinct streams"
+    for s in streams:
+        with torch.cuda.stream(s):
+            out = m.forward_pair(imgs[:1], imgs[1:])[0]["pts3d_pred"]
+        s.synchronize()
+        assert torch.equal(out, ref)
+
+
 def test_split_phase_scheduler_pipelines_two_keyframes(G):
     """sta_regress_views_begin / _finish: decode + pose heads of keyframe B's edges enqueued (second stream) BEFORE keyframe A's
     accept / reject + DPT heads run (first stream) - the pipelined schedule of bench.slam_replay - gives bit for bit what the

@@ -88,7 +88,7 @@ static const int64_t SKBUF_ELEMS = (int64_t)4 << 20;   // 16 MiB: M*N of the lar
 // (independent in OnlineSLAM.step: slam.py:258 vs :263-277).  Weights, tables and the zero page are read-only and shared.
 static const int MAX_STREAM_CTX = 8;
 struct StreamCtx {
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr; uint64_t last_use = 0;      // last_use: the handle's use_clock at the latest call (recycling order)
     char* ws = nullptr; int64_t ws_cap = 0;   // bump-allocated workspace, sized by the dry planning pass of the call
     float* skbuf = nullptr;   // fp32 partial sums of split-K GEMMs with the plane / QKV epilogue (SKBUF_ELEMS floats)
     float* slab = nullptr;    // slab split-K of the small-M in-place residual GEMMs (GemmParams::slab), same size
@@ -121,6 +121,7 @@ struct sta_handle {
     F32Lin pm0, pm1, pm2, pt, pr, pc;
     // staging + workspace
     float* stage = nullptr; int64_t stage_elems = 0;
+    uint64_t use_clock = 0;
     std::vector<StreamCtx> ctx; StreamCtx* cur = nullptr;     // per-stream scratch (stream_ctx); cur = the context of the running call
     f16* zero_page = nullptr;
     int small_grid_mode = 0;  // tools/tile_table.py only (sta_set_gemm_variant 10 / 11): 1 = never the small-grid family, 2 = 4x the product threshold
@@ -173,11 +174,21 @@ struct Bump {
 };
 
 // The context of stream `st` becomes the current one (created on the first call on that stream: 2 x 16 MiB of split-K scratch;
-// the workspace grows with the first call of a shape).  At most MAX_STREAM_CTX streams per handle.
+// the workspace grows with the first call of a shape).  At most MAX_STREAM_CTX contexts per handle: one more stream RECYCLES the
+// least recently used context with no split-phase call pending (behind a device synchronisation - work of the old stream may
+// still be using that scratch, and the old stream itself may be gone).
 static int stream_ctx(sta_handle* h, hipStream_t st) {
-    for (auto& c : h->ctx) if (c.st == st) { h->cur = &c; return 0; }
-    REQUIRE((int)h->ctx.size() < MAX_STREAM_CTX, "this handle has already been used on %d different streams (one scratch context per stream)", MAX_STREAM_CTX);
-    StreamCtx c; c.st = st;
+    for (auto& c : h->ctx) if (c.st == st) { h->cur = &c; c.last_use = ++h->use_clock; return 0; }
+    if ((int)h->ctx.size() >= MAX_STREAM_CTX) {
+        StreamCtx* lru = nullptr;
+        for (auto& c : h->ctx) if (!c.rv_open && (!lru || c.last_use < lru->last_use)) lru = &c;
+        REQUIRE(lru, "all %d scratch contexts of this handle have a split-phase scheduler call pending (sta_regress_views_begin without _finish)", MAX_STREAM_CTX);
+        HIPCHK(hipDeviceSynchronize());
+        lru->st = st; lru->last_use = ++h->use_clock;
+        h->cur = lru;
+        return 0;
+    }
+    StreamCtx c; c.st = st; c.last_use = ++h->use_clock;
     HIPCHK(hipMalloc((void**)&c.skbuf, (size_t)SKBUF_ELEMS * 4));
     if (hipMalloc((void**)&c.slab, (size_t)SKBUF_ELEMS * 4) != hipSuccess) { hipFree(c.skbuf); return set_err("split-K slab alloc failed"); }
     h->ctx.push_back(c);          // (reserve()d in sta_create: pointers into the vector stay valid)
@@ -911,8 +922,18 @@ static bool qkv_pair_one_launch(const sta_handle* h, const GemmParams& pa, const
     return h->prec != STA_PREC_F16 && !pa.mx && !pb.mx && big(pa) && big(pb) && pa.K == pb.K && pa.M == pb.M && auto_family(h);
 }
 // side lane of the current context (dpt_impl, decode_impl): usable unless switched off or a timing mode wants one stream
+// - and unless the application is already overlapping calls on several streams (another context used within the last few
+// calls): the chip is then filled across calls, and more streams than hardware queues make independent streams share a queue
+// and serialise (bench.py slam_replay, three caller streams: 229 keyframes/s without side lanes, 189 with them).
 static bool lanes_on(const sta_handle* h) {
-    return !h->dry && h->opt[6] != 1 && !h->timing && !h->ktime && !h->ktime_all && !h->kstamp_on;
+    if (h->dry || h->opt[6] == 1 || h->timing || h->ktime || h->ktime_all || h->kstamp_on) return false;
+    if (h->opt[6] == 2) return true;          // experiments: always
+    // measured with GPU_MAX_HW_QUEUES=8 in the environment (default: 4): every fork / join between streams on different hardware
+    // queues cost ~0.4 ms (single-stream slam_replay 143 -> 53 keyframes/s) - the lanes are tuned for the runtime's default only
+    static const bool queues_overridden = getenv("GPU_MAX_HW_QUEUES") != nullptr;
+    if (queues_overridden) return false;
+    for (const auto& c : h->ctx) if (&c != h->cur && c.last_use + 8 > h->use_clock) return false;
+    return true;
 }
 struct Lane { sta_handle* h; int v; Lane(sta_handle* h_, int v_) : h(h_), v(h_->lane) { h->lane = v_; } ~Lane() { h->lane = v; } };
 static int gemm_qkv_pair(sta_handle* h, const GemmParams& pa_in, const GemmParams& pb_in, hipStream_t st) {
