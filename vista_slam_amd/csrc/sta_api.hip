@@ -921,12 +921,12 @@ static bool qkv_pair_one_launch(const sta_handle* h, const GemmParams& pa, const
     auto big = [h](const GemmParams& p) { return p.N % 128 == 0 && !small_grid(h, p.M, p.N); };
     return h->prec != STA_PREC_F16 && !pa.mx && !pb.mx && big(pa) && big(pb) && pa.K == pb.K && pa.M == pb.M && auto_family(h);
 }
-// side lane of the current context (dpt_impl, decode_impl): usable unless switched off or a timing mode wants one stream
+// side lane of the current context (dpt_impl, decode_impl): usable unless switched off or a whole-model timing mode wants one stream
 // - and unless the application is already overlapping calls on several streams (another context used within the last few
 // calls): the chip is then filled across calls, and more streams than hardware queues make independent streams share a queue
 // and serialise (bench.py slam_replay, three caller streams: 229 keyframes/s without side lanes, 189 with them).
 static bool lanes_on(const sta_handle* h) {
-    if (h->dry || h->opt[6] == 1 || h->timing || h->ktime || h->ktime_all || h->kstamp_on) return false;
+    if (h->dry || h->opt[6] == 1 || h->timing || h->ktime_all || h->kstamp_on) return false;     // (the one-kernel timing mode of bench.py stays on the product path: its event pairs sit on each launch's own stream)
     if (h->opt[6] == 2) return true;          // experiments: always
     // measured with GPU_MAX_HW_QUEUES=8 in the environment (default: 4): every fork / join between streams on different hardware
     // queues cost ~0.4 ms (single-stream slam_replay 143 -> 53 keyframes/s) - the lanes are tuned for the runtime's default only
@@ -1336,7 +1336,7 @@ static int dpt_impl(sta_handle* h, Bump& ws, const float* enc, int64_t enc_bs,
     // kernel (tools/model_stamps.py: 10 - 25 us of event time around 5 - 17 us of work): 5-edge scheduler call -5.8 %, one pair
     // @512x384 +2.3 %; at the benchmark's 8 pairs the side kernels fill the chain's partial rounds (+0.8 %).  Same kernels, same
     // split-K slices (the side lane has its own scratch): bit-identical to the one-lane order (tests/test_gpu_parity.py).
-    // sta_debug_set_option(h, 6, 1) switches the lane off (A/B: tools/ab_option.py 6 1 0); the timing modes run one lane.
+    // sta_debug_set_option(h, 6, 1) switches the lane off (A/B: tools/ab_option.py 6 1 0); the whole-model timing modes (stage timing, per-launch timing of every GEMM, stamps) run one lane.
     const bool two = lanes_on(h);
     hipStream_t sb = st;                                                  // the side branches' stream
     if (two) {
