@@ -31,6 +31,7 @@ struct AttnParams {
     int S, heads, nq, nk, npad;
     int kv_shift;            // K/V come from sequence (s + kv_shift) % S
     float scale_log2e;       // head_dim^-0.5 * log2(e)
+    int prefetch;            // 1: nk <= 4 key tiles and the launch carries 4 LDS stages - ALL K / V^T tiles are requested up front (small grids)
     int pose;                // decoder: token index nk (== nq) of Q / K / V^T is the pose token.  As a KEY it is folded into the
                              // initial online-softmax state of every query (no 13th key tile for one key); as a QUERY it is served by
                              // the pose blocks (pose == 1: one wave per (sequence, head), plain fp32 dot products; nq % 128 == 0) or
@@ -41,7 +42,8 @@ struct AttnParams {
 #define ATT_TILE_BYTES (64 * 128)   // 64 rows x 64 fp16
 
 template <bool SPLIT>
-constexpr int attn_smem_bytes() { return 2 * (SPLIT ? 4 : 2) * ATT_TILE_BYTES; }
+constexpr int attn_smem_bytes(int stages = 2) { return stages * (SPLIT ? 4 : 2) * ATT_TILE_BYTES; }
+#define ATT_PREFETCH_TILES 4
 
 // The pose-token query of one (sequence, head) per workgroup: 1 x (nk + 1) scores, softmax and 1 x 64 output as fp32 dot products
 // (an MFMA tile would carry 31 dead queries through every key tile).  Phase 1: thread = key (K rows are 128 contiguous bytes),
@@ -246,10 +248,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 
     // one KV tile held in LDS stage `stage_c` (compile-time: the stage / t / d displacements fold into the ds_read
     // offset field); TAIL = last, partly valid tile (keys >= nk masked to -inf)
-    auto tile_body = [&](auto stage_c, auto tail_c, int kv0) {
+    auto tile_body = [&](auto stage_c, auto tail_c, int kv0, int stage_rt = 0) {
         constexpr int STG = decltype(stage_c)::value;
         constexpr bool TAIL = decltype(tail_c)::value;
-        const char* sK = smem + STG * STAGE;
+        const char* sK = smem + STG * STAGE + stage_rt * STAGE;     // stage_rt: the prefetch-all schedule's runtime stage (0 in the double-buffered loop)
         const char* sV = sK + NPL * ATT_TILE_BYTES;
 
         // ---- S^T = K Q^T  (rows = keys, cols = queries)
@@ -365,18 +367,40 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 
     const int ntiles = (p.nk + ATT_KV - 1) / ATT_KV, nfull = p.nk / ATT_KV;
     using F = integral_constant<bool, false>; using T = integral_constant<bool, true>;
-    issue_tile(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int it = 0;
-    for (; it + 1 < nfull; it += 2) {
-        step(integral_constant<int, 0>{}, F{}, it, ntiles);
-        step(integral_constant<int, 1>{}, F{}, it + 1, ntiles);
-    }
-    if (it < nfull) { step(integral_constant<int, 0>{}, F{}, it, ntiles); ++it; }
-    if (it < ntiles) {                                                  // the tail tile, in whichever stage it landed
-        if (it & 1) step(integral_constant<int, 1>{}, T{}, it, ntiles);
-        else step(integral_constant<int, 0>{}, T{}, it, ntiles);
+    if (p.prefetch) {
+        // Small grids (SLAM scale: 196 keys = 4 tiles, <= 256 workgroups): one tile's arithmetic (~0.7 us) is shorter than the
+        // latency of the next tile's DMA (~2 us), so the double-buffered loop below waits ~1.3 us per tile on a chain of four.
+        // With 4 LDS stages every tile is requested up front: one latency, then four tiles of arithmetic.  The DMAs complete in
+        // order, so tile t has landed once at most (ntiles - 1 - t) x DMAS instructions are outstanding.
+        constexpr int DMAS = 4 * NPL;                   // global_load_lds instructions per tile and wave
+        for (int t = 0; t < ntiles; ++t) issue_tile(t, t * ATT_KV);
+        for (int t = 0; t < ntiles; ++t) {
+            switch (ntiles - 1 - t) {
+                case 3: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * DMAS) : "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * DMAS) : "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(1 * DMAS) : "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+            __syncthreads();
+            if (wave_active) {
+                if (t >= nfull) tile_body(integral_constant<int, 0>{}, T{}, t * ATT_KV, t);
+                else tile_body(integral_constant<int, 0>{}, F{}, t * ATT_KV, t);
+            }
+        }
+    } else {
+        issue_tile(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int it = 0;
+        for (; it + 1 < nfull; it += 2) {
+            step(integral_constant<int, 0>{}, F{}, it, ntiles);
+            step(integral_constant<int, 1>{}, F{}, it + 1, ntiles);
+        }
+        if (it < nfull) { step(integral_constant<int, 0>{}, F{}, it, ntiles); ++it; }
+        if (it < ntiles) {                                                  // the tail tile, in whichever stage it landed
+            if (it & 1) step(integral_constant<int, 1>{}, T{}, it, ntiles);
+            else step(integral_constant<int, 0>{}, T{}, it, ntiles);
+        }
     }
 
     // ---- normalise and store: lane owns query q, d = dt*32 + (r&3) + 8*(r>>2) + 4*lhi.

@@ -1068,12 +1068,16 @@ static int run_attn(sta_handle* h, const QKVOut& qkv, const Planes& out, int ldo
     REQUIRE(!pose || (int64_t)(qkv.npad + 8 + 256) * 4 <= attn_smem_bytes<false>(), "internal: pose-query scratch exceeds the LDS allocation");
     REQUIRE(!pose || qkv.npad % 64 == 0, "internal: pose-query path needs npad % 64 == 0");
     dim3 grid((unsigned)(((nq + (p.pose == 2 ? 1 : 0) + 127) / 128) * heads * S + npose));
+    // small grids with <= 4 key tiles: 4 LDS stages, every K / V^T tile requested up front (attention.h; one workgroup per CU then,
+    // which a grid of <= 256 workgroups has anyway)
+    p.prefetch = (nk <= ATT_PREFETCH_TILES * ATT_KV && grid.x <= 256 && h->opt[5] != 1) ? 1 : 0;
+    const int stages = p.prefetch ? ATT_PREFETCH_TILES : 2;
     if (h->prec != STA_PREC_F16) {
         static unsigned attr_done = 0;      // one bit per device
-        if (!(attr_done >> (h->device & 31) & 1u)) { hipFuncSetAttribute((const void*)attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_smem_bytes<true>()); attr_done |= 1u << (h->device & 31); }
-        hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), attn_smem_bytes<true>(), st, p);
+        if (!(attr_done >> (h->device & 31) & 1u)) { hipFuncSetAttribute((const void*)attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_smem_bytes<true>(ATT_PREFETCH_TILES)); attr_done |= 1u << (h->device & 31); }
+        hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), attn_smem_bytes<true>(stages), st, p);
     } else {
-        STA_F16ONLY(hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), attn_smem_bytes<false>(), st, p));
+        STA_F16ONLY(hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), attn_smem_bytes<false>(stages), st, p));
     }
     HIPCHK(hipGetLastError());
     return 0;
