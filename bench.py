@@ -105,7 +105,7 @@ def slam_probe(model, dev, iters=20):
             "note": "frontend-only estimate for a TUM-style keyframe (1 encode + 5 accepted pairs); the reference's CPU stages (ORB/DBoW3, PGO) are not included"}
 
 
-def slam_replay(model, dev, frames=120, warm=12, res=(224, 224), src_hw=(480, 640), neighbor_edge_num=3, loop_edge_num=2):
+def slam_replay(model, dev, frames=120, warm=12, res=(224, 224), src_hw=(480, 640), neighbor_edge_num=3, loop_edge_num=2, streams=None):
     """Data-free stand-in for BASELINE configs[2] (TUM-RGBD through slam.py): `frames` synthetic 640x480 uint8 camera frames
     through the frontend's calls in `OnlineSLAM.step`'s order (slam.py:244-297) with a GROWING feature cache -
     f3 input step (crop / LANCZOS / ImgNorm, slam_images_only.py:19-33) -> add_view = encode (slam.py:142-151) -> the
@@ -138,8 +138,12 @@ def slam_replay(model, dev, frames=120, warm=12, res=(224, 224), src_hw=(480, 64
     raw = [distinct[f % 16] for f in range(n_all)]                      # frames resident in HBM (16 distinct ones, cycled)
     torch.cuda.synchronize()
     main_stream = torch.cuda.current_stream(dev)
-    enc_stream = torch.cuda.Stream(device=dev)
-    edge_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    calib = None
+    pool = None
+    if streams is None:
+        pool = [torch.cuda.Stream(device=dev) for _ in range(6)]
+        streams = pool[:3]
+    enc_stream, edge_streams = streams[0], list(streams[1:3])
 
     def run(nf, thres, pipelined):
         feats, rgbs, first = [], [], {}          # encoder feature cache; normalised frames; first node of every view: (depth, conf, K)
@@ -251,6 +255,22 @@ def slam_replay(model, dev, frames=120, warm=12, res=(224, 224), src_hw=(480, 64
         return ms, stats, npts, len(ids)
 
     _, st_w, _, _ = run(warm, -1.0, False)                               # warm-up: workspace, tables, threshold
+    if pool is not None:
+        # Stream placement: WHICH streams carry the three lanes decides how well they overlap - the same triple of streams is slow or
+        # fast every time it is used (tools/queue_probe.py: 177-183 vs 224-226 keyframes/s; the runtime places streams on a few
+        # hardware queues and the lanes of a slow triple end up serialising).  Nothing in the HIP API says which, so the harness
+        # does what an application would do at start-up: time the warm-up pass on four triples out of six streams, keep the best.
+        calib = {}
+        for idx in ((0, 1, 2), (3, 4, 5), (0, 2, 4), (1, 3, 5)):
+            enc_stream, edge_streams = pool[idx[0]], [pool[idx[1]], pool[idx[2]]]
+            run(warm, -1.0, True)                                        # this triple's scratch contexts
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(2 * warm, -1.0, True)
+            calib[idx] = 2 * warm / (time.perf_counter() - t0)
+        best = max(calib, key=calib.get)
+        enc_stream, edge_streams = pool[best[0]], [pool[best[1]], pool[best[2]]]
+        calib = {"chosen": list(best), "warmup_keyframes_per_s": {",".join(map(str, k)): round(v, 1) for k, v in calib.items()}}
     run(warm, -1.0, True)                                                # ... and the other streams' scratch contexts
     conf = sorted(st_w["nonadj_conf"])
     thres = conf[int(0.4 * len(conf))] if conf else -1.0
@@ -258,12 +278,19 @@ def slam_replay(model, dev, frames=120, warm=12, res=(224, 224), src_hw=(480, 64
     t0 = time.perf_counter()
     ms_s, st_s, npts_s, _ = run(frames, thres, False)
     dt_s = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ms, st, npts, nviews = run(frames, thres, True)
-    dt = time.perf_counter() - t0
+    # the pipelined schedule twice: the first full-length pass still grows per-stream pools (torch's caching allocator keeps one
+    # pool per stream, the library one workspace per stream - the 12-frame warm-up reaches neither high-water mark); the second
+    # pass is the steady state a long-running SLAM process sees and is the one reported; the first is kept beside it
+    dts = []
+    for _rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ms, st, npts, nviews = run(frames, thres, True)
+        dts.append(time.perf_counter() - t0)
+    dt = dts[-1]
     nonadj = len(st["nonadj_conf"])
     return {"frames": frames, "keyframes_per_s": round(frames / dt, 2), "ms_per_keyframe": round(dt / frames * 1e3, 3),
+            "first_pass_keyframes_per_s": round(frames / dts[0], 2), "stream_placement": calib,
             "same_result_as_single_stream": bool(npts == npts_s and st["rejected"] == st_s["rejected"] and st["edges"] == st_s["edges"]),
             "schedule": "three streams: f3 + encode of keyframe i+1 | decode + pose heads of keyframe i's edges (regress_views_begin) | DPT heads, "
                         "reductions and node bookkeeping of keyframe i-1 (regress_views_finish); one library scratch context per stream",
