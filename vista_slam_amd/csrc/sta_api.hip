@@ -936,6 +936,15 @@ static bool lanes_on(const sta_handle* h) {
     return true;
 }
 struct Lane { sta_handle* h; int v; Lane(sta_handle* h_, int v_) : h(h_), v(h_->lane) { h->lane = v_; } ~Lane() { h->lane = v; } };
+// Leaves a function that forked the side lane: the caller's stream waits for whatever the side lane still has in flight - also
+// on the error paths (an early return must not leave side-lane kernels writing a workspace the next call reuses).
+struct LaneJoin {
+    sta_handle* h; hipStream_t st; bool armed;
+    ~LaneJoin() {
+        if (!armed || !h->cur || !h->cur->side) return;
+        if (hipEventRecord(h->cur->side_ev[3], h->cur->side) == hipSuccess) (void)hipStreamWaitEvent(st, h->cur->side_ev[3], 0);
+    }
+};
 static int gemm_qkv_pair(sta_handle* h, const GemmParams& pa_in, const GemmParams& pb_in, hipStream_t st) {
     GemmParams pa = pa_in, pb = pb_in;
     if (h->dry) return 0;
@@ -1237,6 +1246,7 @@ static int decode_impl(sta_handle* h, Bump& ws, const float* feat1, const float*
     // norm1(x) and norm_y(x) from one read: y of one side == x of the other (sta_model.py:231-235); qkv and projk|projv:
     // one class, one plane format.  Layer i+1's pair is issued with layer i's mlp.fc2 (gemm_resid_ln).
     if (c.dec_depth > 0) CHK(run_ln(h, x, M, D, h->dec[0].n1, a1, &h->dec[0].ny, &ay, nullptr, st));
+    LaneJoin join_on_exit{h, st, false};          // armed by the first layer that forks
     for (int i = 0; i < c.dec_depth; ++i) {
         const DecBlk& b = h->dec[i];
         // self-attention q,k,v and the cross-attention k,v of the OTHER side depend only on the layer input: one launch.
@@ -1250,6 +1260,7 @@ static int decode_impl(sta_handle* h, Bump& ws, const float* feat1, const float*
             CHK(gp_qkv(h, pkv, ay, b.ckv, M, 0, D, D, cqkv, N, Hh, wp, 0, Mp));
             if (lanes_on(h) && !qkv_pair_one_launch(h, pq, pkv)) {
                 CHK(ensure_side(h));
+                join_on_exit.armed = true;
                 hipEvent_t* ev = h->cur->side_ev + 2 * (i & 1);
                 HIPCHK(hipEventRecord(ev[0], st));
                 HIPCHK(hipStreamWaitEvent(h->cur->side, ev[0], 0));
@@ -1349,6 +1360,7 @@ static int dpt_impl(sta_handle* h, Bump& ws, const float* enc, int64_t enc_bs,
         HIPCHK(hipEventRecord(h->cur->side_ev[3], st));
         HIPCHK(hipStreamWaitEvent(sb, h->cur->side_ev[3], 0));
     }
+    LaneJoin join_on_exit{h, st, two};
     Planes t0 = act(M, E, use_mx(h, h->act0_0)), t1 = act(M, D, dmx);
     Planes t2 = act(M, D, dmx), t3 = act(M, D, dmx);
     // act_postprocess (dpt_block.py:356-410)
