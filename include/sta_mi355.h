@@ -118,8 +118,9 @@ int sta_set_deterministic(sta_handle* h, int on);
  * tensor that is NOT a function of a LayerNorm output count them - the input and hook conversions, every plane of the DPT head
  * (which has no normalisation layers: convolutions, transposed convolutions, bilinear), the split-K finishers - and the
  * LayerNorm kernels count non-finite rows of the residual streams: counts[0] = fp16-range events, counts[1] = fp8
- * saturations on this handle's device since the last reset (events = (lane, tile) pairs with at least one such value;
- * device-wide: all handles on one GPU share the counters; the call synchronises the device).  QKV / attention / mlp.fc1 outputs
+ * saturations of THIS handle's calls since the last reset (events = (lane, tile) pairs with at least one such value; the
+ * counters live in the handle since round 4 - two handles on one GPU no longer see each other's events; the call
+ * synchronises the device).  QKV / attention / mlp.fc1 outputs
  * are bounded by their LayerNorm inputs and are not counted (0.7 % of the step if they were).  A non-zero counts[0] means the
  * forward left the range the parity goldens cover - the reference (fp32) has no such limit.  reset != 0 clears them. */
 int sta_range_report(sta_handle* h, unsigned long long counts[2], int reset);

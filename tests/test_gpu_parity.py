@@ -70,6 +70,21 @@ def test_range_overflow_is_reported_not_silent(G, prec):
     assert m.range_report() == (0, 0), "the report resets"
 
 
+def test_range_counters_are_per_handle(G):
+    """The range counters live in the handle (round 4; a device-wide pair before): a forward that saturates on one handle
+    (the overflow golden's weights) leaves the report of a second handle on the same GPU at (0, 0)."""
+    import torch
+    from vista_slam_amd import weights as W
+    clean = G.model("tiny", 1.0, DEFAULT, 43, 0)
+    dirty = G.model("tiny", 1.0, DEFAULT, 43, 2)
+    clean.range_report(); dirty.range_report()                  # reset both
+    imgs = torch.from_numpy(W.synth_images(2, 48, 64, seed=43, tag=1)).cuda()
+    dirty.forward_pair(imgs[:1], imgs[1:])
+    clean.forward_pair(imgs[:1], imgs[1:])
+    assert clean.range_report() == (0, 0), "events of another handle leaked into this one"
+    assert dirty.range_report()[0] > 0, "the saturating handle lost its own events"
+
+
 @pytest.mark.parametrize("case", STRESS)
 def test_stress_goldens_default_precision(G, case):
     """Eight more draws (weight / image seeds 44-47, smooth and noisy frames) of the sharpened tiny configuration: these

@@ -31,6 +31,7 @@ struct AttnParams {
     int S, heads, nq, nk, npad;
     int kv_shift;            // K/V come from sequence (s + kv_shift) % S
     float scale_log2e;       // head_dim^-0.5 * log2(e)
+    unsigned long long* range;   // the handle's range counters (sta_common.h)
     int prefetch;            // 1: nk <= 4 key tiles and the launch carries 4 LDS stages - ALL K / V^T tiles are requested up front (small grids)
     int pose;                // decoder: token index nk (== nq) of Q / K / V^T is the pose token.  As a KEY it is folded into the
                              // initial online-softmax state of every query (no 13th key tile for one key); as a QUERY it is served by
@@ -127,8 +128,8 @@ __device__ __forceinline__ void attn_pose_query(const AttnParams& p, char* smem)
     o /= (red[4] + red[5]) + (red[6] + red[7]);
     const int64_t orow = (int64_t)p.S * p.nq + s, orows = (int64_t)p.S * p.nq + p.S;
     const size_t oo = blk_off<SPLIT>(orow, h * 64 + lane, orows);
-    if (SPLIT) { f16 hh, ll; split_f16(o, hh, ll); p.O_hi[oo] = hh; p.O_hi[oo + 32] = ll; }
-    else p.O_hi[oo] = to_f16_sat(o);
+    if (SPLIT) { f16 hh, ll; split_f16(o, hh, ll, p.range); p.O_hi[oo] = hh; p.O_hi[oo + 32] = ll; }
+    else p.O_hi[oo] = to_f16_sat(o, p.range);
 }
 
 template <bool SPLIT>

@@ -17,6 +17,7 @@ struct LnParams {
     // optional first half of a slab split-K residual GEMM (GemmParams::slab): x[row] += sum_s slab[s][row]; x is rewritten,
     // then normalised as usual (g1 == nullptr: only the add)
     const float* slab; int nslab; float* xw;
+    unsigned long long* range;      // the handle's range counters (sta_common.h)
 };
 
 // normalised values n[4] of columns idx..idx+3 of `row` -> affine set 1 (fp32 copy and / or planes) and optional set 2
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)p.C + p.eps);
-    if (lane == 0 && !(fabsf(mean) <= 3.0e38f && rstd <= 3.0e38f && rstd > 0.f)) atomicAdd(&g_sta_range[0], 1ull);   // non-finite row, or a variance that overflowed fp32 (rstd == 0: the row would silently become pure bias)
+    if (lane == 0 && !(fabsf(mean) <= 3.0e38f && rstd <= 3.0e38f && rstd > 0.f)) atomicAdd(p.range, 1ull);   // non-finite row, or a variance that overflowed fp32 (rstd == 0: the row would silently become pure bias)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int idx = (i * 64 + lane) * 4;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void resid_ln_kernel(const LnParams p) {
     if (lane == 0) red[1][wave] = sq;
     __syncthreads();
     const float rstd = 1.0f / sqrtf(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)p.C + p.eps);
-    if (threadIdx.x == 0 && !(fabsf(mean) <= 3.0e38f && rstd <= 3.0e38f && rstd > 0.f)) atomicAdd(&g_sta_range[0], 1ull);   // non-finite row, or a variance that overflowed fp32 (rstd == 0: the row would silently become pure bias)
+    if (threadIdx.x == 0 && !(fabsf(mean) <= 3.0e38f && rstd <= 3.0e38f && rstd > 0.f)) atomicAdd(p.range, 1ull);   // non-finite row, or a variance that overflowed fp32 (rstd == 0: the row would silently become pure bias)
     if (on) {
         float n[4] = {(v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd};
         ln_store4<SPLIT>(p, row, idx, n, af);
@@ -143,7 +144,7 @@ template <bool SPLIT>
 __global__ void rows_to_planes_kernel(const float* x, int64_t bstride, int rows, int C, int64_t total4,
                                       f16* o_hi, f16* o_lo, int64_t obstride /* output batch stride in rows; 0 = rows */,
                                       int64_t orows /* rows of the blocked output planes; 0 = row-major [.,C] (Q/K buffers) */,
-                                      int mx = 0 /* blocked output in the f16mx row format */) {
+                                      int mx, /* blocked output in the f16mx row format */ unsigned long long* rng) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
     const int c4 = C / 4;
@@ -154,10 +155,10 @@ __global__ void rows_to_planes_kernel(const float* x, int64_t bstride, int rows,
         float y[4] = {v.x, v.y, v.z, v.w};
         H4 h, l;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e]); else h.e[e] = to_f16_sat(y[e]); }
+        for (int e = 0; e < 4; ++e) { if (SPLIT) split_f16(y[e], h.e[e], l.e[e], rng); else h.e[e] = to_f16_sat(y[e], rng); }
         const int64_t orow = obstride ? b * obstride + rr : r;
         if (SPLIT && mx && orows) {
-            store_mx4(o_hi, blk_off<SPLIT>(orow, c, orows), split_mx4<false>(y));
+            store_mx4(o_hi, blk_off<SPLIT>(orow, c, orows), split_mx4<false>(y, rng));
         } else if (orows) {
             const size_t o = blk_off<SPLIT>(orow, c, orows);
             *reinterpret_cast<uint2*>(o_hi + o) = h.u;
@@ -187,12 +188,12 @@ __global__ void planes_to_f32_kernel(const f16* hi, const f16* lo, int64_t ibstr
 }
 
 // fp32 V [nb, rows, 64] -> transposed planes Vt [nb, 64, npad]  (test/debug only)
-__global__ void pack_vt_kernel(const float* v, int nb, int rows, int npad, f16* hi, f16* lo) {
+__global__ void pack_vt_kernel(const float* v, int nb, int rows, int npad, f16* hi, f16* lo, unsigned long long* rng) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t total = (int64_t)nb * rows * 64;
     if (i >= total) return;
     int d = (int)(i % 64); int64_t t = i / 64; int r = (int)(t % rows); int64_t b = t / rows;
-    f16 h, l; split_f16(v[i], h, l);
+    f16 h, l; split_f16(v[i], h, l, rng);
     int64_t o = (b * 64 + d) * npad + r;
     hi[o] = h; if (lo) lo[o] = l;
 }
@@ -202,7 +203,7 @@ __global__ void pack_vt_kernel(const float* v, int nb, int rows, int npad, f16* 
 // img NCHW fp32 [n,3,H,W] -> planes [n*hp*wp, 768], K order (c, ky, kx) == conv weight flatten.
 // One thread = one (token, c, ky) row of 16 pixels (64 B in, 32 B out per plane).
 template <bool SPLIT>
-__global__ void patch_gather_kernel(const float* img, int n, int H, int W, f16* o_hi, f16* o_lo, int64_t row0, int64_t orows) {
+__global__ void patch_gather_kernel(const float* img, int n, int H, int W, f16* o_hi, f16* o_lo, int64_t row0, int64_t orows, unsigned long long* rng) {
     const int hp = H / 16, wp = W / 16;
     const int64_t total = (int64_t)n * hp * wp * 48;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -220,7 +221,7 @@ __global__ void patch_gather_kernel(const float* img, int n, int H, int W, f16* 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 f16 hh, ll;
-                if (SPLIT) split_f16(y[e], hh, ll); else { hh = to_f16_sat(y[e]); ll = (f16)0; }
+                if (SPLIT) split_f16(y[e], hh, ll, rng); else { hh = to_f16_sat(y[e], rng); ll = (f16)0; }
                 int k = q * 4 + e;
                 if (k < 8) { h0.e[k] = hh; l0.e[k] = ll; } else { h1.e[k - 8] = hh; l1.e[k - 8] = ll; }
             }
@@ -238,7 +239,7 @@ __global__ void patch_gather_kernel(const float* img, int n, int H, int W, f16* 
 // same operation order, is fused here, so the result is bit-identical to feeding the normalised
 // fp32 NCHW image.
 template <bool SPLIT>
-__global__ void patch_gather_u8hwc_kernel(const uint8_t* img, int n, int H, int W, f16* o_hi, f16* o_lo, int64_t row0, int64_t orows) {
+__global__ void patch_gather_u8hwc_kernel(const uint8_t* img, int n, int H, int W, f16* o_hi, f16* o_lo, int64_t row0, int64_t orows, unsigned long long* rng) {
     const int hp = H / 16, wp = W / 16;
     const int64_t total = (int64_t)n * hp * wp * 16;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -257,7 +258,7 @@ __global__ void patch_gather_u8hwc_kernel(const uint8_t* img, int n, int H, int 
                 const float a = (float)raw.e[kx * 3 + c] / 255.0f;
                 const float v = (a - 0.5f) / 0.5f;
                 f16 hh, ll;
-                if (SPLIT) split_f16(v, hh, ll); else { hh = to_f16_sat(v); ll = (f16)0; }
+                if (SPLIT) split_f16(v, hh, ll, rng); else { hh = to_f16_sat(v, rng); ll = (f16)0; }
                 if (kx < 8) { h0.e[kx] = hh; l0.e[kx] = ll; } else { h1.e[kx - 8] = hh; l1.e[kx - 8] = ll; }
             }
             const size_t o = blk_off<SPLIT>(row0 + tok, (c * 16 + ky) * 16, orows);
@@ -299,7 +300,7 @@ __global__ void emit_tokens_kernel(const float* x, int s0, int B, int N, int D, 
 // round 4) changed nothing.
 template <bool SPLIT, int NR>
 __global__ __launch_bounds__(256) void bilinear_up2_kernel(const f16* i_hi, const f16* i_lo, int n, int Hi, int Wi, int C,
-                                                           int Hc, int Wc, f16* o_hi, f16* o_lo, int mx = 0 /* input and output are f16mx rows */) {
+                                                           int Hc, int Wc, f16* o_hi, f16* o_lo, int mx /* input and output are f16mx rows */, unsigned long long* rng) {
     const int c8 = C / 8;
     const float ry = Hi > 1 ? (float)(Hi - 1) / (float)(2 * Hi - 1) : 0.f;
     const float rx = Wi > 1 ? (float)(Wi - 1) / (float)(2 * Wi - 1) : 0.f;
@@ -381,10 +382,10 @@ __global__ __launch_bounds__(256) void bilinear_up2_kernel(const f16* i_hi, cons
                 const MX4 m0 = split_mx4<false>(vout, ra), m1 = split_mx4<false>(vout + 4, ra);     // two 16-B stores per lane
                 *reinterpret_cast<uint4*>(o_hi + o) = make_uint4(m0.hi.x, m0.hi.y, m1.hi.x, m1.hi.y);
                 *reinterpret_cast<uint4*>(o_hi + o + 32) = make_uint4(m0.pairs.x, m0.pairs.y, m1.pairs.x, m1.pairs.y);
-                ra.flush();
+                ra.flush(rng);
                 return;
             }
-            ra.flush();
+            ra.flush(rng);
             *reinterpret_cast<uint4*>(o_hi + o) = oh.u;
             if (SPLIT) *reinterpret_cast<uint4*>(o_hi + o + 32) = ol.u;
         };
@@ -694,7 +695,7 @@ __global__ void rope2d_inplace_kernel(T* tok, int64_t sb, int64_t sn, const int6
 //   mode 1: conv [Co,Ci,kh,kw] -> [Co][kh][kw][Ci]
 //   mode 2: transposed conv [Ci,Co,k,k] -> [(dy*k+dx)*Co+co][Ci]
 __global__ void repack_weight_kernel(const float* src, f16* hi, f16* lo, int64_t total, int mode,
-                                     int d0, int d1, int d2, int d3, int64_t N, int64_t K, int64_t n_off, int mx = 0) {
+                                     int d0, int d1, int d2, int d3, int64_t N, int64_t K, int64_t n_off, int mx, unsigned long long* rng) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
     for (; i < total; i += step) {
@@ -706,11 +707,11 @@ __global__ void repack_weight_kernel(const float* src, f16* hi, f16* lo, int64_t
             int ci = (int)(i % d0); int64_t t = i / d0; int co = (int)(t % d1); t /= d1; int dx = (int)(t % d3); int dy = (int)(t / d3);
             si = (((int64_t)ci * d1 + co) * d2 + dy) * d3 + dx;
         }
-        f16 h, l; split_f16(src[si], h, l);
+        f16 h, l; split_f16(src[si], h, l, rng);
         // logical packed index i = n*K + k  ->  blocked [K/32][N][hi32|lo32]
         const int64_t nl = i / K, k = i - nl * K, n = nl + n_off;
         const size_t o = ((size_t)(k >> 5) * N + n) * 64 + (k & 31);
-        if (mx) store_mx1<true>(hi, o, src[si]);          // f16mx weight rows: [hi f16 | e4m3(hi*2^4) | e4m3(lo*2^15)]
+        if (mx) store_mx1<true>(hi, o, src[si], rng);          // f16mx weight rows: [hi f16 | e4m3(hi*2^4) | e4m3(lo*2^15)]
         else { hi[o] = h; hi[o + 32] = l; }
     }
 }
@@ -912,7 +913,7 @@ __global__ void mat_to_se3_kernel(const float* pose, int B, float* out) {
 // epilogue_tile<EPI_F16> and writes the blocked output planes.  One thread = 4 consecutive columns of one row.
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* skbuf, int ks, const float* bias, int M, int N, int act,
-                                                            const f16* R1, const f16* R2, f16* C, int64_t c_rp, int r_mx, int c_mx) {
+                                                            const f16* R1, const f16* R2, f16* C, int64_t c_rp, int r_mx, int c_mx, unsigned long long* rng) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int n4 = N >> 2;
     if (i >= (int64_t)M * n4) return;
@@ -938,9 +939,9 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* skbuf, 
             if (R2) { x += (float)R2[o + e]; if (SPLIT) x += (float)R2[o + 32 + e]; }
         }
         v[e] = x;
-        if (SPLIT) split_f16(x, oh.e[e], ol.e[e]); else oh.e[e] = to_f16_sat(x);
+        if (SPLIT) split_f16(x, oh.e[e], ol.e[e], rng); else oh.e[e] = to_f16_sat(x, rng);
     }
-    if (SPLIT && c_mx) { store_mx4(C, o, split_mx4<false>(v)); return; }
+    if (SPLIT && c_mx) { store_mx4(C, o, split_mx4<false>(v, rng)); return; }
     *reinterpret_cast<uint2*>(C + o) = oh.u;
     if (SPLIT) *reinterpret_cast<uint2*>(C + o + 32) = ol.u;
 }

@@ -55,6 +55,7 @@ struct GemmParams {
     int c_mx;                                            // EPI_F16 / EPI_CONVT output in the f16mx row format (consumer = f16mx GEMM)
     int r_mx;                                            // residual planes R1 / R2 are f16mx rows
     int64_t c_rp;
+    unsigned long long* range;                           // the handle's range counters (sta_common.h RangeAcc::flush)
     float* skbuf = nullptr;                              // EPI_F16 split-K: fp32 partial tiles [ksplit][M,N], one slab per K slice (no
                                                          //     atomics); splitk_finish_kernel sums them, applies bias / activation /
                                                          //     residual planes and writes the planes
@@ -475,7 +476,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
                 *reinterpret_cast<uint4*>(p.C_hi + o + 32) = ol.u;
             }
         }
-        ra.flush();
+        ra.flush(p.range);
         return;
     }
     bool ok[16];
@@ -538,7 +539,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
             else p.C_hi[o] = to_f16_sat(v, ra);
         }
     }
-    if (EPI != EPI_GELU) ra.flush();
+    if (EPI != EPI_GELU) ra.flush(p.range);
 }
 // between the tiles of one wave's epilogue: nothing moves across (keeps ONE tile's temporaries live; see epilogue_tile)
 #define STA_EPI_TILE_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -568,8 +569,8 @@ __global__ __launch_bounds__(256) void qkv_finish_kernel(const GemmParams p) {
         f16* const dh = seg == 0 ? p.Q_hi : p.K_hi;
         f16* const dl = seg == 0 ? p.Q_lo : p.K_lo;
         const size_t o = ((size_t)(s_ * p.heads + head) * p.npad + t) * 64 + dcol;
-        if (SPLIT) { f16 h, l; split_f16(v, h, l); dh[o] = h; dl[o] = l; }
-        else dh[o] = to_f16_sat(v);
+        if (SPLIT) { f16 h, l; split_f16(v, h, l, p.range); dh[o] = h; dl[o] = l; }
+        else dh[o] = to_f16_sat(v, p.range);
         return;
     }
     const int64_t j = i - n_qk;
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(256) void qkv_finish_kernel(const GemmParams p) {
         const int row = g * 4 + e < p.M ? g * 4 + e : p.M - 1;
         float v = bv;
         for (int s = 0; s < p.ksplit; ++s) v += p.skbuf[((size_t)s * p.M + row) * p.N + col];
-        if (SPLIT) split_f16(v, hh[e], ll[e]); else { hh[e] = to_f16_sat(v); ll[e] = (f16)0; }
+        if (SPLIT) split_f16(v, hh[e], ll[e], p.range); else { hh[e] = to_f16_sat(v, p.range); ll[e] = (f16)0; }
     }
     const int row0 = g * 4;
     int s0, t0; bool pr0;

@@ -124,6 +124,7 @@ struct sta_handle {
     uint64_t use_clock = 0;
     std::vector<StreamCtx> ctx; StreamCtx* cur = nullptr;     // per-stream scratch (stream_ctx); cur = the context of the running call
     f16* zero_page = nullptr;
+    unsigned long long* range = nullptr;   // the two range counters (sta_range_report): 16 B of device memory, per handle
     int small_grid_mode = 0;  // tools/tile_table.py only (sta_set_gemm_variant 10 / 11): 1 = never the small-grid family, 2 = 4x the product threshold
     int opt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // experiment switches (sta_debug_set_option; 0 = product behaviour)
     int tail_hint = 0;      // decode_impl: the last tail_hint rows of every dense GEMM are pose-token rows (GemmParams::m_tail)
@@ -424,6 +425,7 @@ extern "C" int sta_create(const sta_config* cfg, int device, sta_handle** out) {
     if (big > h->stage_elems) h->stage_elems = big;
     if (hipMalloc((void**)&h->stage, (size_t)h->stage_elems * 4) != hipSuccess) { sta_destroy(h); return set_err("staging alloc failed"); }
     if (hipMalloc((void**)&h->zero_page, 256) != hipSuccess || hipMemset(h->zero_page, 0, 256) != hipSuccess) { sta_destroy(h); return set_err("zero page alloc failed"); }
+    if (hipMalloc((void**)&h->range, 16) != hipSuccess || hipMemset(h->range, 0, 16) != hipSuccess) { sta_destroy(h); return set_err("range counter alloc failed"); }
     *out = h;
     return 0;
 }
@@ -442,6 +444,7 @@ extern "C" int sta_destroy(sta_handle* h) {
     }
     if (h->rope_tab) hipFree(h->rope_tab);
     if (h->zero_page) hipFree(h->zero_page);
+    if (h->range) hipFree(h->range);
     if (h->pre_tab) hipFree(h->pre_tab);
     if (h->clk_buf) hipFree(h->clk_buf);
     if (h->kstamp) hipFree(h->kstamp);
@@ -472,11 +475,8 @@ extern "C" int sta_range_report(sta_handle* h, unsigned long long counts[2], int
     REQUIRE(h && counts, "null argument");
     DEV_SCOPE(h->device);
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpyFromSymbol(counts, HIP_SYMBOL(g_sta_range), 16, 0, hipMemcpyDeviceToHost));
-    if (reset) {
-        const unsigned long long z[2] = {0, 0};
-        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_sta_range), z, 16, 0, hipMemcpyHostToDevice));
-    }
+    HIPCHK(hipMemcpy(counts, h->range, 16, hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(hipMemset(h->range, 0, 16));
     return 0;
 }
 extern "C" int sta_num_expected_tensors(const sta_handle* h) { return h ? (int)h->slots.size() : -1; }
@@ -516,8 +516,8 @@ extern "C" int sta_load_tensor(sta_handle* h, const char* name, const void* host
             } else {
                 int mode = s.kind == SK_W_ID ? 0 : (s.kind == SK_W_CONV ? 1 : 2);
                 int d0 = (int)s.shape[0], d1 = ndim > 1 ? (int)s.shape[1] : 1, d2 = ndim > 2 ? (int)s.shape[2] : 1, d3 = ndim > 3 ? (int)s.shape[3] : 1;
-                repack_weight_kernel<<<blocks, 256>>>(h->stage, s.dst_hi, s.dst_lo, n, mode, d0, d1, d2, d3, s.N, s.K, s.n_off);
-                if (s.dst_mx) repack_weight_kernel<<<blocks, 256>>>(h->stage, s.dst_mx, s.dst_mx + 32, n, mode, d0, d1, d2, d3, s.N, s.K, s.n_off, 1);
+                repack_weight_kernel<<<blocks, 256>>>(h->stage, s.dst_hi, s.dst_lo, n, mode, d0, d1, d2, d3, s.N, s.K, s.n_off, 0, h->range);
+                if (s.dst_mx) repack_weight_kernel<<<blocks, 256>>>(h->stage, s.dst_mx, s.dst_mx + 32, n, mode, d0, d1, d2, d3, s.N, s.K, s.n_off, 1, h->range);
             }
             HIPCHK(hipGetLastError());
             HIPCHK(hipDeviceSynchronize());
@@ -648,6 +648,7 @@ extern "C" int sta_debug_pick_family(int amode, int epi, long long M, int N, int
 template <int AMODE, int EPI>
 static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st, int* slab_ks_out = nullptr) {
     GemmParams p = p_in;
+    p.range = h->range;
     int slab_ks = 0;
     if (slab_ks_out) *slab_ks_out = 0;
     p.zero_page = h->zero_page;
@@ -814,8 +815,8 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st, in
         if (EPI == EPI_F16 && p.ksplit > 1) {
             const int64_t n4 = (int64_t)p.M * (p.N / 4);
             const int blocks = (int)((n4 + 255) / 256);
-            if (split) hipLaunchKernelGGL(splitk_finish_kernel<true>, dim3(blocks), dim3(256), 0, st, p.skbuf, p.ksplit, p.bias, p.M, p.N, p.act, p.R1_hi, p.R2_hi, p.C_hi, p.c_rp, p.r_mx, p.c_mx);
-            else hipLaunchKernelGGL(splitk_finish_kernel<false>, dim3(blocks), dim3(256), 0, st, p.skbuf, p.ksplit, p.bias, p.M, p.N, p.act, p.R1_hi, p.R2_hi, p.C_hi, p.c_rp, 0, 0);
+            if (split) hipLaunchKernelGGL(splitk_finish_kernel<true>, dim3(blocks), dim3(256), 0, st, p.skbuf, p.ksplit, p.bias, p.M, p.N, p.act, p.R1_hi, p.R2_hi, p.C_hi, p.c_rp, p.r_mx, p.c_mx, p.range);
+            else hipLaunchKernelGGL(splitk_finish_kernel<false>, dim3(blocks), dim3(256), 0, st, p.skbuf, p.ksplit, p.bias, p.M, p.N, p.act, p.R1_hi, p.R2_hi, p.C_hi, p.c_rp, 0, 0, p.range);
             HIPCHK(hipGetLastError());
         }
     } else {
@@ -947,6 +948,7 @@ struct LaneJoin {
 };
 static int gemm_qkv_pair(sta_handle* h, const GemmParams& pa_in, const GemmParams& pb_in, hipStream_t st) {
     GemmParams pa = pa_in, pb = pb_in;
+    pa.range = pb.range = h->range;
     if (h->dry) return 0;
     if (!qkv_pair_one_launch(h, pa, pb)) {
         CHK((launch_gemm<A_DENSE, EPI_QKV>(h, pa, st)));
@@ -1040,6 +1042,7 @@ static int run_ln(sta_handle* h, const float* x, int M, int C, const LNp& a, con
                   const float* slab = nullptr, int nslab = 0) {
     if (h->dry) return 0;
     LnParams p; memset(&p, 0, sizeof p);
+    p.range = h->range;
     p.slab = slab; p.nslab = nslab; p.xw = const_cast<float*>(x);     // slab split-K: x += sum of the slices first (x is the residual stream)
     p.x = x; p.ldx = C; p.M = M; p.C = C; p.eps = h->cfg.ln_eps;
     p.g1 = a.g; p.b1 = a.b; p.o1_hi = oa.hi; p.o1_lo = oa.lo;
@@ -1065,6 +1068,7 @@ static int run_attn(sta_handle* h, const QKVOut& qkv, const Planes& out, int ldo
     if (h->dry) return 0;
     REQUIRE(!pose || (nq == nk && nq + 1 <= qkv.npad), "internal: pose-token attention needs nq == nk < npad");
     AttnParams p; memset(&p, 0, sizeof p);
+    p.range = h->range;
     // the pose query: 2 = one more row of the last query block when that block has spare rows (nq = 196: rows 196..255 of the
     // second block are dead anyway - free, and no latency-bound side path at SLAM scale: 12.8 vs 26.1 us for 10 x 12 heads);
     // 1 = wave-per-(sequence, head) side blocks when the patch queries fill their blocks exactly (nq = 768)
@@ -1096,8 +1100,8 @@ static int run_rows_to_planes(sta_handle* h, const float* x, int64_t bstride, in
     if (h->dry) return 0;
     int64_t total4 = (int64_t)nb * rows * C / 4;
     int blocks = (int)((total4 + 255) / 256); if (blocks > 8192) blocks = 8192;
-    if (h->prec != STA_PREC_F16) hipLaunchKernelGGL(rows_to_planes_kernel<true>, dim3(blocks), dim3(256), 0, st, x, bstride, rows, C, total4, o.hi, o.lo, obstride, o.rp, mx ? 1 : 0);
-    else hipLaunchKernelGGL(rows_to_planes_kernel<false>, dim3(blocks), dim3(256), 0, st, x, bstride, rows, C, total4, o.hi, o.lo, obstride, o.rp, 0);
+    if (h->prec != STA_PREC_F16) hipLaunchKernelGGL(rows_to_planes_kernel<true>, dim3(blocks), dim3(256), 0, st, x, bstride, rows, C, total4, o.hi, o.lo, obstride, o.rp, mx ? 1 : 0, h->range);
+    else hipLaunchKernelGGL(rows_to_planes_kernel<false>, dim3(blocks), dim3(256), 0, st, x, bstride, rows, C, total4, o.hi, o.lo, obstride, o.rp, 0, h->range);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1110,10 +1114,10 @@ static int run_up2(sta_handle* h, const Planes& in, int n, int Hi, int Wi, int C
     const bool quad = Hc >= 64 && (int64_t)n * ((Hc + 3) / 4) >= 512 && h->opt[7] != 1;
     const int blocks = quad ? n * ((Hc + 3) / 4) : n * Hc;
     if (h->prec != STA_PREC_F16) {
-        if (quad) hipLaunchKernelGGL((bilinear_up2_kernel<true, 4>), dim3(blocks), dim3(256), 0, st, in.hi, in.lo, n, Hi, Wi, C, Hc, Wc, out.hi, out.lo, in.mx ? 1 : 0);
-        else hipLaunchKernelGGL((bilinear_up2_kernel<true, 1>), dim3(blocks), dim3(256), 0, st, in.hi, in.lo, n, Hi, Wi, C, Hc, Wc, out.hi, out.lo, in.mx ? 1 : 0);
+        if (quad) hipLaunchKernelGGL((bilinear_up2_kernel<true, 4>), dim3(blocks), dim3(256), 0, st, in.hi, in.lo, n, Hi, Wi, C, Hc, Wc, out.hi, out.lo, in.mx ? 1 : 0, h->range);
+        else hipLaunchKernelGGL((bilinear_up2_kernel<true, 1>), dim3(blocks), dim3(256), 0, st, in.hi, in.lo, n, Hi, Wi, C, Hc, Wc, out.hi, out.lo, in.mx ? 1 : 0, h->range);
     } else {
-        STA_F16ONLY(hipLaunchKernelGGL((bilinear_up2_kernel<false, 1>), dim3(blocks), dim3(256), 0, st, in.hi, in.lo, n, Hi, Wi, C, Hc, Wc, out.hi, out.lo, 0));
+        STA_F16ONLY(hipLaunchKernelGGL((bilinear_up2_kernel<false, 1>), dim3(blocks), dim3(256), 0, st, in.hi, in.lo, n, Hi, Wi, C, Hc, Wc, out.hi, out.lo, 0, h->range));
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -1164,10 +1168,10 @@ static int encode_impl(sta_handle* h, Bump& ws, const void* const* imgs, bool u8
         const int64_t row0 = (int64_t)sidx * B * N;
         if (u8hwc) {
             const int b16 = (int)(((int64_t)B * N * 16 + 255) / 256);
-            if (split) hipLaunchKernelGGL(patch_gather_u8hwc_kernel<true>, dim3(b16), dim3(256), 0, st, (const uint8_t*)imgs[sidx], B, H, W, patches.hi, patches.lo, row0, (int64_t)M);
-            else hipLaunchKernelGGL(patch_gather_u8hwc_kernel<false>, dim3(b16), dim3(256), 0, st, (const uint8_t*)imgs[sidx], B, H, W, patches.hi, patches.lo, row0, (int64_t)M);
-        } else if (split) hipLaunchKernelGGL(patch_gather_kernel<true>, dim3(blocks), dim3(256), 0, st, (const float*)imgs[sidx], B, H, W, patches.hi, patches.lo, row0, (int64_t)M);
-        else hipLaunchKernelGGL(patch_gather_kernel<false>, dim3(blocks), dim3(256), 0, st, (const float*)imgs[sidx], B, H, W, patches.hi, patches.lo, row0, (int64_t)M);
+            if (split) hipLaunchKernelGGL(patch_gather_u8hwc_kernel<true>, dim3(b16), dim3(256), 0, st, (const uint8_t*)imgs[sidx], B, H, W, patches.hi, patches.lo, row0, (int64_t)M, h->range);
+            else hipLaunchKernelGGL(patch_gather_u8hwc_kernel<false>, dim3(b16), dim3(256), 0, st, (const uint8_t*)imgs[sidx], B, H, W, patches.hi, patches.lo, row0, (int64_t)M, h->range);
+        } else if (split) hipLaunchKernelGGL(patch_gather_kernel<true>, dim3(blocks), dim3(256), 0, st, (const float*)imgs[sidx], B, H, W, patches.hi, patches.lo, row0, (int64_t)M, h->range);
+        else hipLaunchKernelGGL(patch_gather_kernel<false>, dim3(blocks), dim3(256), 0, st, (const float*)imgs[sidx], B, H, W, patches.hi, patches.lo, row0, (int64_t)M, h->range);
         HIPCHK(hipGetLastError());
     }
     CHK(gemm_f32(h, patches, h->patch, M, feat, E, nullptr, st));

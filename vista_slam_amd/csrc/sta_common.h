@@ -20,16 +20,17 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 // The running maximum is kept on the BIT PATTERN of |x| (v_and + v_max_u32): as unsigned integers NaN (0x7fc00000) > inf
 // (0x7f800000) > every finite value, so a NaN is sticky and counts as a range event too (a float max would drop it, and the
 // clamp below turns it into -65504: silent).  A non-finite ROW of a residual stream is also counted by the LayerNorm kernels.
-__device__ unsigned long long g_sta_range[2];
+// The two counters live in the handle (sta_handle::range, 16 B of device memory): every kernel that reports gets the pointer
+// (GemmParams::range, LnParams::range, AttnParams::range or a trailing `rng` argument).
 #define STA_F16_MAX_BITS 0x477fe000u      // bits of 65504.0f
 #define STA_E5M2_MAX_BITS 0x47600000u     // bits of 57344.0f
 struct RangeAcc {
     unsigned amax = 0u;     // bits of the largest |x| written as an fp16 (hi, residual) pair
     unsigned amax8 = 0u;    // the same for values whose fp8 (e5m2) copy was written (f16mx activation rows: saturates beyond 57344)
     bool w8 = false;        // a WEIGHT e4m3 byte saturated (packing at load time: exact check)
-    __device__ __forceinline__ void flush() {
-        if (__builtin_expect(amax > STA_F16_MAX_BITS, 0)) atomicAdd(&g_sta_range[0], 1ull);
-        if (__builtin_expect(amax8 > STA_E5M2_MAX_BITS || w8, 0)) atomicAdd(&g_sta_range[1], 1ull);
+    __device__ __forceinline__ void flush(unsigned long long* rng) {
+        if (__builtin_expect(amax > STA_F16_MAX_BITS, 0)) atomicAdd(rng, 1ull);
+        if (__builtin_expect(amax8 > STA_E5M2_MAX_BITS || w8, 0)) atomicAdd(rng + 1, 1ull);
         amax = amax8 = 0u; w8 = false;
     }
 };
@@ -46,9 +47,9 @@ __device__ __forceinline__ void split_f16(float x, f16& hi, f16& lo, RangeAcc& r
     hi = (f16)x;
     lo = (f16)(x - (float)hi);
 }
-__device__ __forceinline__ void split_f16(float x, f16& hi, f16& lo) { RangeAcc ra; split_f16(x, hi, lo, ra); ra.flush(); }
+__device__ __forceinline__ void split_f16(float x, f16& hi, f16& lo, unsigned long long* rng) { RangeAcc ra; split_f16(x, hi, lo, ra); ra.flush(rng); }
 __device__ __forceinline__ f16 to_f16_sat(float x, RangeAcc& ra) { return (f16)sat_f16_range(x, ra); }
-__device__ __forceinline__ f16 to_f16_sat(float x) { RangeAcc ra; const f16 r = to_f16_sat(x, ra); ra.flush(); return r; }
+__device__ __forceinline__ f16 to_f16_sat(float x, unsigned long long* rng) { RangeAcc ra; const f16 r = to_f16_sat(x, ra); ra.flush(rng); return r; }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -137,7 +138,7 @@ __device__ __forceinline__ MX4 split_mx4(const float y[4], RangeAcc& ra) {
     return r;
 }
 template <bool WEIGHT>
-__device__ __forceinline__ MX4 split_mx4(const float y[4]) { RangeAcc ra; const MX4 r = split_mx4<WEIGHT>(y, ra); ra.flush(); return r; }
+__device__ __forceinline__ MX4 split_mx4(const float y[4], unsigned long long* rng) { RangeAcc ra; const MX4 r = split_mx4<WEIGHT>(y, ra); ra.flush(rng); return r; }
 // o = blk_off<true>(row, col, rows) with col % 4 == 0: hi at base + o, the byte pairs in the second half of the row block
 __device__ __forceinline__ void store_mx4(f16* base, size_t o, const MX4& v) {
     *reinterpret_cast<uint2*>(base + o) = v.hi;
@@ -166,7 +167,7 @@ __device__ __forceinline__ void store_mx1(f16* base, size_t o, float x, RangeAcc
     reinterpret_cast<unsigned short*>(base)[o + 32] = pair;
 }
 template <bool WEIGHT>
-__device__ __forceinline__ void store_mx1(f16* base, size_t o, float x) { RangeAcc ra; store_mx1<WEIGHT>(base, o, x, ra); ra.flush(); }
+__device__ __forceinline__ void store_mx1(f16* base, size_t o, float x, unsigned long long* rng) { RangeAcc ra; store_mx1<WEIGHT>(base, o, x, ra); ra.flush(rng); }
 
 union H8 { uint4 u; half8 h; f16 e[8]; };
 union H4 { uint2 u; half4 h; f16 e[4]; };

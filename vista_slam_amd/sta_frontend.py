@@ -103,7 +103,7 @@ class STAFrontend:
         self.precision = precision
 
     def range_report(self, reset: bool = True):
-        """(fp16 saturations, fp8 correction-byte saturations) counted by the plane writers on this GPU since the last reset
+        """(fp16 saturations, fp8 correction-byte saturations) counted by the plane writers in THIS handle's calls since the last reset
         (sta_range_report): non-zero fp16 saturations = the forward left the range the fp16 planes can carry."""
         c = (C.c_ulonglong * 2)()
         _lib.check(self.lib.sta_range_report(self._h, c, int(reset)))
