@@ -802,9 +802,22 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st, in
         else if (split) CHK((launch_gemm2<true, AMODE, EPI, 192, 128, 2, 4>(p, st, h->device)));
         else STA_F16ONLY(CHK((launch_gemm2<false, AMODE, EPI, 192, 128, 2, 4>(p, st, h->device))));
     } else if (variant == 6) {
-        if (p.mx) { if constexpr (MX_EPI) CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 2, 2, 3, true>(p, st, h->device))); }
-        else if (split) CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 2, 2, 3>(p, st, h->device)));
-        else STA_F16ONLY(CHK((launch_gemm2<false, AMODE, EPI, 128, 64, 2, 2, 3>(p, st, h->device))));
+        // A grid of <= 256 workgroups leaves every workgroup alone on its CU: with 4 waves (one per SIMD) the barrier, the DMA
+        // issue, the fragment reads and the MFMAs of a K tile simply add up (ablations, tools/ring_ablate.py: 0.12 + 0.14 + 0.09 +
+        // 0.19 = 0.54 us per K tile) - the same tile on 8 waves (two per SIMD, wave tile 32x32) lets one wave's MFMAs run under
+        // the other's issue and waits: encode -3.8 %, one pair @224 +4.1 %.  Larger grids (two workgroups per CU already) keep
+        // the 4-wave form, whose 64x32 wave tile reads 25 % fewer fragments (8 waves there: -1.2 ... -1.4 %).
+        const int sg_grid = ((p.M + 127) / 128) * (p.N / 64) * (p.ksplit > 1 ? p.ksplit : 1);
+        const bool lone = sg_grid <= (h->opt[2] > 1 ? h->opt[2] : 256) && h->opt[2] != 1;
+        if (p.mx) {
+            if constexpr (MX_EPI) {
+                if (lone) CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 4, 2, 3, true>(p, st, h->device)));
+                else CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 2, 2, 3, true>(p, st, h->device)));
+            }
+        } else if (split) {
+            if (lone) CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 4, 2, 3>(p, st, h->device)));
+            else CHK((launch_gemm2<true, AMODE, EPI, 128, 64, 2, 2, 3>(p, st, h->device)));
+        } else STA_F16ONLY(CHK((launch_gemm2<false, AMODE, EPI, 128, 64, 2, 2, 3>(p, st, h->device))));
         if (EPI == EPI_QKV && p.ksplit > 1) {
             const int64_t nthr = (int64_t)p.M * (p.nq + p.nk) + (int64_t)((p.M + 3) / 4) * p.nv;
             const int blocks = (int)((nthr + 255) / 256);
