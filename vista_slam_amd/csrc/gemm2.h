@@ -180,8 +180,12 @@ __device__ __forceinline__ void gemm2_tail(const GemmParams& p, const int tb, ch
     epilogue_tile<SPLIT, EPI>(p, acc, row0, col0 + l31, lane, 0);
 }
 
-template <bool SPLIT, int AMODE, int EPI, int BM, int BN, int WAVES_M, int WAVES_N, int ABL = 0, int NSTG = 2, bool MX = false>
+#ifndef STA_RING_ABL
+#define STA_RING_ABL 0      // probe builds (tools/ring_ablate.py): the ablation mask below applied to the ring family inside the product flow
+#endif
+template <bool SPLIT, int AMODE, int EPI, int BM, int BN, int WAVES_M, int WAVES_N, int ABL_ = 0, int NSTG = 2, bool MX = false>
 __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_id_in) {
+    constexpr int ABL = ABL_ | (NSTG > 2 ? STA_RING_ABL : 0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MT = WM / 32, NT = WN / 32;
@@ -196,7 +200,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
 
     // skinny tail blocks come first in the grid (launch_gemm2 adds them): short, they overlap the first round of tiles
     int block_id = block_id_in;
-    constexpr bool HAS_TAIL = AMODE == A_DENSE && !MX && NSTG == 2 && ABL == 0 && BM >= 192 &&
+    constexpr bool HAS_TAIL = AMODE == A_DENSE && !MX && NSTG == 2 && ABL_ == 0 && BM >= 192 &&
                               (EPI == EPI_F32 || EPI == EPI_F32R || EPI == EPI_GELU || EPI == EPI_QKV);
     if constexpr (HAS_TAIL) {
         if (p.m_tail > 0) {
@@ -339,7 +343,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
     if (RING) {
 #pragma unroll
         for (int s0 = 0; s0 < NSTG - 1; ++s0)
-            if (s0 < nkt) issue_tile(kt0 + s0, s0);
+            if (s0 < nkt && !(ABL & 1)) issue_tile(kt0 + s0, s0);
     } else {
         issue_tile(kt0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -363,7 +367,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
             else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * GPW) : "memory");
             if (p.stamps && kt == 0) st1 = __builtin_amdgcn_s_memrealtime();
             // the barrier also says every wave finished tile kt-1: its stage is free for tile kt+NSTG-1
-            if (kt + NSTG - 1 < nkt) issue_tile(kt0 + kt + NSTG - 1, (kt + NSTG - 1) % NSTG);
+            if (kt + NSTG - 1 < nkt && !(ABL & 1)) issue_tile(kt0 + kt + NSTG - 1, (kt + NSTG - 1) % NSTG);
         } else if (kt + 1 < nkt && !(ABL & 1) && !late_dma) issue_tile(kt0 + kt + 1, cur ^ 1);
         const char* sA = smem + cur * STAGE;
         const char* sB = sA + A_TILE;
