@@ -583,6 +583,16 @@ static inline bool small_grid_m(int mode, int64_t M, int N) {
     if (mode == 2) return M <= 2560 || t < 512;
     return M <= 640 || t < 192;
 }
+// K slices of a small-grid GEMM with tiles_r output tiles: about one workgroup per CU and never more than 256 of them while that
+// still splits (256 / tiles_r >= 2: the grid stays "lone" and runs the 8-wave form, launch_gemm); between 128 and 256 tiles a
+// GEMM whose K slices would need a finisher kernel of their own (QKV, plane epilogues) is not split at all - the finisher is a
+// dispatch (5 - 7 us) for a K loop that two slices shorten by less -, one whose slices are summed by the LayerNorm kernel that
+// follows anyway (in-place residual GEMMs) takes two.  Measured against ceil(256 / tiles_r) everywhere: encode -2 %, 5-edge
+// scheduler -1.7 %, one pair @224 +3.5 %, one pair @512x384 +1 %.  h->opt[1] == 1: the old rule (A/B).
+static inline int sg_slices(const sta_handle* h, int tiles_r, bool own_finisher = false) {
+    if (h->opt[1] != 1) { const int f = 256 / tiles_r; if (f >= 2) return f; if (own_finisher) return 1; }
+    return (256 + tiles_r - 1) / tiles_r;
+}
 static inline bool small_grid(const sta_handle* h, int64_t M, int N) { return small_grid_m(h->small_grid_mode, M, N); }
 
 // Tile-family choice = a quantisation-aware cost model calibrated on profiles/r03_tile_table.txt (tools/tile_table.py: every
@@ -688,7 +698,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st, in
             // cost more than the 4-32 K tiles of a slice); fixed summation order -> also taken in deterministic mode
             // (swept at M = 196 / 394 / 1970: a target of 128 / 192 / 256 / 384 / 512 workgroups -> encode 2.50 / 2.40 / 2.38 /
             // 2.49 / 2.55 ms: one workgroup per CU; more slices cost more slab traffic than their shorter K loops save)
-            int ks = tiles_r < 256 ? (256 + tiles_r - 1) / tiles_r : 1;
+            int ks = tiles_r < 256 ? sg_slices(h, tiles_r) : 1;
             const int max_ks = p.K / 128;                 // keep >= 4 K tiles per slice
             if (ks > max_ks) ks = max_ks;
             while (ks > 1 && (int64_t)ks * p.M * p.N > SKBUF_ELEMS) --ks;
@@ -702,7 +712,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st, in
         // QKV-epilogue GEMMs (attn.qkv, cross_attn.projq / projk|projv) on small grids: K slices to slabs, qkv_finish_kernel
         // applies bias + RoPE and writes Q / K / V^T (un-split attn.qkv at M = 196: 96 workgroups x 32 K tiles = 25 us)
         if (AMODE == A_DENSE && EPI == EPI_QKV && tiles_r <= 192 && p.K >= 512) {
-            int ks = (256 + tiles_r - 1) / tiles_r;
+            int ks = sg_slices(h, tiles_r, true);
             const int max_ks = p.K / 256;                 // keep >= 8 K tiles per slice
             if (ks > max_ks) ks = max_ks;
             while (ks > 1 && (int64_t)ks * p.M * p.N > SKBUF_ELEMS) --ks;
@@ -714,7 +724,7 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st, in
         // 160 / 256 tiles -> DPT 1.00 / 0.85 / 0.83 ms per view; with slabs, 5-edge scheduler: <= 192 / 256 tiles -> 6.04 / 5.89 ms).  An in-kernel fix-up (last slice finishes the tile behind a
         // device-scope fence + ticket) was 1.7x SLOWER than this: the fence writes back / invalidates the XCD's L2.
         if (EPI == EPI_F16 && tiles_r <= 256 && p.K >= 1024 && p.N % 4 == 0 && (int64_t)p.M * p.N <= SKBUF_ELEMS) {
-            int ks = (256 + tiles_r - 1) / tiles_r;
+            int ks = sg_slices(h, tiles_r, true);
             const int max_ks = p.K / 256;                 // keep >= 8 K tiles per slice
             if (ks > max_ks) ks = max_ks;
             while (ks > 1 && (int64_t)ks * p.M * p.N > SKBUF_ELEMS) --ks;      // one slab per K slice
