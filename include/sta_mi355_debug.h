@@ -51,10 +51,12 @@ int sta_debug_attention(sta_handle* h, const float* q, const float* k, const flo
 int sta_debug_attention_pose(sta_handle* h, const float* q, const float* k, const float* v, int S, int heads,
                              int n, int kv_shift, float* out, void* stream);
 
-/* Switches of the tests / tools (0 everywhere = product behaviour; indices 0-3 and 5-7 are free for one-off experiments, see
- * tools/ab_option.py; also settable as STA_OPT<idx> in the environment at sta_create).  idx 4 = 1: sta_debug_gemm (plane
- * epilogue) / conv3x3 / convt / up2 run in the DPT head's f16mx arithmetic (f16mx rows in and out, f16mx weights) when the
- * handle's precision is f16x3h - the kernels that precision uses inside the head. */
+/* Switches of the tests / tools (0 everywhere = product behaviour; see tools/ab_option.py; settable as STA_OPT<idx> in the
+ * environment at sta_create only in -DSTA_BENCH_EXPERIMENTS builds).  idx 4 = 1: sta_debug_gemm (plane epilogue) / conv3x3 /
+ * convt / up2 run in the DPT head's f16mx arithmetic (f16mx rows in and out, f16mx weights) when the handle's precision is
+ * f16x3h - the kernels that precision uses inside the head.  A/B switches of round-4 choices: 1 = 1 small-grid K slices by the
+ * old rule; 2 = 1 small-grid GEMMs always on 4 waves; 5 = 1 attention without the 4-stage prefetch schedule; 6 = 1 no side
+ * lanes (2: always); 7 = 1 bilinear one output row per workgroup.  Indices 0 and 3 are free. */
 int sta_debug_set_option(sta_handle* h, int idx, int value);
 
 /* Row-tail hint for the dense GEMMs (what the decoder sets to its 2B pose-token rows): the last `rows` (<= 32) rows of the
