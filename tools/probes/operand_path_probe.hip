@@ -13,7 +13,7 @@
 
 #define TILE_BYTES (192 * 128)
 
-template <int MODE, int STAGES = 3, bool MIXED = false>
+template <int MODE, int STAGES = 3, bool MIXED = false, bool PRODUCER = false>
 __global__ __launch_bounds__(256) void probe(const char* src, int tiles, unsigned long long* stamps, float* sink) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -24,9 +24,10 @@ __global__ __launch_bounds__(256) void probe(const char* src, int tiles, unsigne
     auto issue = [&](int t, int stage) {
         const char* g = base + (size_t)t * TILE_BYTES;
         char* l = smem + stage * TILE_BYTES;
+        if (PRODUCER && wave != 0) return;
 #pragma unroll
-        for (int s = 0; s < 6; ++s) {
-            const int slot = wave + 4 * s;                                  // 24 slots of 1 KB
+        for (int s = 0; s < (PRODUCER ? 24 : 6); ++s) {
+            const int slot = PRODUCER ? s : wave + 4 * s;                  // 24 slots of 1 KB (PRODUCER: wave 0 issues all of them)
             if (MODE == 0) {
                 // MIXED: slots 0..15 (the activation rows of a 128x64 tile) come from ONE region every workgroup shares (L2-hot),
                 // slots 16..23 (the weight rows) are fresh bytes
@@ -40,7 +41,11 @@ __global__ __launch_bounds__(256) void probe(const char* src, int tiles, unsigne
         for (int q = 0; q < STAGES - 1; ++q) if (q < tiles) issue(q, q);
         for (int t = 0; t < tiles; ++t) {
             int rem = tiles - 1 - t; if (rem > STAGES - 2) rem = STAGES - 2;
-            if (rem == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (PRODUCER) {
+                if (rem == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                else if (rem == 1) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(48)\n\ts_barrier" ::: "memory");
+            } else if (rem == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             else if (rem == 1) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
             else if (rem == 2) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");
@@ -82,12 +87,12 @@ __global__ __launch_bounds__(256) void probe(const char* src, int tiles, unsigne
     if (tid == 0) { stamps[2 * blockIdx.x] = t0; stamps[2 * blockIdx.x + 1] = t1; }
 }
 
-template <int MODE, int STAGES = 3, bool MIXED = false>
+template <int MODE, int STAGES = 3, bool MIXED = false, bool PRODUCER = false>
 static void run(const char* name, const char* src, int wgs, int tiles, unsigned long long* stamps, float* sink) {
-    hipFuncSetAttribute((const void*)probe<MODE, STAGES, MIXED>, hipFuncAttributeMaxDynamicSharedMemorySize, STAGES * TILE_BYTES);
+    hipFuncSetAttribute((const void*)probe<MODE, STAGES, MIXED, PRODUCER>, hipFuncAttributeMaxDynamicSharedMemorySize, STAGES * TILE_BYTES);
     std::vector<double> med;
     for (int rep = 0; rep < 5; ++rep) {
-        hipLaunchKernelGGL((probe<MODE, STAGES, MIXED>), dim3(wgs), dim3(256), STAGES * TILE_BYTES, 0, src, tiles, stamps, sink);
+        hipLaunchKernelGGL((probe<MODE, STAGES, MIXED, PRODUCER>), dim3(wgs), dim3(256), STAGES * TILE_BYTES, 0, src, tiles, stamps, sink);
         hipDeviceSynchronize();
         std::vector<unsigned long long> h(2 * wgs);
         hipMemcpy(h.data(), stamps, sizeof(unsigned long long) * 2 * wgs, hipMemcpyDeviceToHost);
@@ -121,6 +126,8 @@ int main() {
         run<0, 5, true>("LDS-DMA mixed, 5 stages", src, wgs, tiles, stamps, sink);
     }
     run<0, 5, false>("LDS-DMA fresh, 5 stages", src, wgs, 32, stamps, sink);
+    printf("-- one producer wave issues all 24 DMA instructions of a tile (the other three only meet it at the barrier)\n");
+    for (int tiles : {11, 32}) run<0, 3, true, true>("LDS-DMA mixed, 3 stages, one producer wave", src, wgs, tiles, stamps, sink);
     for (int w : {64, 128}) {
         run<0>("LDS-DMA (global_load_lds_dwordx4)", src, w, 32, stamps, sink);
         run<1>("register staged (global_load + ds_write_b128)", src, w, 32, stamps, sink);
