@@ -356,19 +356,8 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
     // K steps - so that one of them always has MFMAs to feed the matrix pipe while the other sits in the
     // (slow, back-pressured) LDS-DMA issue.
     const bool late_dma = (ABL & 8) && !RING && wave >= NW / 2;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = RING ? kt % NSTG : (kt & 1);
-        if (RING) {
-            // tile kt has landed once at most `rem` younger tiles of this wave are outstanding
-            int rem = nkt - 1 - kt; if (rem > NSTG - 2) rem = NSTG - 2;
-            if (rem == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GPW) : "memory");
-            else if (rem == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * GPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * GPW) : "memory");
-            if (p.stamps && kt == 0) st1 = __builtin_amdgcn_s_memrealtime();
-            // the barrier also says every wave finished tile kt-1: its stage is free for tile kt+NSTG-1
-            if (kt + NSTG - 1 < nkt && !(ABL & 1)) issue_tile(kt0 + kt + NSTG - 1, (kt + NSTG - 1) % NSTG);
-        } else if (kt + 1 < nkt && !(ABL & 1) && !late_dma) issue_tile(kt0 + kt + 1, cur ^ 1);
+    // the arithmetic of ONE K tile held in LDS stage `cur` (kt: its index in this block's slice, for the STAGGER experiment)
+    auto compute_tile = [&](const int cur, const int kt) {
         const char* sA = smem + cur * STAGE;
         const char* sB = sA + A_TILE;
         if (MX) {
@@ -427,11 +416,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i].v, b8[j].v, acc[i][j], 1 /* A: e5m2 */, 0 /* B: e4m3 */, 0, sc_a, 0, sc_b);
-            if (!RING) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-            }
-            continue;
+            return;
         }
         half8 a_hi[MT], a_lo[MT], b_hi[NT], b_lo[NT];
         if (ABL & 2) {
@@ -513,7 +498,37 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
             if ((ABL & 8) && ks == 0 && late_dma && kt + 1 < nkt) issue_tile(kt0 + kt + 1, cur ^ 1);
         }
-        if (!RING) {
+    };
+    if (RING) {
+        // Steady state: every step waits for the same number of younger tiles and issues one more - a fixed wait immediate, an
+        // unconditional issue, the stage indices as wrapping counters.  (As ONE loop with the wait count, the issue condition and
+        // kt % NSTG decided per step the control flow alone was ~10 branch instructions per K tile, several of them taken - part
+        // of the 0.12 us a K tile costs with the DMA, the fragment reads and the MFMAs ablated, tools/ring_ablate.py.)  The
+        // last NSTG - 1 tiles (nothing left to issue, fewer tiles outstanding) are peeled.
+        int cur = 0, nxt = NSTG - 1, kt = 0;
+        for (; kt + NSTG - 1 < nkt; ++kt) {
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTG - 2) * GPW) : "memory");      // tile kt landed; every wave finished tile kt-1
+            if (p.stamps && kt == 0) st1 = __builtin_amdgcn_s_memrealtime();
+            if (!(ABL & 1)) issue_tile(kt0 + kt + NSTG - 1, nxt);                                    // into the stage tile kt-1 left
+            compute_tile(cur, kt);
+            cur = cur + 1 == NSTG ? 0 : cur + 1;
+            nxt = nxt + 1 == NSTG ? 0 : nxt + 1;
+        }
+        for (; kt < nkt; ++kt) {
+            const int rem = nkt - 1 - kt;                                  // younger tiles of this wave still outstanding: 0 .. NSTG-2
+            if (rem == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(GPW) : "memory");
+            else if (rem == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * GPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * GPW) : "memory");
+            if (p.stamps && kt == 0) st1 = __builtin_amdgcn_s_memrealtime();
+            compute_tile(cur, kt);
+            cur = cur + 1 == NSTG ? 0 : cur + 1;
+        }
+    } else {
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nkt && !(ABL & 1) && !late_dma) issue_tile(kt0 + kt + 1, cur ^ 1);
+            compute_tile(cur, kt);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
