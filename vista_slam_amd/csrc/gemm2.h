@@ -288,6 +288,9 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
     const size_t a_kstride = (size_t)p.a_rp * A_ES, b_kstride = (size_t)p.N * 64;
 
     int cv_tap = 0, cv_cb = 0;             // conv: (tap, channel block) of the NEXT K tile to be issued (set below, once kt0 is known)
+    // operand bases of the NEXT K tile to be issued (tiles are issued in increasing kt): advanced by one K tile per call instead of
+    // a 64-bit multiply per operand and tile
+    const char* a_run = nullptr; const char* b_run = nullptr;
     auto issue_tile = [&](int kt, int stage) {
         char* sA = smem + stage * STAGE;
         char* sB = sA + A_TILE;
@@ -306,7 +309,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
             if (AMODE == A_DENSE) {
                 unsigned o = a_src[s];
                 asm volatile("" : "+v"(o));      // opaque: keeps the 32-bit offset form (hipcc would hoist base + offset into a VGPR pair)
-                glds16(reinterpret_cast<const char*>(p.A_hi + kt * a_kstride) + o, dst);
+                glds16(a_run + o, dst);
             } else {
                 const unsigned off = (unsigned)(cv_pix0[s] + tap_off) * (unsigned)(A_ES * 2) + cv_coff[s];     // (pixels x 128 B < 2^32: checked by the launcher)
                 const bool ok = (cv_mask[s] >> cv_tap) & 1u;
@@ -319,8 +322,9 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
             if (NSB % NW != 0 && wave + NW * s >= NSB) continue;
             unsigned o = b_src[s];
             asm volatile("" : "+v"(o));
-            glds16(reinterpret_cast<const char*>(p.B_hi + kt * b_kstride) + o, sB + (wave + NW * s) * 1024);
+            glds16(b_run + o, sB + (wave + NW * s) * 1024);
         }
+        a_run += a_kstride * 2; b_run += b_kstride * 2;
     };
 
     floatx16 acc[MT][NT];
@@ -336,6 +340,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
     const int kt0 = (int)((int64_t)kslice * nkt_all / ksplit);
     const int nkt = (int)((int64_t)(kslice + 1) * nkt_all / ksplit) - kt0;
     if (AMODE == A_CONV3) { const int cblocks = p.Cin >> 5; cv_tap = kt0 / cblocks; cv_cb = kt0 - cv_tap * cblocks; }
+    a_run = reinterpret_cast<const char*>(p.A_hi + kt0 * a_kstride); b_run = reinterpret_cast<const char*>(p.B_hi + kt0 * b_kstride);
     constexpr bool RING = NSTG > 2;
     constexpr int GPW = SA + SB;                   // DMA instructions per wave per K tile
     static_assert(!RING || (NSA % NW == 0 && NSB % NW == 0), "ring needs the same DMA count in every wave");
