@@ -471,6 +471,7 @@ struct PoseParams {
     const float* tok; int64_t tok_stride; int D; int Hd;
     const float *w0, *b0, *w1, *b1, *w2, *b2, *wt, *bt, *wr, *br, *wc, *bc;
     float* pose; float* conf;
+    float* pose2; float* conf2; int split;      // samples >= split (when pose2 != nullptr) go to pose2 / conf2, re-indexed from 0
 };
 
 __device__ inline void jacobi_eig3(double A[3][3], double V[3][3]) {
@@ -559,10 +560,11 @@ __global__ __launch_bounds__(256) void pose_final_kernel(const PoseParams p, con
             M[i][0] = a / nrm; M[i][1] = c / nrm; M[i][2] = d / nrm;
         }
         nearest_rotation(M, R);
-        float* o = p.pose + (size_t)b * 16;
+        const bool second = p.pose2 != nullptr && b >= p.split;
+        float* o = second ? p.pose2 + (size_t)(b - p.split) * 16 : p.pose + (size_t)b * 16;
         for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) o[i * 4 + j] = (float)R[i][j]; o[i * 4 + 3] = outv[i]; }
         o[12] = 0.f; o[13] = 0.f; o[14] = 0.f; o[15] = 1.f;
-        p.conf[b] = 1.0f / (1.0f + expf(-outv[12]));
+        (second ? p.conf2 + (b - p.split) : p.conf + b)[0] = 1.0f / (1.0f + expf(-outv[12]));
     }
 }
 

@@ -1328,7 +1328,9 @@ static int decode_impl(sta_handle* h, Bump& ws, const float* feat1, const float*
 }
 
 // ------------------------------------------------------------------------------------------ pose head
-static int pose_impl(sta_handle* h, Bump& ws, const float* tok, int B, int64_t stride, float* pose, float* conf, hipStream_t st) {
+// pose2 / conf2 (optional): the last B - split samples write there (the two sides of a pair: one set of four launches)
+static int pose_impl(sta_handle* h, Bump& ws, const float* tok, int B, int64_t stride, float* pose, float* conf, hipStream_t st,
+                     float* pose2 = nullptr, float* conf2 = nullptr, int split = 0) {
     const int D = h->cfg.dec_embed_dim, Hd = 512;
     float* f0 = (float*)ws.take((int64_t)B * Hd * 4);
     float* f1 = (float*)ws.take((int64_t)B * Hd * 4);
@@ -1338,7 +1340,7 @@ static int pose_impl(sta_handle* h, Bump& ws, const float* tok, int B, int64_t s
     p.tok = tok; p.tok_stride = stride; p.D = D; p.Hd = Hd;
     p.w0 = h->pm0.w; p.b0 = h->pm0.b; p.w1 = h->pm1.w; p.b1 = h->pm1.b; p.w2 = h->pm2.w; p.b2 = h->pm2.b;
     p.wt = h->pt.w; p.bt = h->pt.b; p.wr = h->pr.w; p.br = h->pr.b; p.wc = h->pc.w; p.bc = h->pc.b;
-    p.pose = pose; p.conf = conf;
+    p.pose = pose; p.conf = conf; p.pose2 = pose2; p.conf2 = conf2; p.split = split;
     dim3 grid(Hd / 4, B);
     hipLaunchKernelGGL(pose_layer_kernel, grid, dim3(256), 0, st, tok, stride, p.w0, p.b0, f0, D, Hd, 1);
     hipLaunchKernelGGL(pose_layer_kernel, grid, dim3(256), 0, st, f0, (int64_t)Hd, p.w1, p.b1, f1, Hd, Hd, 1);
@@ -1622,8 +1624,7 @@ static int forward_pair_any(sta_handle* h, const void* img_a, const void* img_b,
         // pose heads read the pose token of the dec_norm'ed last layer (sta_model.py:273,277)
         ws.rewind(mark);
         const float* ptok = hk[2] + (size_t)Ss * N * D;
-        CHK(pose_impl(h, ws, ptok, Bs, (int64_t)D, po[0], pc[0], st));
-        CHK(pose_impl(h, ws, ptok + (size_t)Bs * D, Bs, (int64_t)D, po[1], pc[1], st));
+        CHK(pose_impl(h, ws, ptok, 2 * Bs, (int64_t)D, po[0], pc[0], st, po[1], pc[1], Bs));       // both sides: the 2 Bs pose rows are consecutive
         if (rec) HIPCHK(hipEventRecord(h->ev[3], st));
         ws.rewind(mark);
         CHK(dpt_impl(h, ws, feat, (int64_t)N * E, hk[0], (int64_t)N * D, hk[1], (int64_t)N * D, hk[2], (int64_t)N * D,
