@@ -1247,8 +1247,12 @@ static int decode_impl(sta_handle* h, Bump& ws, const float* feat1, const float*
     { const Planes* z[2] = {&qkv.vt, &cqkv.vt}; CHK(zero_planes(z, 2, hsz, split, st)); }
 
     Planes fp2 = slice_rows(fp, (int64_t)B * N);
-    CHK(run_rows_to_planes(h, feat1, (int64_t)N * E, B, N, E, fp, st));
-    CHK(run_rows_to_planes(h, feat2, (int64_t)N * E, B, N, E, fp2, st));
+    if (feat2 == feat1 + (size_t)B * N * E) {          // both sides in one buffer (sta_forward_pair, the scheduler): one launch
+        CHK(run_rows_to_planes(h, feat1, (int64_t)N * E, 2 * B, N, E, fp, st));
+    } else {
+        CHK(run_rows_to_planes(h, feat1, (int64_t)N * E, B, N, E, fp, st));
+        CHK(run_rows_to_planes(h, feat2, (int64_t)N * E, B, N, E, fp2, st));
+    }
     CHK(gemm_f32(h, fp, h->dec_embed, Mp, x, D, nullptr, st));
     float* xpose = x + (size_t)Mp * D;
     hipLaunchKernelGGL(fill_pose_token_kernel, dim3((S * D + 255) / 256), dim3(256), 0, st, xpose, S, 1, D, h->pose_tok);
