@@ -32,6 +32,9 @@ sys.path.insert(0, ROOT)
 
 H, W_, PAIRS_PER_GPU = 384, 512, 8
 PEAK_F16_MFMA_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+TIMED_EVERY = 4                    # inside the timed region every 4th launch of the dominant kernel symbol carries a HIP-event pair: a pair
+                                   # costs ~9 us of dispatch (tools/probes/boundary_probe.hip: 11.4 vs 2.7 us per launch, profiles/
+                                   # r05_boundary_probe.txt) - on all 36 launches per step that was 0.7 % of `value`
 
 
 def pmc_traffic(kernel_prefix):
@@ -529,7 +532,6 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-slam-probe", action="store_true")
     ap.add_argument("--slam-frames", type=int, default=120, help="frames of the slam_replay section (0 = skip)")
-    ap.add_argument("--gemm-variant", type=int, default=0, help="experiments only: force a GEMM tile family (0 = product selection)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -559,9 +561,6 @@ def main():
     torch.cuda.set_device(local)
 
     model = STAFrontend(Wt.FULL, dev, precision=args.precision).load_procedural(seed=43)      # sta_create(device = LOCAL_RANK)
-    if args.gemm_variant:
-        from vista_slam_amd import _lib
-        _lib.check(model.lib.sta_set_gemm_variant(model._h, args.gemm_variant))
     B = args.pairs
     imgs = Wt.synth_images(2 * B, H, W_, seed=43, tag=rank)          # different pairs on every rank
     img_a = torch.from_numpy(imgs[:B]).to(dev)
@@ -580,14 +579,15 @@ def main():
     if not args.no_kernel_timing:
         # untimed survey step: every GEMM / convolution launch carries an event pair (mode 2) -> per-symbol totals; the
         # symbol with the largest total time is the dominant kernel, and ONLY its launches are timed inside the timed region
-        # (mode 3; an event pair costs ~3.5 us of dispatch, 213 launches per step would cost 3 % of `value`)
+        # (mode 3: a 1-in-TIMED_EVERY sample of them; an event pair costs ~9 us of dispatch)
         model.kernel_timing(2)
         step()
         torch.cuda.synchronize()
         symtab = summarize_gemm_records(model.kernel_timing_records(), args.precision)
         dom = max(symtab.values(), key=lambda g: g["ms"])
         model.kernel_timing(False)
-        model.lib.sta_kernel_timing_filter(model._h, dom["epi"], dom["amode"], dom["fam"], dom["mx"])
+        from vista_slam_amd import _lib
+        _lib.check(model.lib.sta_kernel_timing_filter(model._h, dom["epi"], dom["amode"], dom["fam"], dom["mx"], TIMED_EVERY))
         model.kernel_timing(3)
     dt, step_ms, out = timed_region(runner, args.steps)
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
@@ -615,8 +615,8 @@ def main():
             roof = {"bound": "mfma", "kernel": sym + " - " + ("3x3 convolution, " if g["amode"] else "") + epi_name[g["epi"]],
                     "achieved": round(ach, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "timing": "HIP events recorded by the library around every launch of this kernel on its launch stream, inside the "
-                              "timed region (their cost is part of `value`)",
+                    "timing": f"HIP events recorded by the library around every {TIMED_EVERY}th launch of this kernel on its launch stream, inside "
+                              "the timed region (their cost is part of `value`); `launches` = the timed ones",
                     "algorithmic_bytes_per_launch": int(g["by"] / g["n"]), "gflop_per_launch": round(g["fl"] / g["n"] / 1e9, 2),
                     "launches": g["n"], "avg_launch_us": round(g["ms"] * 1e3 / g["n"], 2),
                     "share_of_gemm_time": round(symtab[sym]["ms"] / tot_ms, 4),

@@ -109,7 +109,17 @@ int sta_set_deterministic(sta_handle* h, int on);
  * the cross-attention K / V under the self-attention) and joins it back before the call's last kernels: the caller sees
  * ordinary stream order.  Same kernels, bit-identical results.
  * (Rounds 2-3 had sta_set_concurrency(h, n): batch slices of ONE forward on library-owned streams.  It stopped paying once
- * the epilogues no longer serialised - -1 % at the headline configuration in round 3 - and was removed in round 4.) */
+ * the epilogues no longer serialised - -1 % at the headline configuration in round 3 - and was removed in round 4.)
+ *
+ * sta_set_side_lanes: the application's switch for those internal side streams.  STA_LANES_AUTO (default): on, EXCEPT while
+ * the application itself overlaps calls on several streams (another scratch context of this handle was used within its last 8
+ * context switches: the chip is then filled across calls and more streams only compete for the runtime's few hardware queues),
+ * and except when GPU_MAX_HW_QUEUES is set in the environment (the lanes are tuned for the runtime's default of 4).
+ * STA_LANES_OFF / STA_LANES_ON make the schedule independent of either.  Results are bit-identical in all three. */
+#define STA_LANES_AUTO (-1)
+#define STA_LANES_OFF 0
+#define STA_LANES_ON 1
+int sta_set_side_lanes(sta_handle* h, int mode);
 
 /* Range report.  Activations travel between kernels as fp16 planes (hi + residual), the f16mx arithmetic of the DPT head adds
  * fp8 correction bytes (activations e5m2, weights e4m3): values beyond +-65504 (or NaN) SATURATE when they are written to a
@@ -266,6 +276,10 @@ int sta_regress_views_begin(sta_handle* h, const float* feat_i, const float* con
 int sta_regress_views_finish(sta_handle* h, const uint8_t* adjacent, float rel_pose_thres,
                              float* pose_conf_host, int* slot_host, int* n_accepted,
                              float* pts, float* conf, float* K, float* depth, void* stream);
+/* Give up a call that was begun on `stream` and will not be finished (a host-side error between the phases): waits for
+ * phase A's confidence copy, clears the pending state, the stream's scratch context is usable again.  Nothing pending on
+ * `stream`: returns 0.  (vista_slam_amd.slam_scheduler.PendingEdges calls it from close() / __del__ / its context manager.) */
+int sta_regress_views_abort(sta_handle* h, void* stream);
 
 /* the compact per-pair record of one step's all-gather (vista_slam_amd/parallel.py; what a SLAM consumer
  * reads of a pair, slam.py:165-185), packed from the outputs of sta_forward_pair* in one launch.  Row b of out_dev
@@ -313,18 +327,16 @@ int sta_kernel_timing_read(sta_handle* h, int tile_family, int* launches, double
  * budget, so the MFMA peak actually available to a kernel is 2.5 PF x clock / 2.4 GHz. */
 int sta_kernel_clock_read(sta_handle* h, float* ghz_out);
 
-/* Time `iters` back-to-back launches of the dominant GEMM kernel (M x N x K, this handle's
- * precision, random operands) with hipEvents on `stream`; average ms per launch in *ms_out.
- * tile: 0 = product selection, 1 = 128x128, 2 = 256x256, 3 = 256x128.  ablation (tile 2/3 only,
- * bench-only kernel variants): 0 none, 1 no DMA in the K loop, 2 DMA+barriers only, 3 MFMA only. */
-int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, int tile, int ablation, float* ms_out, void* stream);
-/* Effective shader clock (GHz) observed inside the kernel of the last sta_bench_gemm call (s_memtime cycles per
- * 100 MHz s_memrealtime tick, sampled on every 64th workgroup): the chip clocks to its power budget (DVFS). */
-float sta_bench_gemm_last_ghz(void);
-/* The attention kernel alone on random operands (tools): ms per launch over `iters` back-to-back launches.  pose != 0: the
- * decoder form (nq == nk patch tokens + the pose token).  which: reserved for kernel variants under test, pass 0. */
-int sta_bench_attention(sta_handle* h, int S, int heads, int nq, int nk, int pose, int iters, int which, float* ms_out, void* stream);
-
+/* Every GEMM / convolution launch after sta_kernel_timing(h, 2) as a record (bench.py's survey step and roofline block;
+ * tools/): shape6 = {M, N, K, epilogue id, A-loader id (0 dense, 1 conv3x3), 1 if the launch ran in the f16mx arithmetic};
+ * variant = tile family (1 = 128x128 register-staged, 2 = 256x256 / 16 waves, 3 = 192x256 / 12 waves, 5 = 192x128 / 8 waves,
+ * 6 = 128x64 small-grid ring, 7 = gemm2_pair_kernel: two 192x128 GEMMs in one launch, 8 = halo-tiled 3x3 convolution). */
+int sta_kernel_timing_dump_shapes(sta_handle* h, int cap, int* shape6, float* ms, int* variant, int* n_out);
+/* Restrict the per-launch timing to ONE kernel symbol {epilogue id, A-loader id, tile family, f16mx flag}; then
+ * sta_kernel_timing(h, 3) times every `every`-th launch of that symbol (bench.py: the dominant kernel inside the timed
+ * region.  An event pair costs ~9 us of dispatch - tools/probes/boundary_probe.hip: 11.4 vs 2.7 us per launch -, so the
+ * timed region samples one launch in four instead of paying that on all 36 per step). */
+int sta_kernel_timing_filter(sta_handle* h, int epilogue, int a_mode, int family, int mx, int every);
 
 const char* sta_last_error(void);
 const char* sta_version(void);

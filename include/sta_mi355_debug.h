@@ -1,7 +1,9 @@
 /*
- * sta_mi355_debug.h - kernel-level TEST entry points of libsta_mi355.so.
+ * sta_mi355_debug.h - kernel-level TEST and micro-benchmark entry points.  They are NOT part of the product ABI: the
+ * product library libsta_mi355.so exports include/sta_mi355.h only; these symbols exist in libsta_mi355_test.so, the same
+ * translation unit compiled with -DSTA_TEST_HOOKS (vista_slam_amd/build.py builds both; tests/ and tools/ load the second).
  *
- * Each function runs exactly one product kernel (the same template instantiation the product path
+ * Each sta_debug_* function runs exactly one product kernel (the same template instantiation the product path
  * launches) on fp32 device tensors so that tests/ can compare it with a plain fp32 reference of the
  * same op (reference ops cited per function).  Nothing in the product path calls these.
  * All pointers are device pointers unless noted; return 0 / negative + sta_last_error().
@@ -87,18 +89,8 @@ int sta_debug_head_final(sta_handle* h, const float* x, const float* w, const fl
 int sta_debug_svd_orthogonalize(sta_handle* h, const float* m, float* r, int B, void* stream);
 
 /* Per-launch record of the timed dominant-kernel family since sta_kernel_timing(h, 1): algorithmic FLOPs, HIP-event
- * duration (ms) and tile family of up to `cap` launches (superseded by sta_kernel_timing_dump_shapes). */
+ * duration (ms) and tile family of up to `cap` launches (superseded by sta_kernel_timing_dump_shapes, sta_mi355.h). */
 int sta_kernel_timing_dump(sta_handle* h, int cap, double* flops, float* ms, int* variant, int* n_out);
-
-/* The same record for EVERY GEMM / convolution launch after sta_kernel_timing(h, 2) (experiments: per-shape in-model
- * durations per tile family, tools/gemm_tiles.py shapes; the roofline block of bench.py): shape6 = {M, N, K, epilogue id,
- * A-loader id (0 dense, 1 conv3x3), 1 if the launch ran in the f16mx arithmetic}; variant = tile family (1 = 128x128
- * register-staged, 2 = 256x256 / 16 waves, 3 = 192x256 / 12 waves, 5 = 192x128 / 8 waves, 6 = 128x64 small-grid ring, 7 = gemm2_pair_kernel: two 192x128 GEMMs in one launch). */
-int sta_kernel_timing_dump_shapes(sta_handle* h, int cap, int* shape6, float* ms, int* variant, int* n_out);
-
-/* Restrict the per-launch timing to ONE kernel symbol {epilogue id, A-loader id, tile family, f16mx flag}; then
- * sta_kernel_timing(h, 3) times only its launches (bench.py: the dominant kernel inside the timed region). */
-int sta_kernel_timing_filter(sta_handle* h, int epilogue, int a_mode, int family, int mx);
 
 /* In-kernel stamps of EVERY GEMM / convolution launch of the calls made since sta_kernel_timing(h, 4) (= mode 2 + stamps; the
  * first 512 launches, 2048 workgroups each): per launch out6 = {workgroups, span, median entry -> first K tile, median main loop,
@@ -112,6 +104,18 @@ int sta_kernel_stamps_dump(sta_handle* h, int cap, double* out6, int* n_out);
  * K slices, median lifetime of a workgroup.  resid == 2: the specialised in-place residual epilogue of the throughput families.
  * raw_host (may be NULL): the four stamps of the first raw_cap workgroups (block id order; block b runs on XCD b % 8). */
 int sta_bench_gemm_stamps(sta_handle* h, int M, int N, int K, int resid, double* out, unsigned long long* raw_host, int raw_cap, void* stream);
+
+/* Time `iters` back-to-back launches of the dominant GEMM kernel (M x N x K, this handle's
+ * precision, random operands) with hipEvents on `stream`; average ms per launch in *ms_out.
+ * tile: 0 = product selection, 1 = 128x128, 2 = 256x256, 3 = 256x128.  ablation (tile 2/3 only,
+ * bench-only kernel variants): 0 none, 1 no DMA in the K loop, 2 DMA+barriers only, 3 MFMA only. */
+int sta_bench_gemm(sta_handle* h, int M, int N, int K, int iters, int tile, int ablation, float* ms_out, void* stream);
+/* Effective shader clock (GHz) observed inside the kernel of the last sta_bench_gemm call (s_memtime cycles per
+ * 100 MHz s_memrealtime tick, sampled on every 64th workgroup): the chip clocks to its power budget (DVFS). */
+float sta_bench_gemm_last_ghz(void);
+/* The attention kernel alone on random operands (tools): ms per launch over `iters` back-to-back launches.  pose != 0: the
+ * decoder form (nq == nk patch tokens + the pose token).  which: reserved for kernel variants under test, pass 0. */
+int sta_bench_attention(sta_handle* h, int S, int heads, int nq, int nk, int pose, int iters, int which, float* ms_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,7 @@ array both files hold (a fixture may gain keys - e.g. the `pos_a` / `pos_b` inte
 array that exists on both sides must not move by one bit).
 
     python oracle/check_oracle_vs_ref.py                       # a quick default selection (~1 min)
-    python oracle/check_oracle_vs_ref.py tiny stress full224   # any case groups of gen_golden.CASES
+    python oracle/check_oracle_vs_ref.py tiny stress full224   # any case groups of gen_golden.CASES / SEQ_CASES (seq, seqfull)
     python oracle/check_oracle_vs_ref.py --update tiny         # additionally copy fixtures that only GAINED keys
 """
 import os
@@ -47,8 +47,8 @@ def main(argv):
     torch.set_num_threads(os.cpu_count())
     bad = 0
     for grp in groups:
-        for c in G.CASES[grp]:
-            G.run_case(**c)
+        for c in (G.CASES.get(grp) or G.SEQ_CASES[grp]):
+            G.run_any(c)
             name = c["name"] + ".npz"
             old, new = os.path.join(GOLDEN, name), os.path.join(scratch, name)
             if not os.path.exists(old):

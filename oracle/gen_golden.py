@@ -349,6 +349,130 @@ def gen_f2(name, cfg, H, W_, nview, sub=1, seed=43, tag=21):
     print(f"[golden] {name}: accepted {acc} thres {thres:.6f} confs {probe} in {time.time() - t0:.1f}s", flush=True)
 
 
+def seq_edge_list(i, neighbor_edge_num, loop_edge_num, loop_dist_min):
+    """Edges of keyframe i in OnlineSLAM.step's order (slam.py:262-277): the <= neighbor_edge_num previous views, then the
+    <= loop_edge_num loop candidates.  The reference's candidates come from `LoopDetector.detect_loop(img_gray,
+    farthest_neighbor)` (DBoW3 on ORB features: a CPU stage, out of scope, absent here); the replay substitutes a deterministic
+    list with the detector's own filter shape - views older than the farthest neighbour and more than `loop_dist_min` keyframes
+    back (configs: 40; the short replays use 3) - ordered by a hash of (i, j) in place of the BoW similarity."""
+    far = max(0, i - neighbor_edge_num)
+    js = list(range(far, i))
+    cand = [j for j in range(far) if i - j > loop_dist_min]
+    cand.sort(key=lambda j: ((i * 7919 + j * 104729 + 13) % 1009, j))
+    return js + cand[:loop_edge_num], far
+
+
+def gen_seq(name, cfg, H, W_, nkf, neighbor_edge_num, loop_edge_num, rel_pose_thres=None, loop_dist_min=3, sub=1, nrand=0,
+            seed=43, tag=31, config_name=""):
+    """A multi-keyframe replay of the FRONTEND calls of `OnlineSLAM.step` (slam.py:244-297) on the reference model with a
+    growing feature cache: per keyframe `add_view` (:142-151: _encode_image(normalize=False), cached), then
+    `connect_view_i_j(i, j)` (:191-241) for the neighbour edges and the loop candidates - `regress_two_views` (:153-189: the
+    four split calls _decode_stereo / head_pose_s / head_pts x 2 + estimate_intrinsic_from_pts3d, early return below
+    `rel_pose_thres` unless adjacent) and, for accepted edges, the node bookkeeping's device arithmetic (:203-218): a node per
+    view with (depth, conf), and for a view that already has a node the scale edge to its FIRST node -
+    estimate_scale_with_depth_and_confidence + the sqrt-mean confidence.  slam.py itself cannot be imported (pypose, cv2,
+    DBoW3Py absent), so the method bodies are replayed statement by statement with the reference's own model methods and
+    slam_utils functions; pypose-only statements (mat2SE3, Sim3 products) are left out, the 4x4 pose is stored.
+
+    rel_pose_thres None -> the 'mid' variant: the widest gap near the median of the non-adjacent confidences (probe pass),
+    so accepted and rejected non-adjacent edges both occur with a margin far above fp32 noise; a number (0.75 = the value of
+    configs/tumrgbd.yaml:46 / 7scenes.yaml:46) is used as it is - with procedural weights every confidence sits near 0.5, so at
+    0.75 only the adjacent edges survive (the exemption of slam.py:169)."""
+    t0 = time.time()
+    su = _ref_slam_utils()
+    sd = W.state_dict(cfg, seed=seed)
+    model = load_reference_model(cfg, sd)
+    # frames: white-noise keyframes (even) and smooth ones (odd) - two input statistics in one sequence
+    noise = W.synth_images(nkf, H, W_, seed=seed, tag=tag)
+    smooth = W.smooth_images(nkf, H, W_, seed=seed, tag=tag)
+    frames = np.stack([noise[k] if k % 2 == 0 else smooth[k] for k in range(nkf)])
+    imgs = torch.from_numpy(frames.copy())
+    ts = torch.tensor([[H, W_]])
+    rng = np.random.RandomState(1000 + seed)
+    rand_idx = np.sort(rng.choice(H * W_, size=nrand, replace=False)) if nrand else None
+
+    def regress_two_views(enc_features, enc_pos, i, j, thres):               # slam.py:153-189
+        dec_feat_ij, dec_feat_ji = model._decode_stereo(enc_features[i], enc_features[j], enc_pos[i], enc_pos[j])
+        pose_ij = model.head_pose_s(dec_feat_ij[-1][:, 0, :])
+        rel_pose_conf_ij = pose_ij["conf"]
+        if rel_pose_conf_ij < thres and i - j != 1:
+            return pose_ij["pose"], rel_pose_conf_ij, None, None, None
+        ji_in = [enc_features[j]] + [tok[:, 1:, :].float() for tok in dec_feat_ji]
+        ij_in = [enc_features[i]] + [tok[:, 1:, :].float() for tok in dec_feat_ij]
+        ji_ret = model.head_pts(ji_in, ts)
+        ij_ret = model.head_pts(ij_in, ts)
+        pcls = torch.cat([ij_ret["pts3d"], ji_ret["pts3d"]], dim=0)
+        confs = torch.cat([ij_ret["conf"], ji_ret["conf"]], dim=0)
+        intri = su.estimate_intrinsic_from_pts3d(pcls, confs, shared_intrinsic=True)
+        return pose_ij["pose"], rel_pose_conf_ij, confs, intri, pcls[..., 2]
+
+    def replay(thres, record):
+        enc_features, enc_pos = [], []
+        first_node = {}                                  # view -> (depth, conf) of its first node (pose_graph_nodes.view_to_node[v][0])
+        res, nonadj, n = {}, [], 0
+        for i in range(nkf):
+            f, p_ = model._encode_image(imgs[i:i + 1], ts, normalize=False)          # add_view (slam.py:142-151)
+            enc_features.append(f); enc_pos.append(p_)
+            js, _far = seq_edge_list(i, neighbor_edge_num, loop_edge_num, loop_dist_min)
+            for j in js:                                                             # connect_view_i_j (slam.py:191-241)
+                pose, c, confs, intri, depths = regress_two_views(enc_features, enc_pos, i, j, thres)
+                if i - j != 1:
+                    nonadj.append(float(c))
+                if record:
+                    res[f"e{n}_ij"] = np.array([i, j], np.int64)
+                    res[f"e{n}_pose"] = pose[0].numpy(); res[f"e{n}_conf"] = np.float32(float(c))
+                    res[f"e{n}_accepted"] = np.array(confs is not None)
+                if confs is not None:
+                    scales = np.full(2, np.nan, np.float32); sconf = np.full(2, np.nan, np.float32)
+                    for k, (v, depth, pcl_conf) in enumerate(zip([i, j], depths, confs)):   # slam.py:203-218
+                        if v in first_node:
+                            depth_other, conf_other = first_node[v]
+                            scales[k] = float(su.estimate_scale_with_depth_and_confidence(depth, depth_other, pcl_conf, conf_other))
+                            sconf[k] = float((pcl_conf * conf_other).sqrt().mean())
+                        else:
+                            first_node[v] = (depth, pcl_conf)
+                    if record:
+                        cn, dn = confs.numpy(), depths.numpy()
+                        res[f"e{n}_confs"] = cn[:, ::sub, ::sub].copy(); res[f"e{n}_depths"] = dn[:, ::sub, ::sub].copy()
+                        if rand_idx is not None:
+                            res[f"e{n}_confs_rand"] = cn.reshape(2, -1)[:, rand_idx].copy()
+                            res[f"e{n}_depths_rand"] = dn.reshape(2, -1)[:, rand_idx].copy()
+                        res[f"e{n}_intri"] = intri.numpy()
+                        res[f"e{n}_confs_l2"] = np.sqrt((confs.double().numpy() ** 2).sum())
+                        res[f"e{n}_depths_l2"] = np.sqrt((depths.double().numpy() ** 2).sum())
+                        res[f"e{n}_scale"] = scales; res[f"e{n}_scale_conf"] = sconf
+                n += 1
+        return res, nonadj, n
+
+    if rel_pose_thres is None:
+        _r, nonadj, _n = replay(-1.0, False)             # probe pass: every confidence, every edge accepted
+        c = np.sort(np.array(nonadj))
+        lo, hi = len(c) // 4, max(len(c) // 4 + 1, 3 * len(c) // 4)
+        gaps = c[lo + 1:hi + 1] - c[lo:hi]
+        g = lo + int(np.argmax(gaps))
+        thres = float(0.5 * (c[g] + c[g + 1]))
+        margin = float(c[g + 1] - c[g]) / 2
+    else:
+        thres, margin = float(rel_pose_thres), None
+    res, nonadj, nedges = replay(thres, True)
+    if margin is None:
+        margin = float(np.min(np.abs(np.array(nonadj) - thres))) if nonadj else 1.0
+    res["thres"] = np.float64(thres); res["thres_margin"] = np.float64(margin)
+    res["n_edges"] = np.int64(nedges)
+    if rand_idx is not None:
+        res["rand_idx"] = rand_idx.astype(np.int64)
+    meta = dict(H=H, W=W_, nkf=nkf, neighbor_edge_num=neighbor_edge_num, loop_edge_num=loop_edge_num, loop_dist_min=loop_dist_min,
+                sub=sub, nrand=nrand, seed=seed, tag=tag)
+    res["meta_keys"] = np.array(list(meta.keys()))
+    res["meta_vals"] = np.array([float(v) for v in meta.values()], dtype=np.float64)
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **res)
+    acc = [bool(res[f"e{n}_accepted"]) for n in range(nedges)]
+    print(f"[golden] {name} ({config_name}): {nkf} keyframes, {nedges} edges, {sum(acc)} accepted, thres {thres:.6f} (margin {margin:.2e}), "
+          f"{os.path.getsize(path) / 1e6:.2f} MB in {time.time() - t0:.1f}s", flush=True)
+
+
 CASES = {
     "tiny": [
         dict(name="tiny_32x32_b1", cfg=W.TINY, H=32, W_=32, B=1, taps=True),
@@ -403,6 +527,30 @@ CASES = {
     ],
 }
 
+# Multi-keyframe replays of OnlineSLAM.step's frontend calls in the edge regimes of the reference's configs (BASELINE configs[2-3]):
+# configs/tumrgbd.yaml:26,29 = 3 neighbour + <= 2 loop edges; configs/7scenes.yaml:26,29 = 2 + 3.  `_t075`: the yamls' own
+# rel_pose_thres (0.75, :46); the others: a mid threshold so that accepted AND rejected non-adjacent edges occur.
+SEQ_CASES = {
+    "seq": [
+        dict(name="seq_tum_tiny_48x64", cfg=W.TINY, H=48, W_=64, nkf=10, neighbor_edge_num=3, loop_edge_num=2, sub=2, config_name="tumrgbd.yaml regime"),
+        dict(name="seq_7scenes_tiny_48x64", cfg=W.TINY, H=48, W_=64, nkf=10, neighbor_edge_num=2, loop_edge_num=3, sub=2, tag=32, config_name="7scenes.yaml regime"),
+        dict(name="seq_tum_tiny_48x64_t075", cfg=W.TINY, H=48, W_=64, nkf=8, neighbor_edge_num=3, loop_edge_num=2, rel_pose_thres=0.75, sub=4, config_name="tumrgbd.yaml regime, rel_pose_thres 0.75"),
+    ],
+    "seqfull": [
+        dict(name="seq_tum_full_224", cfg=W.FULL, H=224, W_=224, nkf=8, neighbor_edge_num=3, loop_edge_num=2, sub=16, nrand=512, config_name="tumrgbd.yaml regime"),
+        dict(name="seq_7scenes_full_224", cfg=W.FULL, H=224, W_=224, nkf=8, neighbor_edge_num=2, loop_edge_num=3, sub=16, nrand=512, tag=32, config_name="7scenes.yaml regime"),
+    ],
+}
+
+
+def run_any(c):
+    """One case of CASES (forward goldens) or SEQ_CASES (keyframe sequences): used by check_oracle_vs_ref.py."""
+    if "nkf" in c:
+        gen_seq(**c)
+    else:
+        run_case(**c)
+
+
 if __name__ == "__main__":
     sel = sys.argv[1:] or ["ops", "post", "tiny", "full224", "full512"]
     torch.set_num_threads(os.cpu_count())
@@ -418,6 +566,9 @@ if __name__ == "__main__":
             gen_f2("f2_full_224", W.FULL, 224, 224, nview=4, sub=8)
         elif s == "f2portrait":
             gen_f2("f2_tiny_80x48_portrait", W.TINY, 80, 48, nview=4, tag=22)
+        elif s in SEQ_CASES:
+            for c in SEQ_CASES[s]:
+                gen_seq(**c)
         else:
             for c in CASES[s]:
                 run_case(**c)

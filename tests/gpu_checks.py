@@ -25,12 +25,14 @@ def st():
     return torch.cuda.current_stream().cuda_stream
 
 
-def model(cfg_name="tiny", qk_gain=1.0, precision="f16x3", seed=43, outlier=0):
-    """Cached frontends (weights are procedural, so (cfg, gain, seed, outlier level) identifies them)."""
-    key = (cfg_name, qk_gain, seed, outlier)
+def model(cfg_name="tiny", qk_gain=1.0, precision="f16x3", seed=43, outlier=0, hooks=False):
+    """Cached frontends (weights are procedural, so (cfg, gain, seed, outlier level) identifies them).  hooks=False: the PRODUCT
+    library libsta_mi355.so (what every golden / parity test runs); hooks=True: the test-hooks build libsta_mi355_test.so (same
+    translation unit + the kernel-level entry points and experiment switches of include/sta_mi355_debug.h)."""
+    key = (cfg_name, qk_gain, seed, outlier, bool(hooks))
     if key not in _models:
         cfg = W.TINY if cfg_name == "tiny" else W.FULL
-        m = STAFrontend(cfg, DEV, precision=precision)
+        m = STAFrontend(cfg, DEV, precision=precision, lib=_lib.load_test() if hooks else None)
         m.load_procedural(seed=seed, qk_gain=qk_gain, outlier=outlier)
         _models[key] = m
     m = _models[key]
@@ -46,13 +48,21 @@ def drop_models():
 def kernel_handle(precision, variant=0):
     """precision "head_mx": the DPT head's arithmetic of the default policy (f16 main product + one block-scaled fp8 correction
     MFMA on f16mx rows) in the kernels that have it: the debug GEMM (plane epilogue), conv3x3, ConvT, bilinear."""
-    m = model("tiny", 1.0, "f16x3h" if precision == "head_mx" else precision)
+    m = model("tiny", 1.0, "f16x3h" if precision == "head_mx" else precision, hooks=True)
     _lib.check(m.lib.sta_set_gemm_variant(m._h, variant))
     _lib.check(m.lib.sta_debug_set_option(m._h, 4, 1 if precision == "head_mx" else 0))
     return m, m.lib, m._h
 
 
+def has_hooks(m):
+    return hasattr(m.lib, "sta_set_gemm_variant")
+
+
 def set_variant(m, variant):
+    """Force a GEMM tile family (test-hooks build only).  On a product-library frontend only `0` (= what it always does) is legal."""
+    if not has_hooks(m):
+        assert variant == 0, "forced tile families need a frontend on the test-hooks library (model(..., hooks=True))"
+        return
     _lib.check(m.lib.sta_set_gemm_variant(m._h, variant))
 
 
@@ -320,7 +330,7 @@ def run_golden_case(name, precision, taps=True, variant=0):
     """HIP forward on the procedural inputs of a golden case; returns {key: rel-L2 error}."""
     g, meta = load_golden(name)
     cfg_name = "tiny" if int(meta["cfg_enc_embed_dim"]) == W.TINY.enc_embed_dim else "full"
-    m = model(cfg_name, float(meta["qk_gain"]), precision, int(meta["seed"]), int(meta.get("outlier", 0)))
+    m = model(cfg_name, float(meta["qk_gain"]), precision, int(meta["seed"]), int(meta.get("outlier", 0)), hooks=variant != 0)
     set_variant(m, variant)
     cfg = m.cfg
     m.range_report(reset=True)

@@ -8,24 +8,38 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    names = set()
-    for hdr in ("sta_mi355.h", "sta_mi355_debug.h"):
-        src = open(os.path.join(ROOT, "include", hdr)).read()
-        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-        names |= set(re.findall(r"\b(sta_[a-z0-9_]+)\s*\(", src))
-    return names
+def declared_symbols(hdr):
+    src = open(os.path.join(ROOT, "include", hdr)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return set(re.findall(r"\b(sta_[a-z0-9_]+)\s*\(", src))
+
+
+def exported_symbols(path):
+    """Dynamic symbols `sta_*` of a built library (nm -D; no GPU, nothing is called)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("sta_")}
 
 
 def test_library_builds_and_exports_every_declared_symbol():
+    """The product library exports EXACTLY include/sta_mi355.h; the test-hooks build additionally include/sta_mi355_debug.h;
+    the ctypes tables mirror the two headers one for one."""
     from vista_slam_amd import build, _lib
     build.build_lib()
+    prod, dbg = declared_symbols("sta_mi355.h"), declared_symbols("sta_mi355_debug.h")
+    assert prod and dbg and not (prod & dbg), (prod & dbg)
+    assert prod == set(_lib.SIGNATURES), (prod ^ set(_lib.SIGNATURES))
+    assert dbg == set(_lib.TEST_SIGNATURES), (dbg ^ set(_lib.TEST_SIGNATURES))
+    assert exported_symbols(_lib.LIB_PATH) == prod, (exported_symbols(_lib.LIB_PATH) ^ prod)          # no test hooks in the product ABI
+    assert exported_symbols(_lib.TEST_LIB_PATH) == prod | dbg, (exported_symbols(_lib.TEST_LIB_PATH) ^ (prod | dbg))
     lib = _lib.load()
-    decl = declared_symbols()
-    assert decl, "no declarations parsed"
-    assert decl == set(_lib.SIGNATURES), (decl ^ set(_lib.SIGNATURES))
-    for name in decl:
-        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+    for name in prod:
+        assert hasattr(lib, name), f"{name} declared in include/sta_mi355.h but not exported"
+    for name in dbg:
+        assert not hasattr(lib, name), f"{name} is a test hook but the product library exports it"
+    tlib = _lib.load_test()
+    for name in prod | dbg:
+        assert hasattr(tlib, name), f"{name} missing from libsta_mi355_test.so"
     assert b"gfx950" in lib.sta_version()
 
 

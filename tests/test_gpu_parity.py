@@ -197,7 +197,7 @@ def test_integer_positions_bit_exact(G):
 def test_curope_compat_module_vs_reference_rope_golden(G):
     """vista_slam_amd.curope_compat.cuRoPE2D - the class the reference's import switch (pos_embed.py:106-108) would pick up -
     against the reference RoPE2D vectors of ops.npz (incl. position -1), on the strided q / k views the attention layer hands
-    it (sta_blocks.py:132-137: (B,H,N,D) views of the (B,N,3,H,D) qkv tensor), forward and backward (curope2d.py:24-29)."""
+    it (sta_blocks.py:132-137: (B,H,N,D) views of the (B,N,3,H,D) qkv tensor), forward and inverse rotation."""
     import numpy as np
     import torch
     import vista_slam_amd.curope_compat as cc
@@ -215,12 +215,16 @@ def test_curope_compat_module_vs_reference_rope_golden(G):
     assert out.data_ptr() == k.data_ptr()                         # in place, returns its argument (curope2d.py:38-40)
     assert max_rel(out.cpu().numpy(), g["rope_out"]) < 2e-6
     assert float(qkv[:, :, 0].abs().max()) == 0.0 and float(qkv[:, :, 2].abs().max()) == 0.0     # q / v slots untouched
-    # autograd: the backward is the inverse rotation of the incoming gradient
-    t = torch.from_numpy(g["rope_tok"]).cuda().permute(0, 2, 1, 3).contiguous().requires_grad_(True)      # (B,N,H,D): the kernel's layout
-    y = cc.cuRoPE2D_func.apply(t * 1.0, pos, 100.0, 1.0)
-    gy = torch.from_numpy(g["rope_out"]).cuda().permute(0, 2, 1, 3).contiguous()
-    (y * gy).sum().backward()
-    assert max_rel(t.grad.cpu().numpy(), t.detach().cpu().numpy()) < 5e-6      # R^T (R t) = t
+    # the inverse rotation (fwd = -F0: what the reference's backward applies to the gradient, curope2d.py:24-29) undoes the forward
+    t = torch.from_numpy(g["rope_tok"]).cuda().permute(0, 2, 1, 3).contiguous()      # (B,N,H,D): the kernel's layout
+    y = t.clone()
+    cc.rope_2d(y, pos, 100.0, 1.0)
+    assert max_rel(y.permute(0, 2, 1, 3).cpu().numpy(), g["rope_out"]) < 2e-6
+    cc.rope_2d(y, pos, 100.0, -1.0)
+    assert max_rel(y.cpu().numpy(), t.cpu().numpy()) < 5e-6                           # R^T (R t) = t
+    # inference-only: a tensor that requires grad is refused loudly (no silent gradient drop)
+    with pytest.raises(RuntimeError):
+        rope(torch.zeros(1, 1, 2, 4, device="cuda", requires_grad=True), torch.zeros(1, 2, 2, dtype=torch.int64, device="cuda"))
     # the module-level function has the extension's signature (curope.cpp:49-65) and refuses CPU tensors loudly
     with pytest.raises(RuntimeError):
         cc.rope_2d(torch.zeros(1, 1, 1, 4), torch.zeros(1, 1, 2, dtype=torch.int64), 100.0, 1.0)
@@ -491,8 +495,9 @@ def test_calls_on_two_streams_overlap_safely(G, prec):
 @pytest.mark.parametrize("prec", [DEFAULT, "f16x3"])
 def test_dpt_side_lane_is_bit_identical(G, prec):
     """dpt_impl's side lane (the branch kernels of the DPT head on an internal second stream, SLAM-scale calls only) runs the
-    same kernels with the same split-K slices as the one-lane order: outputs bit for bit equal with the lane switched off
-    (sta_debug_set_option 6 = 1), for forward_pair and for a scheduler call, repeatedly (races would show as flakiness)."""
+    same kernels with the same split-K slices as the one-lane order: outputs bit for bit equal with the lanes switched off
+    (sta_set_side_lanes: the application's switch), for forward_pair and for a scheduler call, repeatedly (races would show as
+    flakiness)."""
     import torch
     from vista_slam_amd import weights as W, _lib
     from vista_slam_amd.slam_scheduler import regress_views
@@ -502,13 +507,13 @@ def test_dpt_side_lane_is_bit_identical(G, prec):
     imgs = torch.from_numpy(W.synth_images(6, H, Wd, seed=43, tag=23)).cuda()
     feats = [m._encode_image(imgs[v:v + 1], None, normalize=False)[0] for v in range(4)]
     try:
-        _lib.check(m.lib.sta_debug_set_option(m._h, 6, 1))
+        m.set_side_lanes("off")
         ref = m.forward_pair(imgs[4:5], imgs[5:6])
         ref_pts, ref_conf = ref[0]["pts3d_pred"].clone(), ref[1]["conf"].clone()
         ref_e = regress_views(m, feats[3], feats[:3], [False, False, True], -1.0, H, Wd)
         ref_d = [r.depths.clone() for r in ref_e]
         torch.cuda.synchronize()
-        _lib.check(m.lib.sta_debug_set_option(m._h, 6, 0))
+        m.set_side_lanes("on")
         for it in range(5):
             out = m.forward_pair(imgs[4:5], imgs[5:6])
             e = regress_views(m, feats[3], feats[:3], [False, False, True], -1.0, H, Wd)
@@ -517,7 +522,7 @@ def test_dpt_side_lane_is_bit_identical(G, prec):
             for r, d in zip(e, ref_d):
                 assert torch.equal(r.depths, d), f"scheduler differs with the side lane (iteration {it})"
     finally:
-        _lib.check(m.lib.sta_debug_set_option(m._h, 6, 0))
+        m.set_side_lanes("auto")
     assert m.range_report() == (0, 0)
 
 

@@ -59,9 +59,9 @@ def test_picked_family_is_current_and_within_3_percent_of_best():
     """(Needs the built library - pick_family is a host function inside it - but no GPU.  When the cost-model constants are
     retuned the table must be re-measured with tools/tile_table.py on an MI355X and committed; `stale` below says so.)"""
     from vista_slam_amd import _lib
-    if not os.path.exists(_lib.LIB_PATH):
+    if not os.path.exists(_lib.TEST_LIB_PATH):
         pytest.skip("libsta_mi355.so not built here (python -m vista_slam_amd.build)")
-    lib = _lib.load()
+    lib = _lib.load_test()          # sta_debug_pick_family lives in the test-hooks build (include/sta_mi355_debug.h)
     stale, slow = [], []
     for x in rows():
         if x["fam"] == 7:

@@ -1,6 +1,6 @@
 """Same-process, same-box A/B of two builds of the library on the benchmark workload (8 pairs @512x384):
     python tools/ab_inproc.py [other.so] [precision] [rounds]
-NEW = vista_slam_amd/libsta_mi355.so, OLD = vista_slam_amd/libsta_old.so by default (kept out of git); AB_B / AB_H / AB_W in the
+NEW = vista_slam_amd/libsta_mi355.so, OLD = tools/ab/libsta_old.so by default (kept out of git); AB_B / AB_H / AB_W in the
 environment change the workload (e.g. AB_B=2, or AB_H=224 AB_W=224).  The two frontends
 live side by side (own weights, own workspace) and alternate, so box drift hits both arms equally."""
 import os, sys, time
@@ -9,7 +9,7 @@ import torch
 from vista_slam_amd import weights as W, _lib
 from vista_slam_amd.sta_frontend import STAFrontend
 
-other = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "vista_slam_amd", "libsta_old.so")
+other = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tools", "ab", "libsta_old.so")
 prec = sys.argv[2] if len(sys.argv) > 2 else "f16x3h"
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 B, H, Wd = (int(os.environ.get(k, d)) for k, d in (("AB_B", 8), ("AB_H", 384), ("AB_W", 512)))      # workload: env AB_B / AB_H / AB_W

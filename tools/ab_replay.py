@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import torch
 import bench
 from vista_slam_amd import weights as W, _lib
+from vista_slam_amd import _lib as _hooks_lib; _hooks_lib.use_test_hooks()      # tools use the test-hooks build (include/sta_mi355_debug.h)
 from vista_slam_amd.sta_frontend import STAFrontend
 
 args = sys.argv[1:]

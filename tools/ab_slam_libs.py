@@ -1,6 +1,6 @@
 """Same-process, same-box A/B of two builds of the library at SLAM scale (224x224, batch 1 encode; 5-edge scheduler call):
     python tools/ab_slam_libs.py [other.so] [rounds]
-NEW = vista_slam_amd/libsta_mi355.so, OLD = vista_slam_amd/libsta_old.so by default; the two frontends alternate."""
+NEW = vista_slam_amd/libsta_mi355.so, OLD = tools/ab/libsta_old.so by default; the two frontends alternate."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
@@ -8,7 +8,7 @@ from vista_slam_amd import weights as W, _lib
 from vista_slam_amd.sta_frontend import STAFrontend
 from vista_slam_amd.slam_scheduler import regress_views
 
-other = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "vista_slam_amd", "libsta_old.so")
+other = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tools", "ab", "libsta_old.so")
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 new = STAFrontend(W.FULL, "cuda:0").load_procedural(seed=43)
 prod = _lib._lib

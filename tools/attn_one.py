@@ -4,6 +4,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 from vista_slam_amd import weights as W, _lib
+from vista_slam_amd import _lib as _hooks_lib; _hooks_lib.use_test_hooks()      # tools use the test-hooks build (include/sta_mi355_debug.h)
 from vista_slam_amd.sta_frontend import STAFrontend
 a = [int(x) for x in sys.argv[1:]]
 S, heads, nq, nk, iters = (a + [16, 16, 768, 768, 10][len(a):])[:5]

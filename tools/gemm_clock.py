@@ -3,6 +3,7 @@ In-kernel probe: s_memtime cycles per constant-100-MHz s_memrealtime tick (sta_b
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from vista_slam_amd import weights as W
+from vista_slam_amd import _lib as _hooks_lib; _hooks_lib.use_test_hooks()      # tools use the test-hooks build (include/sta_mi355_debug.h)
 from vista_slam_amd.sta_frontend import STAFrontend
 m = STAFrontend(W.TINY, "cuda:0", precision="f16x3").load_procedural()
 NAMES = {0: "full", 1: "noDMA", 2: "noLDS", 3: "MFMA only", 4: "noMFMA", 5: "LDS only", 6: "DMA only", 7: "barriers only"}

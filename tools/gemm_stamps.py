@@ -4,6 +4,7 @@ import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 from vista_slam_amd import weights as W, _lib
+from vista_slam_amd import _lib as _hooks_lib; _hooks_lib.use_test_hooks()      # tools use the test-hooks build (include/sta_mi355_debug.h)
 from vista_slam_amd.sta_frontend import STAFrontend
 m = STAFrontend(W.TINY, "cuda:0", precision="f16x3").load_procedural()
 st = torch.cuda.current_stream().cuda_stream

@@ -4,6 +4,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 from vista_slam_amd import weights as W, _lib
+from vista_slam_amd import _lib as _hooks_lib; _hooks_lib.use_test_hooks()      # tools use the test-hooks build (include/sta_mi355_debug.h)
 from vista_slam_amd.sta_frontend import STAFrontend
 cfgs = [(c.split(":")[0], int(c.split(":")[1]), (c.split(":") + [""])[2]) for c in (sys.argv[1:] or ["f16x3h:0", "f16x3:0"])]   # precision:forced tile family[:ENVVAR to set]
 m = STAFrontend(W.FULL, "cuda:0", precision="f16x3").load_procedural(seed=43)

@@ -5,6 +5,7 @@ import collections, ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 from vista_slam_amd import weights as W, _lib
+from vista_slam_amd import _lib as _hooks_lib; _hooks_lib.use_test_hooks()      # tools use the test-hooks build (include/sta_mi355_debug.h)
 from vista_slam_amd.sta_frontend import STAFrontend
 B, H, Wd = (int(os.environ.get(k, d)) for k, d in (("AB_B", 8), ("AB_H", 384), ("AB_W", 512)))
 m = STAFrontend(W.FULL, "cuda:0").load_procedural(seed=43)

@@ -5,7 +5,7 @@ from vista_slam_amd import _lib, weights as W
 from vista_slam_amd.sta_frontend import STAFrontend
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 outs = {}
-for tag, path in (("new", None), ("old", os.path.join(R, "vista_slam_amd", "libsta_old.so"))):
+for tag, path in (("new", None), ("old", os.path.join(R, "tools", "ab", "libsta_old.so"))):
     prod = _lib._lib if _lib._lib is not None else _lib.load()
     if path: _lib._lib = _lib.load_other(path)
     m = STAFrontend(W.TINY, "cuda:0", precision="f16x3h").load_procedural()

@@ -6,6 +6,7 @@ import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 from vista_slam_amd import weights as W, _lib
+from vista_slam_amd import _lib as _hooks_lib; _hooks_lib.use_test_hooks()      # tools use the test-hooks build (include/sta_mi355_debug.h)
 from vista_slam_amd.sta_frontend import STAFrontend
 NAMES = {0: "full", 1: "no DMA", 2: "no LDS reads", 4: "no MFMA", 6: "DMA only", 7: "barriers only", 3: "MFMA only", 5: "LDS reads only"}
 SHAPES = ((196, 3072, 1024, 0), (196, 1024, 1024, 1), (196, 1024, 4096, 1), (392, 1024, 4096, 1), (1970, 768, 3072, 1))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-box A/B of two library builds at the SLAM scale (B = 1 @224x224 split entry points + 5-edge scheduler):
-# NEW = vista_slam_amd/libsta_mi355.so, OLD = vista_slam_amd/libsta_old.so.
+# NEW = vista_slam_amd/libsta_mi355.so, OLD = tools/ab/libsta_old.so.
 set -u
 cd "$(dirname "$0")/.."
 run() { timeout 200 python - <<'PY'
@@ -17,7 +17,7 @@ PY
 }
 cp vista_slam_amd/libsta_mi355.so /tmp/new.so
 echo NEW; run 2>&1 | tail -1
-cp vista_slam_amd/libsta_old.so vista_slam_amd/libsta_mi355.so
+cp tools/ab/libsta_old.so vista_slam_amd/libsta_mi355.so
 echo OLD; run 2>&1 | tail -1
 cp /tmp/new.so vista_slam_amd/libsta_mi355.so
 echo NEW; run 2>&1 | tail -1

@@ -2,6 +2,7 @@
 ragged M) and reference goldens, for each variant id given on the command line."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from vista_slam_amd import _lib as _hooks_lib; _hooks_lib.use_test_hooks()      # tools use the test-hooks build (include/sta_mi355_debug.h)
 import gpu_checks as G
 variants = [int(x) for x in sys.argv[1:]] or [10, 11, 12]
 for v in variants:

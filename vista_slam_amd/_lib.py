@@ -2,12 +2,18 @@
 
 There is NO fallback: if the HIP library is missing or fails to load, importing the product path
 raises.  (The CPU oracle under oracle/ is test infrastructure and is never imported from here.)
+
+Two builds of the same translation unit (vista_slam_amd/build.py): `load()` = libsta_mi355.so, the product, which exports
+include/sta_mi355.h and nothing else; `load_test()` = libsta_mi355_test.so (-DSTA_TEST_HOOKS), which additionally exports the
+kernel-level test / micro-benchmark entry points of include/sta_mi355_debug.h.  Only tests/ and tools/ load the second one
+(`STAFrontend(..., lib=_lib.load_test())`, or `_lib.use_test_hooks()` at the top of a tool).
 """
 import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libsta_mi355.so")
+TEST_LIB_PATH = os.path.join(PKG, "libsta_mi355_test.so")
 
 STA_PREC_F16 = 1
 STA_PREC_F16X3 = 3
@@ -25,13 +31,14 @@ class StaConfig(C.Structure):
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _fp = C.c_void_p   # device float* passed as integer address
 
-# name -> (restype, argtypes); mirrors include/sta_mi355.h and include/sta_mi355_debug.h
+# name -> (restype, argtypes); mirrors include/sta_mi355.h (the product ABI)
 SIGNATURES = {
     "sta_default_config": (None, [C.POINTER(StaConfig)]),
     "sta_create": (_i, [C.POINTER(StaConfig), _i, C.POINTER(_vp)]),
     "sta_destroy": (_i, [_vp]),
     "sta_set_precision": (_i, [_vp, _i]),
     "sta_set_deterministic": (_i, [_vp, _i]),
+    "sta_set_side_lanes": (_i, [_vp, _i]),
     "sta_num_expected_tensors": (_i, [_vp]),
     "sta_num_loaded_tensors": (_i, [_vp]),
     "sta_load_tensor": (_i, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i, _i]),
@@ -56,8 +63,7 @@ SIGNATURES = {
                                C.POINTER(_i), C.POINTER(_i), _fp, _fp, _fp, _fp, _vp]),
     "sta_regress_views_begin": (_i, [_vp, _fp, C.POINTER(_vp), _i, _i, _i, _fp, _vp]),
     "sta_regress_views_finish": (_i, [_vp, C.c_char_p, _f, C.POINTER(C.c_float), C.POINTER(_i), C.POINTER(_i), _fp, _fp, _fp, _fp, _vp]),
-    "sta_kernel_stamps_dump": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(_i)]),
-    "sta_bench_gemm_stamps": (_i, [_vp, _i, _i, _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong), _i, _vp]),
+    "sta_regress_views_abort": (_i, [_vp, _vp]),
     "sta_pack_compact": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _fp, _i64, _vp]),
     "sta_rope2d_inplace": (_i, [_fp, _i64, _i64, _vp, _i, _i, _i, _i, _f, _f, _vp]),
     "sta_rope2d_inplace_dtype": (_i, [_vp, _i, _i64, _i64, _vp, _i, _i, _i, _i, _f, _f, _vp]),
@@ -69,17 +75,22 @@ SIGNATURES = {
     "sta_kernel_timing": (_i, [_vp, _i]),
     "sta_kernel_timing_read": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sta_kernel_clock_read": (_i, [_vp, C.POINTER(C.c_float)]),
-    "sta_bench_gemm": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(_f), _vp]),
-    "sta_bench_gemm_last_ghz": (C.c_float, []),
+    "sta_kernel_timing_filter": (_i, [_vp, _i, _i, _i, _i, _i]),
+    "sta_kernel_timing_dump_shapes": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(C.c_float), C.POINTER(_i), C.POINTER(_i)]),
     "sta_range_report": (_i, [_vp, C.POINTER(C.c_ulonglong), _i]),
-    "sta_bench_attention": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_f), _vp]),
     "sta_last_error": (C.c_char_p, []),
     "sta_version": (C.c_char_p, []),
-    # ---- debug / kernel-level test entry points
+}
+
+# include/sta_mi355_debug.h: kernel-level test / micro-benchmark entry points, exported by libsta_mi355_test.so only
+TEST_SIGNATURES = {
     "sta_set_gemm_variant": (_i, [_vp, _i]),
     "sta_kernel_timing_dump": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(_i), C.POINTER(_i)]),
-    "sta_kernel_timing_filter": (_i, [_vp, _i, _i, _i, _i]),
-    "sta_kernel_timing_dump_shapes": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(C.c_float), C.POINTER(_i), C.POINTER(_i)]),
+    "sta_kernel_stamps_dump": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(_i)]),
+    "sta_bench_gemm_stamps": (_i, [_vp, _i, _i, _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong), _i, _vp]),
+    "sta_bench_gemm": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(_f), _vp]),
+    "sta_bench_gemm_last_ghz": (C.c_float, []),
+    "sta_bench_attention": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_f), _vp]),
     "sta_debug_gemm": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _vp]),
     "sta_debug_qkv_rope": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _vp]),
     "sta_debug_attention": (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _vp]),
@@ -96,10 +107,28 @@ SIGNATURES = {
 }
 
 _lib = None
+_test_lib = None
 
 
 class StaError(RuntimeError):
     pass
+
+
+_last_called = None      # the library object of the most recent C call: sta_last_error() is per library (two builds may be loaded)
+
+
+def _bind(lib, table, strict):
+    def note(result, _func, _args):
+        global _last_called
+        _last_called = lib
+        return result
+    for name, (res, args) in table.items():
+        fn = getattr(lib, name, None) if not strict else getattr(lib, name)    # strict: AttributeError if the .so does not export it
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
+            if name != "sta_last_error":
+                fn.errcheck = note
 
 
 def load_other(path):
@@ -107,37 +136,59 @@ def load_other(path):
     the symbols that build exports; never used by the product path."""
     import torch  # noqa: F401
     lib = C.CDLL(path)
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name, None)
-        if fn is not None:
-            fn.restype = res
-            fn.argtypes = args
+    _bind(lib, SIGNATURES, strict=False)
+    _bind(lib, TEST_SIGNATURES, strict=False)
     return lib
 
 
+def _missing(path):
+    return StaError(f"{path} not found: the MI355X STA frontend has no CPU fallback. "
+                    "Build it with `python -m vista_slam_amd.build` (needs hipcc) or `__graft_entry__.build()`.")
+
+
 def load():
-    """Load libsta_mi355.so and bind every exported symbol; raises if the library is absent."""
+    """Load libsta_mi355.so (the product library) and bind every symbol of include/sta_mi355.h; raises if it is absent."""
     global _lib
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise StaError(
-            f"{LIB_PATH} not found: the MI355X STA frontend has no CPU fallback. "
-            "Build it with `python -m vista_slam_amd.build` (needs hipcc) or `__graft_entry__.build()`.")
+        raise _missing(LIB_PATH)
     # torch must be imported BEFORE the library: the ROCm wheel bundles its own libamdhip64 and the
     # process must end up with exactly one HIP runtime (loading /opt/rocm's first makes the second
     # initialisation fail with "no ROCm-capable device is detected").
     import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)          # AttributeError if the .so does not export it
-        fn.restype = res
-        fn.argtypes = args
+    _bind(lib, SIGNATURES, strict=True)
     _lib = lib
     return lib
 
 
+def load_test():
+    """Load libsta_mi355_test.so: the product ABI plus the kernel-level test / micro-benchmark entry points
+    (include/sta_mi355_debug.h).  tests/ and tools/ only."""
+    global _test_lib
+    if _test_lib is not None:
+        return _test_lib
+    if not os.path.exists(TEST_LIB_PATH):
+        raise _missing(TEST_LIB_PATH)
+    import torch  # noqa: F401
+    lib = C.CDLL(TEST_LIB_PATH)
+    _bind(lib, SIGNATURES, strict=True)
+    _bind(lib, TEST_SIGNATURES, strict=True)
+    _test_lib = lib
+    return lib
+
+
+def use_test_hooks():
+    """tools/: make the test-hooks build THIS process's default library, so that every STAFrontend() created afterwards has the
+    sta_debug_* / sta_bench_* entry points.  Never called by the product path."""
+    global _lib
+    _lib = load_test()
+    return _lib
+
+
 def check(rc):
     if rc != 0:
-        msg = load().sta_last_error()
+        lib = _last_called or _lib or _test_lib or load()
+        msg = lib.sta_last_error()
         raise StaError((msg or b"unknown error").decode())

@@ -1,6 +1,9 @@
-"""Build the gfx950 C-ABI library in-tree with hipcc (no torch, no cmake).
+"""Build the gfx950 C-ABI libraries in-tree with hipcc (no torch, no cmake).
 
-    python -m vista_slam_amd.build          # -> vista_slam_amd/libsta_mi355.so
+    python -m vista_slam_amd.build          # -> vista_slam_amd/libsta_mi355.so        the product: exports include/sta_mi355.h only
+                                            #    vista_slam_amd/libsta_mi355_test.so   the same translation unit + -DSTA_TEST_HOOKS:
+                                            #    additionally the kernel-level test / micro-benchmark entry points of
+                                            #    include/sta_mi355_debug.h (loaded by tests/ and tools/ only)
 """
 import os
 import shutil
@@ -10,6 +13,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libsta_mi355.so")
+TEST_LIB = os.path.join(PKG, "libsta_mi355_test.so")
 SOURCES = ["sta_api.hip"]
 DEPS = ["sta_api.hip", "sta_debug.inc", "sta_rows.inc", "sta_bench.inc", "gemm.h", "gemm2.h", "conv3h.h", "attention.h", "elementwise.h", "sta_common.h",
         os.path.join("..", "..", "include", "sta_mi355.h"), os.path.join("..", "..", "include", "sta_mi355_debug.h")]
@@ -23,6 +27,7 @@ def hipcc_path():
 
 
 HASH_FILE = LIB + ".srchash"
+TEST_HASH_FILE = TEST_LIB + ".srchash"
 
 
 def extra_flags():
@@ -48,26 +53,42 @@ def source_hash():
     return h.hexdigest()
 
 
-def is_stale():
-    if not os.path.exists(LIB) or not os.path.exists(HASH_FILE):
+def is_stale(lib=LIB, hash_file=HASH_FILE):
+    if not os.path.exists(lib) or not os.path.exists(hash_file):
         return True
-    with open(HASH_FILE) as f:
+    with open(hash_file) as f:
         return f.read().strip() != source_hash()
 
 
-def build_lib(force=False, verbose=True):
-    if not force and not is_stale():
+def _cmd(hipcc, out, hooks):
+    return ([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-o", out] + extra_flags() +
+            (["-DSTA_TEST_HOOKS"] if hooks else []) + [os.path.join(CSRC, s) for s in SOURCES])
+
+
+def build_lib(force=False, verbose=True, test_hooks=True):
+    """Build the product library and (test_hooks) the test-hooks library; both compile concurrently (one hipcc process each,
+    ~100 s).  Returns the product library's path."""
+    jobs = []
+    if force or is_stale(LIB, HASH_FILE):
+        jobs.append((LIB, HASH_FILE, False))
+    if test_hooks and (force or is_stale(TEST_LIB, TEST_HASH_FILE)):
+        jobs.append((TEST_LIB, TEST_HASH_FILE, True))
+    if not jobs:
         return LIB
     hipcc = hipcc_path()
     if hipcc is None:
         raise RuntimeError("hipcc not found: cannot build libsta_mi355.so (ROCm toolchain required)")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-o", LIB] + extra_flags() + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print("[build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=CSRC)
-    with open(HASH_FILE, "w") as f:
-        f.write(source_hash())
+    procs = []
+    for out, _hf, hooks in jobs:
+        cmd = _cmd(hipcc, out, hooks)
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        procs.append((subprocess.Popen(cmd, cwd=CSRC), cmd))
+    for (p, cmd), (out, hf, _hooks) in zip(procs, jobs):
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+        with open(hf, "w") as f:
+            f.write(source_hash())
     return LIB
 
 

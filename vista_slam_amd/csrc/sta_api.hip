@@ -137,11 +137,14 @@ struct sta_handle {
     unsigned long long* clk_buf = nullptr;   // {shader cycles, 100 MHz ticks} summed over sampled workgroups of the timed GEMMs
     bool ktime = false; std::vector<hipEvent_t> kev; int kn = 0; std::vector<double> kflops, kbytes; std::vector<int> kvar;
     int kfilter[4] = {-1, -1, -1, -1};    // mode 3: {epilogue, A-loader, tile family, mx} of the one kernel symbol that is timed
+    int kevery = 1, kseen = 0;            // mode 3: every kevery-th matching launch carries the event pair (an event pair costs ~9 us of
+                                          // dispatch, tools/probes/boundary_probe.hip: 11.4 vs 2.7 us per launch)
     bool ktime_all = false; std::vector<int> kshape;   // sta_kernel_timing(h, 2): every GEMM / conv launch is timed; {M, N, K, EPI, AMODE, mx} per record
     unsigned long long* kstamp = nullptr; bool kstamp_on = false;   // sta_kernel_timing(h, 4): mode 2 + in-kernel stamps (GemmParams::stamps) of every launch, KSTAMP_WG workgroups x 4 per record
     // f3 input-step tables (one cached geometry)
     int pre_key[6] = {0, 0, 0, 0, 0, 0}; int* pre_tab = nullptr; int64_t pre_cap = 0; int pre_meta[12] = {0};
     bool dry = false;   // planning pass: run the orchestration without launching to size the workspace
+    int lanes_mode = STA_LANES_AUTO;   // sta_set_side_lanes
     int lane = 0;       // 1 while dpt_impl enqueues on the context's side stream (launch_gemm then hands out the side lane's split-K scratch)
 };
 
@@ -199,6 +202,9 @@ static int stream_ctx(sta_handle* h, hipStream_t st) {
 static int ensure_ws(sta_handle* h, int64_t bytes, hipStream_t st) {
     CHK(stream_ctx(h, st));
     StreamCtx& c = *h->cur;
+    // every path that takes this stream's workspace comes through here (plan_and_run, the kernel-level test entry points):
+    // phase B of a pending scheduler call still reads what phase A left in it
+    REQUIRE(!c.rv_open, "a scheduler call begun with sta_regress_views_begin is pending on this stream: finish (or abort) it before the next call on the same stream");
     if (bytes <= c.ws_cap) return 0;
     HIPCHK(hipDeviceSynchronize());
     if (c.ws) HIPCHK(hipFree(c.ws));
@@ -229,10 +235,10 @@ static Bump cur_bump(sta_handle* h) { return Bump{h->cur->ws, h->cur->ws_cap}; }
 // side lane of the current context (created on first use: one stream, 16 MiB of split-K scratch, four events)
 static int ensure_side(sta_handle* h) {
     StreamCtx& c = *h->cur;
-    if (c.side) return 0;
-    HIPCHK(hipMalloc((void**)&c.side_skbuf, (size_t)SKBUF_ELEMS * 4));
-    for (auto& e : c.side_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIPCHK(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+    // every resource on its own: a failure half way leaves what exists in place for the next attempt (nothing is leaked twice)
+    if (!c.side_skbuf) HIPCHK(hipMalloc((void**)&c.side_skbuf, (size_t)SKBUF_ELEMS * 4));
+    for (auto& e : c.side_ev) if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (!c.side) HIPCHK(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
     return 0;
 }
 static inline float* lane_skbuf(sta_handle* h) { return h->lane ? h->cur->side_skbuf : h->cur->skbuf; }
@@ -465,12 +471,19 @@ extern "C" int sta_set_deterministic(sta_handle* h, int on) {
     h->deterministic = on != 0;
     return 0;
 }
+extern "C" int sta_set_side_lanes(sta_handle* h, int mode) {
+    REQUIRE(h && (mode == STA_LANES_AUTO || mode == STA_LANES_OFF || mode == STA_LANES_ON), "sta_set_side_lanes: bad argument");
+    h->lanes_mode = mode;
+    return 0;
+}
+#ifdef STA_TEST_HOOKS      // libsta_mi355_test.so only (include/sta_mi355_debug.h)
 extern "C" int sta_set_gemm_variant(sta_handle* h, int variant) {
     REQUIRE(h && ((variant >= 0 && variant <= 4) || (variant >= 8 && variant <= 11)), "bad gemm variant");
     h->small_grid_mode = variant == 10 ? 1 : (variant == 11 ? 2 : 0);     // measurement tool only; per handle
     h->gemm_variant = variant >= 10 ? 0 : variant;
     return 0;
 }
+#endif
 extern "C" int sta_range_report(sta_handle* h, unsigned long long counts[2], int reset) {
     REQUIRE(h && counts, "null argument");
     DEV_SCOPE(h->device);
@@ -649,10 +662,12 @@ static int pick_family(const FamilyQuery& q) {
     }
     return best;
 }
+#ifdef STA_TEST_HOOKS
 extern "C" int sta_debug_pick_family(int amode, int epi, long long M, int N, int K, int split, int cstride, int Ho, int Wo) {
     FamilyQuery q{amode, epi, M, N, K, split, cstride, Ho, Wo, 0};
     return pick_family(q);
 }
+#endif
 
 // slab_ks_out: K slices a slab GEMM wrote (0: it did not take the slab path) - the caller's finisher sums exactly those
 template <int AMODE, int EPI>
@@ -754,7 +769,8 @@ static int launch_gemm(sta_handle* h, const GemmParams& p_in, hipStream_t st, in
     // per-launch HIP-event timing (bench / tools): every launch (mode 2), or only the launches of ONE kernel symbol
     // (mode 3, sta_kernel_timing_filter: the event pairs break back-to-back dispatch, ~3.5 us each, so the timed region of
     // bench.py carries them on the dominant kernel only)
-    const bool timed = h->ktime && (h->ktime_all || (h->kfilter[0] == EPI && h->kfilter[1] == AMODE && h->kfilter[2] == variant && h->kfilter[3] == p.mx));
+    bool timed = h->ktime && (h->ktime_all || (h->kfilter[0] == EPI && h->kfilter[1] == AMODE && h->kfilter[2] == variant && h->kfilter[3] == p.mx));
+    if (timed && !h->ktime_all && (h->kseen++ % h->kevery) != 0) timed = false;      // mode 3: a 1-in-kevery sample of the symbol's launches
     if (timed) {
         if ((int)h->kev.size() < 2 * (h->kn + 1)) {
             hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
@@ -945,15 +961,19 @@ static bool qkv_pair_one_launch(const sta_handle* h, const GemmParams& pa, const
     auto big = [h](const GemmParams& p) { return p.N % 128 == 0 && !small_grid(h, p.M, p.N); };
     return h->prec != STA_PREC_F16 && !pa.mx && !pb.mx && big(pa) && big(pb) && pa.K == pb.K && pa.M == pb.M && auto_family(h);
 }
-// side lane of the current context (dpt_impl, decode_impl): usable unless switched off or a whole-model timing mode wants one stream
-// - and unless the application is already overlapping calls on several streams (another context used within the last few
-// calls): the chip is then filled across calls, and more streams than hardware queues make independent streams share a queue
-// and serialise (bench.py slam_replay, three caller streams: 229 keyframes/s without side lanes, 189 with them).
+// Side lanes of the current context (dpt_impl, decode_impl): inside one call the library forks an internal second stream for the
+// launches that are off the call's critical chain.  sta_set_side_lanes(h, mode) is the application's switch (include/sta_mi355.h):
+//   STA_LANES_OFF / STA_LANES_ON: what they say (results are bit-identical either way);
+//   STA_LANES_AUTO (default): on, unless the application itself is overlapping calls on several streams - another scratch context
+//     of this handle was used within its last 8 context switches - because the chip is then filled ACROSS calls and the extra
+//     internal streams only compete for the runtime's few hardware queues (bench.py slam_replay, three caller streams: 229
+//     keyframes/s without side lanes, 189 with them); and off when GPU_MAX_HW_QUEUES is set in the environment (measured with 8:
+//     every fork / join between streams on different hardware queues cost ~0.4 ms; the lanes are tuned for the runtime default).
+// The whole-model timing modes (stage timing, per-launch timing of every GEMM, stamps) always run one lane.
 static bool lanes_on(const sta_handle* h) {
-    if (h->dry || h->opt[6] == 1 || h->timing || h->ktime_all || h->kstamp_on) return false;     // (the one-kernel timing mode of bench.py stays on the product path: its event pairs sit on each launch's own stream)
-    if (h->opt[6] == 2) return true;          // experiments: always
-    // measured with GPU_MAX_HW_QUEUES=8 in the environment (default: 4): every fork / join between streams on different hardware
-    // queues cost ~0.4 ms (single-stream slam_replay 143 -> 53 keyframes/s) - the lanes are tuned for the runtime's default only
+    if (h->dry || h->timing || h->ktime_all || h->kstamp_on) return false;     // (the one-kernel timing mode of bench.py stays on the product path: its event pairs sit on each launch's own stream)
+    if (h->lanes_mode == STA_LANES_OFF || h->opt[6] == 1) return false;
+    if (h->lanes_mode == STA_LANES_ON || h->opt[6] == 2) return true;
     static const bool queues_overridden = getenv("GPU_MAX_HW_QUEUES") != nullptr;
     if (queues_overridden) return false;
     for (const auto& c : h->ctx) if (&c != h->cur && c.last_use + 8 > h->use_clock) return false;
@@ -984,7 +1004,8 @@ static int gemm_qkv_pair(sta_handle* h, const GemmParams& pa_in, const GemmParam
                              !small_grid(h, pa.M - h->tail_hint, pa.N) && !small_grid(h, pb.M - h->tail_hint, pb.N)) ? h->tail_hint : 0;
     const int ta = ((pa.M - pa.m_tail + 191) / 192) * (pa.N / 128) + (pa.m_tail ? pa.N / 32 : 0);
     const int tb = ((pb.M - pb.m_tail + 191) / 192) * (pb.N / 128) + (pb.m_tail ? pb.N / 32 : 0);
-    const bool timed = h->ktime && (h->ktime_all || (h->kfilter[0] == EPI_QKV && h->kfilter[1] == A_DENSE && h->kfilter[2] == 7 && h->kfilter[3] == 0));
+    bool timed = h->ktime && (h->ktime_all || (h->kfilter[0] == EPI_QKV && h->kfilter[1] == A_DENSE && h->kfilter[2] == 7 && h->kfilter[3] == 0));
+    if (timed && !h->ktime_all && (h->kseen++ % h->kevery) != 0) timed = false;
     if (timed) {      // one record: M x (Na + Nb) x K, tile family id 7 = gemm2_pair_kernel
         if ((int)h->kev.size() < 2 * (h->kn + 1)) {
             hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
@@ -1666,12 +1687,14 @@ extern "C" int sta_kernel_timing(sta_handle* h, int enable) {
     }
     h->kstamp_on = enable == 4;
     h->ktime = enable != 0; h->ktime_all = enable == 2 || enable == 4; h->kn = 0;
-    if (enable != 3) h->kfilter[0] = h->kfilter[1] = h->kfilter[2] = h->kfilter[3] = -1;
+    if (enable != 3) { h->kfilter[0] = h->kfilter[1] = h->kfilter[2] = h->kfilter[3] = -1; h->kevery = 1; }
+    h->kseen = 0;
     return 0;
 }
-extern "C" int sta_kernel_timing_filter(sta_handle* h, int epilogue, int a_mode, int family, int mx) {
-    REQUIRE(h, "null handle");
+extern "C" int sta_kernel_timing_filter(sta_handle* h, int epilogue, int a_mode, int family, int mx, int every) {
+    REQUIRE(h && every >= 1, "sta_kernel_timing_filter: null handle or every < 1");
     h->kfilter[0] = epilogue; h->kfilter[1] = a_mode; h->kfilter[2] = family; h->kfilter[3] = mx;
+    h->kevery = every; h->kseen = 0;
     return 0;
 }
 extern "C" int sta_kernel_clock_read(sta_handle* h, float* ghz_out) {
@@ -1700,6 +1723,7 @@ extern "C" int sta_kernel_timing_read(sta_handle* h, int variant, int* launches,
     return 0;
 }
 
+#ifdef STA_TEST_HOOKS
 extern "C" int sta_kernel_timing_dump(sta_handle* h, int cap, double* flops, float* ms, int* variant, int* n_out) {
     REQUIRE(h && flops && ms && variant && n_out, "null argument");
     DEV_SCOPE(h->device);
@@ -1712,6 +1736,7 @@ extern "C" int sta_kernel_timing_dump(sta_handle* h, int cap, double* flops, flo
     *n_out = n;
     return 0;
 }
+#endif
 
 extern "C" int sta_kernel_timing_dump_shapes(sta_handle* h, int cap, int* shape6, float* ms, int* variant, int* n_out) {
     REQUIRE(h && shape6 && ms && variant && n_out, "null argument");
@@ -1727,6 +1752,7 @@ extern "C" int sta_kernel_timing_dump_shapes(sta_handle* h, int cap, int* shape6
     return 0;
 }
 
+#ifdef STA_TEST_HOOKS
 // In-kernel stamps of the launches recorded since sta_kernel_timing(h, 4): per launch out6 = {workgroups, span us, median entry ->
 // first K tile, median main loop, median epilogue, spread of the exits} (100-MHz stamps of every workgroup, GemmParams::stamps).
 extern "C" int sta_kernel_stamps_dump(sta_handle* h, int cap, double* out6, int* n_out) {
@@ -1753,6 +1779,7 @@ extern "C" int sta_kernel_stamps_dump(sta_handle* h, int cap, double* out6, int*
     *n_out = n;
     return 0;
 }
+#endif
 
 extern "C" int sta_enable_stage_timing(sta_handle* h, int on) { REQUIRE(h, "null handle"); h->timing = on != 0; return 0; }
 extern "C" int sta_get_stage_ms(sta_handle* h, float ms[4]) {
@@ -1781,6 +1808,8 @@ extern "C" int sta_rope2d_inplace(float* tokens_dev, int64_t stride_b, int64_t s
     return sta_rope2d_inplace_dtype(tokens_dev, STA_DTYPE_F32, stride_b, stride_n, pos_dev, B, N, Hh, D, base, fwd, stream);
 }
 
-#include "sta_bench.inc"    // FLOP model + GEMM micro-benchmark entry points
+#include "sta_bench.inc"    // FLOP model (product) + GEMM / attention micro-benchmark entry points (STA_TEST_HOOKS)
 
-#include "sta_debug.inc"
+#ifdef STA_TEST_HOOKS
+#include "sta_debug.inc"   // kernel-level test entry points: libsta_mi355_test.so only
+#endif

@@ -1,24 +1,20 @@
-"""`cuRoPE2D`-shaped drop-in over the HIP rope kernel (`sta_rope2d_inplace_dtype`).
+"""Inference-only stand-in for the reference's `curope` package over the HIP rope kernel (`sta_rope2d_inplace_dtype`).
 
-The reference picks its rotary embedding with an import switch (pos_embed/pos_embed.py:106-108):
+The reference selects its rotary embedding at import time (pos_embed/pos_embed.py:106-108): if `from .curope import cuRoPE2D`
+succeeds, `RoPE2D = cuRoPE2D`, otherwise a slow PyTorch class.  Two names are interface there:
 
-    try:
-        from .curope import cuRoPE2D
-        RoPE2D = cuRoPE2D
-    except ImportError: ...   # slow pytorch version
+  * the module class `cuRoPE2D(freq, F0)` with `forward(tokens (B,H,N,D), positions (B,N,2)) -> tokens`, rotating IN PLACE
+    (the attention layers hand it strided views of the qkv tensor, sta_blocks.py:132-137), and
+  * the compiled extension's one function `rope_2d(tokens (B,N,H,D), positions, base, fwd)` (curope.cpp:49-65).
 
-`.curope` is the package pos_embed/curope/__init__.py, which exports `cuRoPE2D` from curope2d.py:32-40; that module
-wraps the compiled extension's one function `rope_2d(tokens, positions, base, fwd)` (curope.cpp:49-65).  This file
-mirrors those three names one for one, so either of these makes the reference use the gfx950 kernel unchanged:
+Both are provided here, so either of these makes the reference's own PyTorch layers run the gfx950 kernel:
 
-  * point the switch at it:   `from vista_slam_amd.curope_compat import cuRoPE2D`   (one-line edit of pos_embed.py:107), or
-  * leave pos_embed.py alone and install this module AS the extension the wrapper imports (curope2d.py:6-9):
-        import sys, vista_slam_amd.curope_compat as cc; sys.modules["curope"] = cc
-    (`import curope as _kernels` then resolves to `cc`, whose `rope_2d` has the extension's signature).
+    from vista_slam_amd.curope_compat import cuRoPE2D                    # one-line edit of pos_embed.py:107
+    import sys, vista_slam_amd.curope_compat as cc; sys.modules["curope"] = cc      # or no edit: be the extension (curope2d.py:6-9)
 
-Same contract as the CUDA kernel (kernels.cu:84-108): tokens (B, N, H, D) with stride(3) == 1 and stride(2) == D (the
-transposed view of the attention layer's (B, H, N, D) q / k), positions (B, N, 2) int64 contiguous, fp16 / fp32 / fp64
-tokens, rotation evaluated in fp32, IN PLACE; `fwd = -F0` is the backward pass (curope2d.py:24-29).
+Kernel contract (kernels.cu:84-108): tokens with stride(3) == 1 and stride(2) == D, int64 contiguous positions, fp16 / fp32 /
+fp64 storage, rotation evaluated in fp32.  This frontend is inference-only (training is out of scope): there
+is no autograd wrapper; calling the module on tensors that require grad raises instead of silently dropping the gradient.
 """
 import torch
 
@@ -26,41 +22,24 @@ from .sta_frontend import rope2d_inplace
 
 
 def rope_2d(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: float) -> None:
-    """curope.rope_2d (curope.cpp:49-65).  GPU tensors only: this library has no CPU path (the reference's rope_2d_cpu,
-    curope.cpp:21-47, is restated only in the test infrastructure, as the checker)."""
+    """Signature of the extension function (curope.cpp:49-65); `fwd < 0` applies the inverse rotation.  GPU tensors only:
+    the library has no CPU path (the reference's CPU loop, curope.cpp:21-47, is restated only in the test oracle)."""
     if not tokens.is_cuda:
         raise RuntimeError("vista_slam_amd.curope_compat.rope_2d: CPU tensors are not served (no CPU path in this library)")
     rope2d_inplace(tokens, positions, float(base), float(fwd))
 
 
-class cuRoPE2D_func(torch.autograd.Function):
-    """curope2d.py:12-29: in-place rotation forward, inverse rotation of the incoming gradient backward."""
-
-    @staticmethod
-    def forward(ctx, tokens, positions, base, F0=1):
-        ctx.save_for_backward(positions)
-        ctx.saved_base = base
-        ctx.saved_F0 = F0
-        rope_2d(tokens, positions, base, F0)
-        ctx.mark_dirty(tokens)
-        return tokens
-
-    @staticmethod
-    def backward(ctx, grad_res):
-        positions, base, F0 = ctx.saved_tensors[0], ctx.saved_base, ctx.saved_F0
-        rope_2d(grad_res, positions, base, -F0)
-        ctx.mark_dirty(grad_res)
-        return grad_res, None, None, None
-
-
 class cuRoPE2D(torch.nn.Module):
-    """curope2d.py:32-40: `forward(tokens (B,H,N,D), positions (B,N,2))` rotates `tokens` in place and returns it."""
+    """`RoPE2D` drop-in for inference: rotates the (B,H,N,D) view it is given in place and returns that same tensor."""
 
-    def __init__(self, freq=100.0, F0=1.0):
+    def __init__(self, freq: float = 100.0, F0: float = 1.0):
         super().__init__()
-        self.base = freq
-        self.F0 = F0
+        self.base, self.F0 = float(freq), float(F0)
 
-    def forward(self, tokens, positions):
-        cuRoPE2D_func.apply(tokens.transpose(1, 2), positions, self.base, self.F0)
+    @torch.no_grad()
+    def forward(self, tokens: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
+        if tokens.requires_grad:
+            raise RuntimeError("vista_slam_amd.curope_compat.cuRoPE2D is inference-only (no backward pass); run under torch.no_grad()")
+        # the kernel walks (B, N, H, D); the layer's (B, H, N, D) view transposed is exactly that, with no copy
+        rope_2d(tokens.transpose(1, 2), positions, self.base, self.F0)
         return tokens

@@ -31,15 +31,32 @@ def pack_compact(main: Dict[str, torch.Tensor], supp: Dict[str, torch.Tensor], m
     With `model` (an STAFrontend) and contiguous GPU outputs the record is written by ONE kernel (sta_pack_compact),
     straight into `out` when given (e.g. the send buffer of the step's all-gather); otherwise a torch.cat of the slices."""
     pts = main["pts3d_pred"]
-    if model is not None and pts.is_cuda and all(o[k].is_contiguous() for o in (main, supp)
-                                                for k in ("pts3d_pred", "conf", "relative_pose", "relative_pose_conf")):
+    keys = ("pts3d_pred", "conf", "relative_pose", "relative_pose_conf")
+
+    def fast_ok():
+        """The one-kernel path reads raw fp32 device pointers: every input (and `out`) must be fp32, contiguous, on the same GPU
+        and of the expected shape - anything else takes the torch path below, which converts or rejects it."""
+        if model is None or not pts.is_cuda or pts.dim() != 4:
+            return False
+        B, H, W = pts.shape[0], pts.shape[1], pts.shape[2]
+        want = {"pts3d_pred": (B, H, W, 3), "conf": (B, H, W), "relative_pose": (B, 4, 4), "relative_pose_conf": (B,)}
+        for o in (main, supp):
+            for k in keys:
+                t = o[k]
+                if t.dtype != torch.float32 or t.device != pts.device or not t.is_contiguous() or tuple(t.shape) != want[k]:
+                    return False
+        if out is not None and (out.dtype != torch.float32 or out.device != pts.device or out.dim() != 2):
+            return False
+        return True
+
+    if fast_ok():
         import ctypes as C
         from . import _lib
         B, H, W = pts.shape[0], pts.shape[1], pts.shape[2]
         if out is None:
             out = torch.empty(B, compact_elems_per_pair(H, W), device=pts.device, dtype=torch.float32)
         assert out.shape[0] == B and out.stride(1) == 1 and out.shape[1] == compact_elems_per_pair(H, W)
-        arr = [(C.c_void_p * 2)(main[k].data_ptr(), supp[k].data_ptr()) for k in ("pts3d_pred", "conf", "relative_pose", "relative_pose_conf")]
+        arr = [(C.c_void_p * 2)(main[k].data_ptr(), supp[k].data_ptr()) for k in keys]
         _lib.check(model.lib.sta_pack_compact(model._h, arr[0], arr[1], arr[2], arr[3], B, H, W, out.data_ptr(), out.stride(0),
                                               torch.cuda.current_stream(pts.device).cuda_stream))
         return out
@@ -48,7 +65,7 @@ def pack_compact(main: Dict[str, torch.Tensor], supp: Dict[str, torch.Tensor], m
         B = o["relative_pose"].shape[0]
         parts += [o["relative_pose"].reshape(B, 16), o["relative_pose_conf"].reshape(B, 1),
                   o["pts3d_pred"][..., 2].reshape(B, -1), o["conf"].reshape(B, -1)]
-    res = torch.cat(parts, dim=1).contiguous()
+    res = torch.cat([p.float() for p in parts], dim=1).contiguous()
     if out is not None:
         out.copy_(res)
         return out

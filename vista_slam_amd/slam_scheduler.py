@@ -35,8 +35,31 @@ class EdgeResult:
 
 class PendingEdges:
     """A scheduler call between its two phases (sta_regress_views_begin / _finish): the output tensors, the inputs kept
-    alive, and the stream the call lives on."""
-    __slots__ = ("k", "H", "W", "stream", "pose", "pts", "conf", "K", "depth", "_keep")
+    alive, and the stream the call lives on.  While it is open its stream's scratch context inside the library is reserved;
+    `regress_views_finish` closes it, and so does `close()` / leaving a `with` block / garbage collection (an exception between
+    the phases must not leave the stream unusable: sta_regress_views_abort)."""
+    __slots__ = ("k", "H", "W", "stream", "pose", "pts", "conf", "K", "depth", "_keep", "_frontend", "_open")
+
+    def close(self):
+        """Abort the call if it is still pending (idempotent)."""
+        if getattr(self, "_open", False):
+            self._open = False
+            fe = self._frontend
+            if getattr(fe, "_h", None):
+                fe.lib.sta_regress_views_abort(fe._h, self.stream)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *_exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def regress_views_begin(frontend: STAFrontend, enc_feat_i: torch.Tensor, enc_feats_j: Sequence[torch.Tensor], H: int, W: int) -> PendingEdges:
@@ -60,7 +83,9 @@ def regress_views_begin(frontend: STAFrontend, enc_feat_i: torch.Tensor, enc_fea
     p.K = torch.empty(k, 3, 3, device=dev, dtype=torch.float32)
     p.depth = torch.empty(k, 2, H, W, device=dev, dtype=torch.float32)
     p._keep = (fi, fj)
+    p._frontend, p._open = frontend, False
     _lib.check(frontend.lib.sta_regress_views_begin(frontend._h, fi.data_ptr(), ptrs, k, H, W, p.pose.data_ptr(), p.stream))
+    p._open = True
     return p
 
 
@@ -73,6 +98,8 @@ def regress_views_finish(frontend: STAFrontend, p: PendingEdges, adjacent: Seque
     pconf = (C.c_float * k)()
     slot = (C.c_int * k)()
     nacc = C.c_int(0)
+    assert p._open, "this scheduler call was already finished or aborted"
+    p._open = False                 # the C call closes the pending state whether it succeeds or not
     _lib.check(frontend.lib.sta_regress_views_finish(frontend._h, adj, float(rel_pose_thres), pconf, slot, C.byref(nacc),
                                                      p.pts.data_ptr(), p.conf.data_ptr(), p.K.data_ptr(), p.depth.data_ptr(), p.stream))
     pts, conf, depth = p.pts, p.conf, p.depth

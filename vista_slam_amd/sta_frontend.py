@@ -29,8 +29,10 @@ def _stream_ptr(device=None) -> int:
 
 class STAFrontend:
     def __init__(self, cfg: W.STAConfig = W.FULL, device: str | torch.device = "cuda:0",
-                 precision: str = "f16x3h", img_size=(224, 224)):
-        self.lib = _lib.load()
+                 precision: str = "f16x3h", img_size=(224, 224), lib=None):
+        """`lib`: tests / tools only - another build of the library (`_lib.load_test()`: the test-hooks build with the
+        kernel-level entry points of include/sta_mi355_debug.h); the product path never passes it."""
+        self.lib = lib if lib is not None else _lib.load()
         if not torch.cuda.is_available():
             raise _lib.StaError("STAFrontend needs a ROCm GPU (MI355X / gfx950); there is no CPU fallback")
         self.cfg = cfg
@@ -112,6 +114,11 @@ class STAFrontend:
     def set_deterministic(self, on: bool = True):
         """Bit-reproducible results (no split-K fp32 atomics at SLAM scale; include/sta_mi355.h)."""
         _lib.check(self.lib.sta_set_deterministic(self._h, int(on)))
+
+    def set_side_lanes(self, mode: str = "auto"):
+        """The library's internal side streams (include/sta_mi355.h, sta_set_side_lanes): "auto" (default: on unless the
+        application overlaps calls on several streams itself), "off", "on".  Results are bit-identical in all three."""
+        _lib.check(self.lib.sta_set_side_lanes(self._h, {"auto": -1, "off": 0, "on": 1}[mode]))
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state: Dict[str, "torch.Tensor | np.ndarray"], strict: bool = True):
@@ -386,6 +393,7 @@ class STAFrontend:
         return [tuple(sh[6 * i + q] for q in range(6)) + (var[i], float(ms[i])) for i in range(n.value)]
 
     def bench_gemm(self, M: int, N: int, K: int, iters: int = 20, tile: int = 0, ablation: int = 0) -> float:
+        """tools/ only: needs the test-hooks build (`STAFrontend(..., lib=_lib.load_test())`); the product library does not export it."""
         ms = C.c_float()
         _lib.check(self.lib.sta_bench_gemm(self._h, M, N, K, iters, tile, ablation, C.byref(ms), self._stream()))
         return float(ms.value)
