@@ -131,8 +131,6 @@ def slam_replay(model, dev, frames=120, warm=12, res=(224, 224), src_hw=(480, 64
     import torch
     from vista_slam_amd import weights as Wt
     from vista_slam_amd.preprocess import process_image
-    from vista_slam_amd.slam_scheduler import regress_views_begin, regress_views_finish
-    from vista_slam_amd.post import estimate_scale_with_depth_and_confidence
     from vista_slam_amd.formats import world_pointcloud
     Hs, Ws = src_hw
     Wr, Hr = res
@@ -140,31 +138,35 @@ def slam_replay(model, dev, frames=120, warm=12, res=(224, 224), src_hw=(480, 64
     distinct = [torch.from_numpy(Wt.synth_frames_u8(Hs, Ws, seed=43, tag=t)).to(dev) for t in range(16)]
     raw = [distinct[f % 16] for f in range(n_all)]                      # frames resident in HBM (16 distinct ones, cycled)
     torch.cuda.synchronize()
-    main_stream = torch.cuda.current_stream(dev)
-    calib = None
-    pool = None
+    # the three lanes run on streams the LIBRARY hands out after measuring that they overlap pairwise (sta_pipeline_streams; round 4
+    # timed its warm-up on four triples of torch streams and kept the best: 188 vs 231 keyframes/s depending on which streams share
+    # a hardware queue).  `streams` overrides them (tools/queue_probe.py).
+    placement = {"source": "caller"}
     if streams is None:
-        pool = [torch.cuda.Stream(device=dev) for _ in range(6)]
-        streams = pool[:3]
+        streams = model.pipeline_streams(3)
+        placement = {"source": "sta_pipeline_streams (library-owned, pairwise overlap measured by a spin probe)",
+                     "verified_concurrent": model.pipeline_streams_verified}
     enc_stream, edge_streams = streams[0], list(streams[1:3])
 
     def run(nf, thres, pipelined):
-        feats, rgbs, first = [], [], {}          # encoder feature cache; normalised frames; first node of every view: (depth, conf, K)
+        from vista_slam_amd.keyframe_pipeline import replay
+        rgbs = []
         poses = {0: torch.eye(4, device=dev)}
-        ev = {k: [] for k in ("f3", "encode", "edges_decode", "edges_heads", "f1")}
-        stats = {"edges": 0, "rejected": 0, "scale_edges": 0, "nonadj_conf": []}
+        ev = {k: [] for k in ("f3", "encode", "edges_decode", "edges_heads", "bookkeeping")}
+        stats = {"edges": 0, "rejected": 0, "nonadj_conf": []}
 
         def mark():
             e = torch.cuda.Event(enable_timing=True); e.record(); return e
 
-        def add_view(i):                        # f3 + encode of frame i on the CURRENT stream -> (feat, rgb, done event)
+        def add_view(i):                        # f3 + encode of frame i on the CURRENT stream (slam.py:142-151)
             t0 = mark()
             pre = process_image(model, raw[i], resolution=(Wr, Hr))
             t1 = mark()
-            feat, _pos = model.encode_u8hwc(pre["u8"][None])
+            feat, pos = model.encode_u8hwc(pre["u8"][None])
             t2 = mark()
             ev["f3"].append((t0, t1)); ev["encode"].append((t1, t2))
-            return feat, pre["rgb"], t2
+            rgbs.append(pre["rgb"])
+            return feat, pos
 
         def edge_list(i):                       # neighbours (slam.py:262-265), then loop candidates among the older views (:273-277)
             far = max(0, i - neighbor_edge_num)
@@ -173,74 +175,20 @@ def slam_replay(model, dev, frames=120, warm=12, res=(224, 224), src_hw=(480, 64
                 js += sorted({(i * 7919 + 13) % far, (i * 104729 + 7) % far})[:loop_edge_num]
             return js
 
-        def begin(i, feat):                     # on the CURRENT stream
-            js = edge_list(i)
-            if not js:
-                return None
-            t0 = mark()
-            pend = regress_views_begin(model, feat, [feats[j] for j in js], Hr, Wr)
-            ev["edges_decode"].append((t0, mark()))
-            return i, js, pend
-
-        def finish(job, after=None):            # on the CURRENT stream (the one begin(i) ran on)
-            if job is None:
-                return None
-            i, js, pend = job
-            t0 = mark()
-            res_e = regress_views_finish(model, pend, [i - j == 1 for j in js], thres)
-            t1 = mark()
-            ev["edges_heads"].append((t0, t1))
-            if after is not None:               # the previous keyframe's bookkeeping ran on the other edge stream
-                torch.cuda.current_stream(dev).wait_event(after)
-            for j, r in zip(js, res_e):
+        def on_edges(i, js, recs):              # host-side statistics + the pose chain of the harness (first accepted edge to a posed view)
+            for r in recs:
                 stats["edges"] += 1
-                if i - j != 1:
+                if r.i - r.j != 1:
                     stats["nonadj_conf"].append(r.rel_pose_conf)
                 if not r.accepted:
                     stats["rejected"] += 1
-                    continue
-                for v, k in ((i, 0), (j, 1)):          # node bookkeeping (slam.py:203-218): scale edge to the view's first node
-                    if v in first:
-                        d0, c0 = first[v][0], first[v][1]
-                        estimate_scale_with_depth_and_confidence(model, r.depths[k], d0, r.confs[k], c0)
-                        (r.confs[k] * c0).sqrt().mean()
-                        stats["scale_edges"] += 1
-                    else:
-                        first[v] = (r.depths[k], r.confs[k], r.intri)
-                if i not in poses and j in poses:
-                    poses[i] = poses[j] @ r.pose
-            t2 = mark()
-            ev["f1"].append((t1, t2))
-            return t2
+                elif r.i not in poses and r.j in poses:
+                    poses[r.i] = poses[r.j] @ r.pose
 
-        if not pipelined:
-            for i in range(nf):
-                feat, rgb, _done = add_view(i)
-                feats.append(feat); rgbs.append(rgb)
-                finish(begin(i, feat))
-        else:
-            with torch.cuda.stream(enc_stream):
-                nxt = add_view(0)
-            job, last_fin = None, None
-            for i in range(nf):
-                feat, rgb, done = nxt
-                feats.append(feat); rgbs.append(rgb)
-                if i + 1 < nf:
-                    with torch.cuda.stream(enc_stream):
-                        nxt = add_view(i + 1)
-                with torch.cuda.stream(edge_streams[i & 1]):
-                    edge_streams[i & 1].wait_event(done)
-                    new_job = begin(i, feat)
-                if job is not None:
-                    with torch.cuda.stream(edge_streams[(i - 1) & 1]):
-                        last_fin = finish(job, last_fin)
-                job = new_job
-            if job is not None:
-                with torch.cuda.stream(edge_streams[(nf - 1) & 1]):
-                    last_fin = finish(job, last_fin)
-            if last_fin is not None:
-                main_stream.wait_event(last_fin)
-            main_stream.wait_stream(enc_stream)
+        _recs, book, _feats = replay(model, nf, add_view, edge_list, thres, Hr, Wr, schedule="pipelined" if pipelined else "batched",
+                                     streams=[enc_stream] + edge_streams, timeline=ev, on_edges=on_edges, keep_records=False)
+        stats["scale_edges"] = book.scale_edges
+        first = book.first
         # f4: world point cloud of every view that has a node (slam.py:396-408)
         t4 = mark()
         ids = sorted(v for v in first if v in poses)
@@ -254,27 +202,12 @@ def slam_replay(model, dev, frames=120, warm=12, res=(224, 224), src_hw=(480, 64
         t5 = mark()
         torch.cuda.synchronize()
         ms = {k: sum(a.elapsed_time(b) for a, b in v) for k, v in ev.items()}
+        ms["f1"] = ms.pop("bookkeeping")
         ms["f4"] = t4.elapsed_time(t5)
         return ms, stats, npts, len(ids)
 
     _, st_w, _, _ = run(warm, -1.0, False)                               # warm-up: workspace, tables, threshold
-    if pool is not None:
-        # Stream placement: WHICH streams carry the three lanes decides how well they overlap - the same triple of streams is slow or
-        # fast every time it is used (tools/queue_probe.py: 177-183 vs 224-226 keyframes/s; the runtime places streams on a few
-        # hardware queues and the lanes of a slow triple end up serialising).  Nothing in the HIP API says which, so the harness
-        # does what an application would do at start-up: time the warm-up pass on four triples out of six streams, keep the best.
-        calib = {}
-        for idx in ((0, 1, 2), (3, 4, 5), (0, 2, 4), (1, 3, 5)):
-            enc_stream, edge_streams = pool[idx[0]], [pool[idx[1]], pool[idx[2]]]
-            run(warm, -1.0, True)                                        # this triple's scratch contexts
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            run(2 * warm, -1.0, True)
-            calib[idx] = 2 * warm / (time.perf_counter() - t0)
-        best = max(calib, key=calib.get)
-        enc_stream, edge_streams = pool[best[0]], [pool[best[1]], pool[best[2]]]
-        calib = {"chosen": list(best), "warmup_keyframes_per_s": {",".join(map(str, k)): round(v, 1) for k, v in calib.items()}}
-    run(warm, -1.0, True)                                                # ... and the other streams' scratch contexts
+    run(warm, -1.0, True)                                                # ... and the lanes' scratch contexts
     conf = sorted(st_w["nonadj_conf"])
     thres = conf[int(0.4 * len(conf))] if conf else -1.0
     torch.cuda.synchronize()
@@ -293,7 +226,7 @@ def slam_replay(model, dev, frames=120, warm=12, res=(224, 224), src_hw=(480, 64
     dt = dts[-1]
     nonadj = len(st["nonadj_conf"])
     return {"frames": frames, "keyframes_per_s": round(frames / dt, 2), "ms_per_keyframe": round(dt / frames * 1e3, 3),
-            "first_pass_keyframes_per_s": round(frames / dts[0], 2), "stream_placement": calib,
+            "first_pass_keyframes_per_s": round(frames / dts[0], 2), "stream_placement": placement,
             "same_result_as_single_stream": bool(npts == npts_s and st["rejected"] == st_s["rejected"] and st["edges"] == st_s["edges"]),
             "schedule": "three streams: f3 + encode of keyframe i+1 | decode + pose heads of keyframe i's edges (regress_views_begin) | DPT heads, "
                         "reductions and node bookkeeping of keyframe i-1 (regress_views_finish); one library scratch context per stream",
@@ -383,6 +316,20 @@ class StepRunner:
     def last_gathered(self):
         return None if not self.use_dist or self.n == 0 else self.gathered[(self.n - 1) & 1]
 
+    def verify_gather(self):
+        """After a step: on THIS rank, the last receive buffer must hold a non-trivial record from EVERY rank (a pose row has
+        pose[3][3] = 1, so an all-zero slice means that rank's shard never arrived).  Returns the per-source-rank checksums;
+        raises on a missing shard.  First-run hardening for N > 1: proves what the collective delivered, on every rank."""
+        torch = self.torch
+        g = self.last_gathered()
+        assert g is not None, "verify_gather before the first distributed step"
+        if self.cuda:
+            torch.cuda.synchronize()
+        sums = g.view(self.world, self.B, -1).abs().double().sum(dim=(1, 2)).cpu().tolist()
+        finite = bool(torch.isfinite(g).all())
+        assert finite and all(s_ > 0.0 for s_ in sums), f"all-gather delivered empty / non-finite shards: per-source-rank checksums {sums}"
+        return sums
+
     def gather_ms(self):
         if self.cuda:
             return sorted(a.elapsed_time(b) for a, b in self.gather_ev)
@@ -424,18 +371,40 @@ def timed_region(runner, steps, warmup_done=True):
     return dt, step_ms, out
 
 
-def distributed_fields(runner, dt, steps):
-    """MAX over ranks of the timed wall clock + the per-rank rates and the gather statistics of the JSON line."""
+def rank_identity(dev):
+    """What this rank actually drives: device name + PCI address (a launcher that maps two ranks onto one GPU shows up here)."""
+    import socket
+    import torch
+    d = torch.device(dev)
+    if d.type != "cuda":
+        return {"host": socket.gethostname(), "device": "cpu", "pci": None, "pid": os.getpid()}
+    p = torch.cuda.get_device_properties(d)
+    pci = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
+    return {"host": socket.gethostname(), "device": p.name, "pci": pci, "index": d.index, "pid": os.getpid(),
+            "hip_visible_devices": os.environ.get("HIP_VISIBLE_DEVICES")}
+
+
+def distributed_fields(runner, dt, steps, first_step_checksums=None):
+    """MAX over ranks of the timed wall clock + the per-rank rates, the gather statistics and - first-run hardening - what the
+    process group really is: the world size the backend reports, every rank's device / PCI address (gathered over the group) and
+    every rank's view of the first step's gathered records (per-source-rank checksums, `StepRunner.verify_gather`)."""
     import torch
     import torch.distributed as dist
     t = torch.tensor([dt], device=runner.dev, dtype=torch.float64)
     allt = [torch.zeros_like(t) for _ in range(runner.world)]
     dist.all_gather(allt, t)
     g = runner.gather_ms()
+    ident = [None] * dist.get_world_size()
+    dist.all_gather_object(ident, {"rank": dist.get_rank(), **rank_identity(runner.dev), "first_step_checksums": first_step_checksums})
+    pcis = [i["pci"] for i in ident if i.get("pci")]
+    assert dist.get_world_size() == runner.world, f"backend reports world {dist.get_world_size()}, launcher said {runner.world}"
+    assert len(set((i["host"], i["pci"]) for i in ident if i.get("pci"))) == len(pcis), f"two ranks drive the same GPU: {ident}"
     return max(float(x.item()) for x in allt), {
         "per_rank_pairs_per_s": [round(runner.B * steps / float(x.item()), 3) for x in allt],
         "all_gather_ms_median": round(g[len(g) // 2], 4) if g else None,
-        "all_gather_bytes_per_rank": int(runner.B * runner.P.compact_elems_per_pair(runner.H, runner.W) * 4)}
+        "all_gather_bytes_per_rank": int(runner.B * runner.P.compact_elems_per_pair(runner.H, runner.W) * 4),
+        "world_size_reported_by_backend": dist.get_world_size(), "backend": dist.get_backend(),
+        "ranks": ident}
 
 
 def host_cores():
@@ -555,6 +524,7 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("NCCL_DEBUG", "VERSION")          # RCCL prints its version line to stderr at init: which library the ranks really met through
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = local_device(local, torch.cuda.device_count())
@@ -570,8 +540,11 @@ def main():
     runner = StepRunner(lambda: model.forward_pair(img_a, img_b), B, H, W_, world, use_dist, dev, model=model)
     step = runner.step
 
-    for _ in range(args.warmup):
+    first_sums = None
+    for w in range(args.warmup):
         step()
+        if w == 0 and use_dist:
+            first_sums = runner.verify_gather()          # every rank: a non-empty record from every rank after the FIRST step
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -593,7 +566,9 @@ def main():
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     dist_fields = None
     if use_dist:
-        dt, dist_fields = distributed_fields(runner, dt, args.steps)
+        if first_sums is None:
+            first_sums = runner.verify_gather()
+        dt, dist_fields = distributed_fields(runner, dt, args.steps, first_sums)
     assert bool(torch.isfinite(out[0]["pts3d_pred"]).all()), "non-finite output"
 
     roof = None

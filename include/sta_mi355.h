@@ -116,6 +116,16 @@ int sta_set_deterministic(sta_handle* h, int on);
  * context switches: the chip is then filled across calls and more streams only compete for the runtime's few hardware queues),
  * and except when GPU_MAX_HW_QUEUES is set in the environment (the lanes are tuned for the runtime's default of 4).
  * STA_LANES_OFF / STA_LANES_ON make the schedule independent of either.  Results are bit-identical in all three. */
+/* sta_pipeline_streams: n (<= 4) library-owned non-blocking streams that were MEASURED to overlap pairwise on this device.
+ * The runtime maps streams onto a few hardware queues and two streams on one queue serialise - which streams those are is not
+ * visible through the HIP API (round 4: the same three application streams were reproducibly 20 % slower or faster) - so the
+ * library probes: a kernel that spins ~200 us on one stream, a stamp kernel on the other, overlap iff the second started before
+ * the first ended; candidates are kept when they overlap every stream kept so far.  The streams belong to the handle (created on
+ * the first call, ~1 ms; destroyed by sta_destroy) and are meant for the application's lanes: add_view of keyframe i+1 | edges
+ * of keyframe i | heads of keyframe i-1 (vista_slam_amd.keyframe_pipeline).  *n_verified_out (may be NULL): how many of the n
+ * are verified mutually concurrent (n unless the runtime has fewer usable queues). */
+int sta_pipeline_streams(sta_handle* h, int n, void** streams_out, int* n_verified_out);
+
 #define STA_LANES_AUTO (-1)
 #define STA_LANES_OFF 0
 #define STA_LANES_ON 1

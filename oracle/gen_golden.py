@@ -70,10 +70,20 @@ def run_case(name, cfg, H, W_, B, qk_gain=1.0, taps=False, sub=1, smooth=False, 
     for h in handles:
         h.remove()
     res = {}
+    # Sub-sampled fixtures (sub > 1): next to the `::sub` lattice - which only ever sees pixel (0, 0) of a 16x16 patch, row 0 of
+    # an 8x32 convolution tile, phase 0 of the ConvT scatter and of the x2 bilinear - a seeded OFF-LATTICE sample: 4096 random
+    # pixels of the flattened map (every pixel phase mod 16 / mod 8 / mod 32 occurs), the same indices for every map
+    rand_idx = None
+    if sub > 1:
+        rand_idx = np.sort(np.random.RandomState(2000 + seed).choice(H * W_, size=min(4096, H * W_), replace=False)).astype(np.int64)
+        res["rand_idx"] = rand_idx
     for side, key in (("main", "main_views"), ("supp", "support_views")):
         v = out[key][0]
         pts = v["pts3d_pred"].numpy()
         conf = v["conf"].numpy()
+        if rand_idx is not None:
+            res[f"{side}_pts3d_rand"] = pts.reshape(pts.shape[0], -1, 3)[:, rand_idx].copy()
+            res[f"{side}_conf_rand"] = conf.reshape(conf.shape[0], -1)[:, rand_idx].copy()
         res[f"{side}_pose"] = v["relative_pose"].numpy()
         res[f"{side}_pose_conf"] = v["relative_pose_conf"].numpy()
         res[f"{side}_pts3d"] = pts[:, ::sub, ::sub].copy()
@@ -349,17 +359,7 @@ def gen_f2(name, cfg, H, W_, nview, sub=1, seed=43, tag=21):
     print(f"[golden] {name}: accepted {acc} thres {thres:.6f} confs {probe} in {time.time() - t0:.1f}s", flush=True)
 
 
-def seq_edge_list(i, neighbor_edge_num, loop_edge_num, loop_dist_min):
-    """Edges of keyframe i in OnlineSLAM.step's order (slam.py:262-277): the <= neighbor_edge_num previous views, then the
-    <= loop_edge_num loop candidates.  The reference's candidates come from `LoopDetector.detect_loop(img_gray,
-    farthest_neighbor)` (DBoW3 on ORB features: a CPU stage, out of scope, absent here); the replay substitutes a deterministic
-    list with the detector's own filter shape - views older than the farthest neighbour and more than `loop_dist_min` keyframes
-    back (configs: 40; the short replays use 3) - ordered by a hash of (i, j) in place of the BoW similarity."""
-    far = max(0, i - neighbor_edge_num)
-    js = list(range(far, i))
-    cand = [j for j in range(far) if i - j > loop_dist_min]
-    cand.sort(key=lambda j: ((i * 7919 + j * 104729 + 13) % 1009, j))
-    return js + cand[:loop_edge_num], far
+from oracle.seq_protocol import seq_edge_list, seq_frames   # noqa: E402  (shared with the tests that replay the fixtures)
 
 
 def gen_seq(name, cfg, H, W_, nkf, neighbor_edge_num, loop_edge_num, rel_pose_thres=None, loop_dist_min=3, sub=1, nrand=0,
@@ -382,11 +382,7 @@ def gen_seq(name, cfg, H, W_, nkf, neighbor_edge_num, loop_edge_num, rel_pose_th
     su = _ref_slam_utils()
     sd = W.state_dict(cfg, seed=seed)
     model = load_reference_model(cfg, sd)
-    # frames: white-noise keyframes (even) and smooth ones (odd) - two input statistics in one sequence
-    noise = W.synth_images(nkf, H, W_, seed=seed, tag=tag)
-    smooth = W.smooth_images(nkf, H, W_, seed=seed, tag=tag)
-    frames = np.stack([noise[k] if k % 2 == 0 else smooth[k] for k in range(nkf)])
-    imgs = torch.from_numpy(frames.copy())
+    imgs = torch.from_numpy(seq_frames(W, nkf, H, W_, seed, tag).copy())
     ts = torch.tensor([[H, W_]])
     rng = np.random.RandomState(1000 + seed)
     rand_idx = np.sort(rng.choice(H * W_, size=nrand, replace=False)) if nrand else None

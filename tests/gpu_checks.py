@@ -347,6 +347,15 @@ def run_golden_case(name, precision, taps=True, variant=0):
         res[f"{side}_conf"] = rel_l2(conf[:, ::sub, ::sub], g[f"{side}_conf"])
         res[f"{side}_pose"] = rel_l2(o["relative_pose"].cpu().numpy(), g[f"{side}_pose"])
         res[f"{side}_pose_conf"] = rel_l2(o["relative_pose_conf"].cpu().numpy(), g[f"{side}_pose_conf"])
+        # the same outputs in the max norm (max-abs error / max-abs value): an isolated bad pixel that rel-L2 averages away shows here
+        res[f"{side}_pts3d_maxrel"] = max_rel(pts[:, ::sub, ::sub], g[f"{side}_pts3d"])
+        res[f"{side}_conf_maxrel"] = max_rel(conf[:, ::sub, ::sub], g[f"{side}_conf"])
+        res[f"{side}_pose_maxrel"] = max_rel(o["relative_pose"].cpu().numpy(), g[f"{side}_pose"])
+        if "rand_idx" in g:      # off-lattice pixels of the sub-sampled fixtures: every pixel phase of the patch / conv tile / ConvT / bilinear grids
+            ri = g["rand_idx"]
+            pr, cr = pts.reshape(pts.shape[0], -1, 3)[:, ri], conf.reshape(conf.shape[0], -1)[:, ri]
+            res[f"{side}_pts3d_rand"] = rel_l2(pr, g[f"{side}_pts3d_rand"]); res[f"{side}_pts3d_rand_maxrel"] = max_rel(pr, g[f"{side}_pts3d_rand"])
+            res[f"{side}_conf_rand"] = rel_l2(cr, g[f"{side}_conf_rand"]); res[f"{side}_conf_rand_maxrel"] = max_rel(cr, g[f"{side}_conf_rand"])
         res[f"{side}_pts3d_norm"] = abs(float(np.sqrt((pts.astype(np.float64) ** 2).sum(axis=(1, 2, 3)))[0]) / float(g[f"{side}_pts3d_l2"][0]) - 1.0)
     # split entry points (what slam.py calls): encoder features + decoder hooks
     ts = torch.tensor([[H, W_]] * B)

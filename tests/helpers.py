@@ -49,3 +49,54 @@ def grid_pos(B, hp, wp, pose_tok=False):
     if pose_tok:
         p = np.concatenate([np.full((1, 2), -1, np.int64), p], 0)
     return np.broadcast_to(p[None], (B,) + p.shape).copy()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# keyframe-sequence goldens (tests/golden/seq_*.npz, oracle/gen_golden.py gen_seq): one record per candidate edge
+def seq_meta(meta):
+    return {k: int(meta[k]) for k in ("H", "W", "nkf", "neighbor_edge_num", "loop_edge_num", "loop_dist_min", "sub", "nrand", "seed", "tag")}
+
+
+def compare_seq_edges(edges, g, meta, tol=1e-3):
+    """`edges`: list of dicts {i, j, pose [4,4], conf float, accepted bool, confs [2,H,W] / None, intri, depths, scales [2] with
+    NaN for 'no scale edge', scale_confs [2]} (numpy), in the reference's edge order.  Compares every field of every edge of the
+    golden `g`: decisions and (i, j) exactly, numbers as rel-L2 AND max-abs / max-abs - both below `tol`.  -> worst errors."""
+    m = seq_meta(meta)
+    n = int(g["n_edges"])
+    assert len(edges) == n, (len(edges), n)
+    sub, rand_idx = m["sub"], g.get("rand_idx")
+    worst = {}
+
+    def note(key, got, want):
+        e1, e2 = rel_l2(got, want), max_rel(got, want)
+        worst[key] = max(worst.get(key, 0.0), e1)
+        worst[key + "_max"] = max(worst.get(key + "_max", 0.0), e2)
+        assert e1 < tol and e2 < tol, (key, e1, e2)
+
+    for e in range(n):
+        r = edges[e]
+        assert (r["i"], r["j"]) == tuple(int(v) for v in g[f"e{e}_ij"]), (e, r["i"], r["j"], g[f"e{e}_ij"])
+        assert bool(r["accepted"]) == bool(g[f"e{e}_accepted"]), (e, r["conf"], float(g["thres"]))          # decisions identical
+        note("pose", r["pose"], g[f"e{e}_pose"])
+        assert abs(float(r["conf"]) - float(g[f"e{e}_conf"])) < 0.1 * float(g["thres_margin"]), (e, r["conf"], float(g[f"e{e}_conf"]))
+        note("pose_conf", np.array([r["conf"]]), np.array([float(g[f"e{e}_conf"])]))
+        if not r["accepted"]:
+            assert r["confs"] is None and r["intri"] is None and r["depths"] is None
+            continue
+        note("confs", r["confs"][:, ::sub, ::sub], g[f"e{e}_confs"])
+        note("depths", r["depths"][:, ::sub, ::sub], g[f"e{e}_depths"])
+        if rand_idx is not None:                                   # off-lattice pixels: every phase of the 16x16 patch / conv tiles
+            note("confs_rand", r["confs"].reshape(2, -1)[:, rand_idx], g[f"e{e}_confs_rand"])
+            note("depths_rand", r["depths"].reshape(2, -1)[:, rand_idx], g[f"e{e}_depths_rand"])
+        note("intri", r["intri"], g[f"e{e}_intri"])
+        worst["confs_norm"] = max(worst.get("confs_norm", 0.0), abs(float(np.sqrt((r["confs"].astype(np.float64) ** 2).sum())) / float(g[f"e{e}_confs_l2"]) - 1.0))
+        worst["depths_norm"] = max(worst.get("depths_norm", 0.0), abs(float(np.sqrt((r["depths"].astype(np.float64) ** 2).sum())) / float(g[f"e{e}_depths_l2"]) - 1.0))
+        for k in range(2):
+            want = float(g[f"e{e}_scale"][k])
+            got = r["scales"][k]
+            assert np.isnan(want) == (got is None or np.isnan(got)), (e, k, want, got)        # the same views get scale edges
+            if not np.isnan(want):
+                note("scale", np.array([got]), np.array([want]))
+                note("scale_conf", np.array([r["scale_confs"][k]]), np.array([float(g[f"e{e}_scale_conf"][k])]))
+    assert worst.get("confs_norm", 0.0) < tol and worst.get("depths_norm", 0.0) < tol, worst
+    return worst

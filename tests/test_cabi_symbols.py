@@ -73,3 +73,26 @@ def test_no_gpu_means_loud_failure():
     from vista_slam_amd.sta_frontend import STAFrontend
     with pytest.raises(_lib.StaError):
         STAFrontend()
+
+
+def test_install_as_reference_registers_the_import_path(tmp_path, monkeypatch):
+    """vista_slam_amd.install_as_reference(): `from .sta_model.sta_model import SymmetricTwoViewAssociation as STA` inside a
+    package named vista_slam (what vista_slam/slam.py:9 does) resolves to STAFrontend - here with a stand-in package holding a
+    stand-in caller (the reference's slam.py needs pypose / cv2 / DBoW3Py, absent everywhere this suite runs).  CPU part: the
+    import path; the GPU test test_checkpoint_file_through_the_reference_import_path runs the caller end to end."""
+    import importlib
+    import sys
+    pkg = tmp_path / "vista_slam"
+    pkg.mkdir()
+    (pkg / "__init__.py").write_text("")
+    (pkg / "caller.py").write_text("from .sta_model.sta_model import SymmetricTwoViewAssociation as STA\n")
+    monkeypatch.syspath_prepend(str(tmp_path))
+    for k in [k for k in sys.modules if k == "vista_slam" or k.startswith("vista_slam.")]:
+        monkeypatch.delitem(sys.modules, k)
+    import vista_slam_amd
+    from vista_slam_amd.sta_frontend import STAFrontend
+    vista_slam_amd.install_as_reference()
+    caller = importlib.import_module("vista_slam.caller")
+    assert caller.STA is STAFrontend
+    for k in [k for k in sys.modules if k == "vista_slam" or k.startswith("vista_slam.")]:
+        monkeypatch.delitem(sys.modules, k)

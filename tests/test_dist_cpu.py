@@ -159,12 +159,17 @@ def _bench_worker(rank, world, port, ret):
             calls[0] += 1
             return fake_outputs(ids)
         runner = bench.StepRunner(forward, B, H, W_, w, use_dist, "cpu", model=None)
-        for _ in range(2):
-            runner.step()                                      # warm-up, untimed
+        runner.step()                                          # warm-up, untimed
+        sums = runner.verify_gather()                          # first-run hardening: a non-empty record from EVERY rank after step 1
+        assert len(sums) == world and all(v > 0 for v in sums)
+        runner.step()
         steps = 5
         dt, step_ms, out = bench.timed_region(runner, steps)
         assert calls[0] == 2 + steps and len(step_ms) == steps and dt > 0       # EXACTLY K timed steps
-        dt_max, fields = bench.distributed_fields(runner, dt, steps)
+        dt_max, fields = bench.distributed_fields(runner, dt, steps, sums)
+        assert fields["world_size_reported_by_backend"] == world and fields["backend"] == "gloo"
+        assert [i["rank"] for i in fields["ranks"]] == list(range(world)) and all(len(i["first_step_checksums"]) == world for i in fields["ranks"])
+        assert len({i["pid"] for i in fields["ranks"]}) == world                     # one process per rank, each reported by itself
         ok = dt_max >= dt and len(fields["per_rank_pairs_per_s"]) == world and fields["all_gather_ms_median"] is not None
         ok &= fields["all_gather_bytes_per_rank"] == B * P.compact_elems_per_pair(H, W_) * 4
         # the last step's receive buffer holds every rank's records in global pair order
@@ -183,6 +188,22 @@ def test_bench_step_runner_two_ranks_gloo():
     ret = mp.Manager().dict()
     mp.spawn(_bench_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def test_verify_gather_catches_a_missing_shard():
+    """A rank whose records never arrive (an all-zero slice of the receive buffer) fails the first-step check loudly."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    B = 2
+    runner = bench.StepRunner(lambda: fake_outputs([0, 1]), B, H, W_, 2, False, "cpu", model=None)
+    runner.use_dist, runner.n = True, 1
+    full = P.pack_compact(*fake_outputs([0, 1, 2, 3]))
+    runner.gathered = [full.clone(), full.clone()]
+    assert len(runner.verify_gather()) == 2
+    runner.gathered[0][B:] = 0.0                                                     # rank 1's shard missing
+    with pytest.raises(AssertionError, match="empty"):
+        runner.verify_gather()
 
 
 def test_bench_rank_env_and_local_device(monkeypatch):

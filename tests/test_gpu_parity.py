@@ -585,10 +585,55 @@ def test_split_phase_scheduler_pipelines_two_keyframes(G):
             if acc:
                 assert torch.equal(r.depths, rest[0]) and torch.equal(r.confs, rest[1]) and torch.equal(r.intri, rest[2])
     with torch.cuda.stream(s1):
-        with pytest.raises(_lib.StaError, match="no scheduler call was begun"):
+        with pytest.raises(AssertionError, match="already finished"):
             regress_views_finish(m, pa, [False, False, True], thres)
         m._encode_image(imgs[:1], None, normalize=False)                   # and the stream is usable again
     torch.cuda.synchronize()
+
+
+def test_abandoned_scheduler_call_releases_its_stream(G):
+    """a begin that is never finished (an exception between the phases, a dropped PendingEdges) must not leave its
+    stream unusable.  PendingEdges.close() / `with` / garbage collection call sta_regress_views_abort; nine abandoned calls on
+    nine streams no longer exhaust the handle's eight scratch contexts; an aborted call cannot be finished."""
+    import gc
+    import torch
+    from vista_slam_amd import _lib, weights as W
+    from vista_slam_amd.slam_scheduler import regress_views, regress_views_begin, regress_views_finish
+    m = G.model("tiny", 1.0, DEFAULT)
+    H, Wd = 48, 64
+    imgs = torch.from_numpy(W.synth_images(3, H, Wd, seed=43, tag=29)).cuda()
+    feats = [m._encode_image(imgs[v:v + 1], None, normalize=False)[0] for v in range(3)]
+    ref = regress_views(m, feats[2], feats[:2], [False, True], -1.0, H, Wd)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        p = regress_views_begin(m, feats[2], feats[:2], H, Wd)
+        with pytest.raises(_lib.StaError, match="pending"):
+            m._encode_image(imgs[:1], None, normalize=False)
+        p.close()                                                          # explicit abort
+        p.close()                                                          # idempotent
+        m._encode_image(imgs[:1], None, normalize=False)                   # the stream is usable again
+        with pytest.raises(AssertionError, match="already finished or aborted"):
+            regress_views_finish(m, p, [False, True], -1.0)
+        try:
+            with regress_views_begin(m, feats[2], feats[:2], H, Wd):
+                raise KeyError("host-side failure between the phases")
+        except KeyError:
+            pass
+        got = regress_views(m, feats[2], feats[:2], [False, True], -1.0, H, Wd)      # context manager released it
+    torch.cuda.synchronize()
+    for a, b in zip(got, ref):
+        assert torch.equal(a.pose, b.pose) and torch.equal(a.depths, b.depths)
+    streams = [torch.cuda.Stream() for _ in range(9)]
+    for st_ in streams:                                                    # nine dropped begins: each released by __del__
+        with torch.cuda.stream(st_):
+            q = regress_views_begin(m, feats[2], feats[:2], H, Wd)
+            del q
+            gc.collect()
+    with torch.cuda.stream(streams[0]):
+        got = regress_views(m, feats[2], feats[:2], [False, True], -1.0, H, Wd)
+    torch.cuda.synchronize()
+    assert torch.equal(got[1].depths, ref[1].depths)
 
 
 def _pre_goldens():
@@ -973,3 +1018,194 @@ def test_decode_stereo_unequal_token_counts_is_refused(G):
     p1 = torch.zeros(1, 12, 2, dtype=torch.int64, device="cuda"); p2 = torch.zeros(1, 8, 2, dtype=torch.int64, device="cuda")
     with pytest.raises(AssertionError, match="same token grid"):
         m._decode_stereo(f1, f2, p1, p2)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE configs[2-3] as a workload: the frontend call sequence of OnlineSLAM.step over a growing feature cache, in the
+# tumrgbd.yaml (3 neighbour + <= 2 loop edges) and 7scenes.yaml (2 + 3) edge regimes, against REFERENCE goldens
+# (oracle/gen_golden.py gen_seq: add_view + connect_view_i_j replayed on the imported reference model, slam.py:142-241,244-297).
+SEQ_TINY = ["seq_tum_tiny_48x64", "seq_7scenes_tiny_48x64", "seq_tum_tiny_48x64_t075"]
+SEQ_FULL = ["seq_tum_full_224", "seq_7scenes_full_224"]
+
+
+def _seq_run(G, case, schedule, prec=DEFAULT):
+    import numpy as np
+    import torch
+    from helpers import load_golden, seq_meta
+    from oracle.seq_protocol import seq_edge_list, seq_frames
+    from vista_slam_amd import weights as W
+    from vista_slam_amd.keyframe_pipeline import replay
+    g, meta = load_golden(case)
+    sm = seq_meta(meta)
+    H, Wd = sm["H"], sm["W"]
+    m = G.model("tiny" if "tiny" in case else "full", 1.0, prec, sm["seed"])
+    m.range_report(reset=True)
+    frames = torch.from_numpy(seq_frames(W, sm["nkf"], H, Wd, sm["seed"], sm["tag"])).cuda()
+    ts = torch.tensor([[H, Wd]])
+
+    def add_view(i):                                               # slam.py:142-151
+        return m._encode_image(frames[i:i + 1], ts, normalize=False)
+
+    def edge_list(i):
+        return seq_edge_list(i, sm["neighbor_edge_num"], sm["loop_edge_num"], sm["loop_dist_min"])[0]
+    recs, book, _feats = replay(m, sm["nkf"], add_view, edge_list, float(g["thres"]), H, Wd, schedule=schedule)
+    torch.cuda.synchronize()
+
+    def n(t):
+        return None if t is None else t.detach().cpu().numpy()
+    edges = [dict(i=r.i, j=r.j, pose=n(r.pose), conf=float(r.rel_pose_conf), accepted=bool(r.accepted), confs=n(r.confs), intri=n(r.intri),
+                  depths=n(r.depths), scales=[None if s is None else float(s) for s in r.scales],
+                  scale_confs=[None if s is None else float(s) for s in r.scale_confs]) for r in recs]
+    return edges, g, meta, m
+
+
+@pytest.mark.parametrize("schedule", ["split", "batched", "pipelined"])
+@pytest.mark.parametrize("case", SEQ_TINY + SEQ_FULL)
+def test_keyframe_sequence_vs_reference_golden(G, case, schedule):
+    """Every candidate edge of a >= 8-keyframe replay - pose, confidence, accept / reject decision, shared K, depth and
+    confidence maps (lattice + off-lattice pixels + norms), and the scale edges between overlapping edges - against the
+    reference, three ways: (a) "split" = the four split calls exactly as slam.py:142-189 issues them, B = 1 per edge (the
+    zero-edit drop-in path); (b) "batched" = regress_views; (c) "pipelined" = the three-stream schedule bench.py's slam_replay
+    reports (vista_slam_amd/keyframe_pipeline.py).  Decisions identical, numbers within 1e-3 in rel-L2 AND in max-abs."""
+    from helpers import compare_seq_edges
+    edges, g, meta, m = _seq_run(G, case, schedule)
+    worst = compare_seq_edges(edges, g, meta, tol=TOL)
+    acc = [e["accepted"] for e in edges]
+    assert any(acc) and not all(acc)
+    if not case.endswith("_t075"):
+        assert any(e["i"] - e["j"] != 1 and e["accepted"] for e in edges), "no accepted non-adjacent edge in the fixture"
+    assert m.range_report() == (0, 0)
+    print(f"[seq] {case} {schedule}: " + " ".join(f"{k}={v:.1e}" for k, v in sorted(worst.items())))
+
+
+def test_keyframe_sequence_schedules_agree(G):
+    """The three schedules against EACH OTHER on one sequence: same decisions, poses / maps / scale edges equal to the
+    self-consistency bound of two valid schedules (different batch sizes take different tile families and K slices)."""
+    import numpy as np
+    from helpers import rel_l2
+    case = "seq_tum_full_224"
+    runs = {s: _seq_run(G, case, s)[0] for s in ("split", "batched", "pipelined")}
+    ref = runs["batched"]
+    for s in ("split", "pipelined"):
+        for a, b in zip(runs[s], ref):
+            assert (a["i"], a["j"], a["accepted"]) == (b["i"], b["j"], b["accepted"])
+            assert rel_l2(a["pose"], b["pose"]) < ctol(DEFAULT)
+            if a["accepted"]:
+                assert rel_l2(a["depths"], b["depths"]) < ctol(DEFAULT) and rel_l2(a["confs"], b["confs"]) < ctol(DEFAULT)
+    # the pipelined schedule runs the SAME batched calls on other streams: bit-identical to "batched"
+    for a, b in zip(runs["pipelined"], ref):
+        assert np.array_equal(a["pose"], b["pose"]) and (not a["accepted"] or np.array_equal(a["depths"], b["depths"]))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The documented integration path (INTEGRATION.md section 2; slam.py:9,95-106): a checkpoint FILE -> torch.load ->
+# STA().load_state_dict(checkpoint['model'], strict=True) -> .to(device) -> .eval(), reached through the reference's own import
+# path with no edit to the caller (vista_slam_amd.install_as_reference).
+_STANDIN_CALLER = '''"""Stand-in for the frontend half of vista_slam/slam.py (which needs pypose / cv2 / DBoW3Py): the same import, the same
+construction and loading sequence, the same four split calls per edge."""
+import torch
+from .sta_model.sta_model import SymmetricTwoViewAssociation as STA
+
+
+class Loop:
+    def __init__(self, ckpt_path):
+        self.device = torch.device("cuda")
+        frontend = STA()
+        checkpoint = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+        frontend.load_state_dict(checkpoint["model"], strict=True)
+        del checkpoint
+        frontend.to(self.device)
+        frontend.eval()
+        self.frontend = frontend
+        self.total_params = sum(p.numel() for p in frontend.parameters())
+
+    def pair(self, img_i, img_j, shape):
+        with torch.no_grad():
+            fi, pi = self.frontend._encode_image(img_i, shape, normalize=False)
+            fj, pj = self.frontend._encode_image(img_j, shape, normalize=False)
+            dij, dji = self.frontend._decode_stereo(fi, fj, pi, pj)
+            pose = self.frontend.head_pose_s(dij[-1][:, 0, :])
+            ij = self.frontend.head_pts([fi] + [t[:, 1:, :].float() for t in dij], shape)
+            ji = self.frontend.head_pts([fj] + [t[:, 1:, :].float() for t in dji], shape)
+        return pose, ij, ji
+'''
+
+
+def test_checkpoint_file_through_the_reference_import_path(G, tmp_path, monkeypatch):
+    """torch.save({'model': state_dict}) with torch tensors in the checkpoint's key order (both alias keys of every shared DPT
+    tensor included) -> a caller that imports `SymmetricTwoViewAssociation` by the reference's module path and loads the file
+    exactly as slam.py:95-106 does -> outputs BIT-identical to the procedural-weights frontend every other test uses, and equal
+    to the reference golden; the parameter count the SLAM loop prints (slam.py:46) is the architecture's."""
+    import importlib
+    import sys
+    import numpy as np
+    import torch
+    import vista_slam_amd
+    from helpers import load_golden, rel_l2
+    from vista_slam_amd import weights as W
+    sd = W.state_dict(W.FULL, seed=43)
+    aliases = [k for k in sd if W._alias_of(k) != k]
+    assert len(sd) == 665 and len(aliases) == 4 and all(W._alias_of(k) in sd for k in aliases)
+    ckpt = tmp_path / "frontend_sta_weights.pth"
+    torch.save({"model": {k: torch.from_numpy(v.copy()) for k, v in sd.items()}, "epoch": 0}, str(ckpt))
+    del sd
+    pkg = tmp_path / "vista_slam"
+    pkg.mkdir()
+    (pkg / "__init__.py").write_text("")
+    (pkg / "loop.py").write_text(_STANDIN_CALLER)
+    monkeypatch.syspath_prepend(str(tmp_path))
+    for k in [k for k in sys.modules if k == "vista_slam" or k.startswith("vista_slam.")]:
+        monkeypatch.delitem(sys.modules, k)
+    vista_slam_amd.install_as_reference()
+    loop = importlib.import_module("vista_slam.loop").Loop(str(ckpt))
+    assert type(loop.frontend).__name__ == "STAFrontend" and loop.frontend._finalized
+    ref_params = sum(int(np.prod(shape)) for name, shape, _k, _f in W.schema(W.FULL) if W._alias_of(name) == name)
+    assert loop.total_params == ref_params
+    g, meta = load_golden("full_224_b1")
+    imgs = torch.from_numpy(W.synth_images(2, 224, 224, seed=43, tag=0)).cuda()
+    shape = torch.tensor([[224, 224]])
+    pose, ij, ji = loop.pair(imgs[:1], imgs[1:], shape)
+    m = G.model("full", 1.0, DEFAULT)                                   # load_procedural: same values, never through a file
+    fa, pa = m._encode_image(imgs[:1], shape, normalize=False)
+    fb, pb = m._encode_image(imgs[1:], shape, normalize=False)
+    d1, d2 = m._decode_stereo(fa, fb, pa, pb)
+    pose2 = m.head_pose_s(d1[-1][:, 0, :])
+    ij2 = m.head_pts([fa] + [t[:, 1:, :] for t in d1], shape)
+    torch.cuda.synchronize()
+    assert torch.equal(pose["pose"], pose2["pose"]) and torch.equal(ij["pts3d"], ij2["pts3d"]) and torch.equal(ij["conf"], ij2["conf"])
+    sub = int(meta["sub"])
+    assert rel_l2(ij["pts3d"].cpu().numpy()[:, ::sub, ::sub], g["main_pts3d"]) < TOL
+    assert rel_l2(ji["pts3d"].cpu().numpy()[:, ::sub, ::sub], g["supp_pts3d"]) < TOL
+    assert rel_l2(pose["pose"].cpu().numpy(), g["main_pose"]) < TOL
+    for k in [k for k in sys.modules if k == "vista_slam" or k.startswith("vista_slam.")]:
+        monkeypatch.delitem(sys.modules, k)
+
+
+def test_checkpoint_with_fp16_tensors_and_shuffled_keys(G, tmp_path):
+    """A checkpoint stored in fp16 (and in another key order) loads like the fp32 tensors of the same VALUES: load_state_dict
+    converts every tensor to fp32 on the host (sta_frontend._load_one), the key order is irrelevant (slots are named)."""
+    import numpy as np
+    import torch
+    from vista_slam_amd import weights as W
+    from vista_slam_amd.sta_frontend import STAFrontend
+    sd = W.state_dict(W.TINY, seed=43)
+    half = {k: torch.from_numpy(v.copy()).half() for k, v in sd.items()}
+    keys = list(half)
+    rng = np.random.default_rng(3)
+    rng.shuffle(keys)
+    path = tmp_path / "tiny_fp16.pth"
+    torch.save({"model": {k: half[k] for k in keys}}, str(path))
+    ck = torch.load(str(path), map_location="cpu", weights_only=False)
+    assert next(iter(ck["model"].values())).dtype == torch.float16
+    a = STAFrontend(W.TINY, "cuda:0").load_state_dict(ck["model"], strict=True)
+    b = STAFrontend(W.TINY, "cuda:0").load_state_dict({k: half[k].float().numpy() for k in half}, strict=True)
+    imgs = torch.from_numpy(W.synth_images(2, 48, 64, seed=43, tag=0)).cuda()
+    oa, ob = a.forward_pair(imgs[:1], imgs[1:]), b.forward_pair(imgs[:1], imgs[1:])
+    torch.cuda.synchronize()
+    for x, y in zip(oa, ob):
+        for k in x:
+            assert torch.equal(x[k], y[k]), k
+    # a missing key and a foreign key still fail like the reference's strict load
+    bad = dict(ck["model"]); bad.pop(keys[0])
+    with pytest.raises(Exception, match="missing key"):
+        STAFrontend(W.TINY, "cuda:0").load_state_dict(bad, strict=True)

@@ -145,6 +145,7 @@ struct sta_handle {
     int pre_key[6] = {0, 0, 0, 0, 0, 0}; int* pre_tab = nullptr; int64_t pre_cap = 0; int pre_meta[12] = {0};
     bool dry = false;   // planning pass: run the orchestration without launching to size the workspace
     int lanes_mode = STA_LANES_AUTO;   // sta_set_side_lanes
+    std::vector<hipStream_t> pipe_streams; int pipe_verified = 0;   // sta_pipeline_streams: library-owned streams probed to overlap pairwise
     int lane = 0;       // 1 while dpt_impl enqueues on the context's side stream (launch_gemm then hands out the side lane's split-K scratch)
 };
 
@@ -448,6 +449,7 @@ extern "C" int sta_destroy(sta_handle* h) {
         if (c.side) hipStreamDestroy(c.side); if (c.side_skbuf) hipFree(c.side_skbuf);
         for (auto& e : c.side_ev) if (e) hipEventDestroy(e);
     }
+    for (hipStream_t s : h->pipe_streams) if (s) hipStreamDestroy(s);
     if (h->rope_tab) hipFree(h->rope_tab);
     if (h->zero_page) hipFree(h->zero_page);
     if (h->range) hipFree(h->range);

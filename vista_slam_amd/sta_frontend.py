@@ -120,6 +120,16 @@ class STAFrontend:
         application overlaps calls on several streams itself), "off", "on".  Results are bit-identical in all three."""
         _lib.check(self.lib.sta_set_side_lanes(self._h, {"auto": -1, "off": 0, "on": 1}[mode]))
 
+    def pipeline_streams(self, n: int = 3):
+        """n library-owned streams measured to overlap pairwise (sta_pipeline_streams), as torch stream objects - the lanes of
+        `keyframe_pipeline.replay(schedule="pipelined")`.  `self.pipeline_streams_verified` = how many of them are verified
+        mutually concurrent."""
+        ptrs = (C.c_void_p * n)()
+        nv = C.c_int(0)
+        _lib.check(self.lib.sta_pipeline_streams(self._h, n, ptrs, C.byref(nv)))
+        self.pipeline_streams_verified = int(nv.value)
+        return [torch.cuda.ExternalStream(int(ptrs[i]), device=self.device) for i in range(n)]
+
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state: Dict[str, "torch.Tensor | np.ndarray"], strict: bool = True):
         if not strict:
