@@ -499,6 +499,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-224", action="store_true", help="time the oracle on one 224x224 pair (4.3x less work) instead of 512x384")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--timed-every", type=int, default=TIMED_EVERY, help="the dominant kernel's launches inside the timed region: every N-th carries a HIP-event pair")
     ap.add_argument("--no-slam-probe", action="store_true")
     ap.add_argument("--slam-frames", type=int, default=120, help="frames of the slam_replay section (0 = skip)")
     args = ap.parse_args()
@@ -560,7 +561,7 @@ def main():
         dom = max(symtab.values(), key=lambda g: g["ms"])
         model.kernel_timing(False)
         from vista_slam_amd import _lib
-        _lib.check(model.lib.sta_kernel_timing_filter(model._h, dom["epi"], dom["amode"], dom["fam"], dom["mx"], TIMED_EVERY))
+        _lib.check(model.lib.sta_kernel_timing_filter(model._h, dom["epi"], dom["amode"], dom["fam"], dom["mx"], args.timed_every))
         model.kernel_timing(3)
     dt, step_ms, out = timed_region(runner, args.steps)
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
@@ -590,7 +591,7 @@ def main():
             roof = {"bound": "mfma", "kernel": sym + " - " + ("3x3 convolution, " if g["amode"] else "") + epi_name[g["epi"]],
                     "achieved": round(ach, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "timing": f"HIP events recorded by the library around every {TIMED_EVERY}th launch of this kernel on its launch stream, inside "
+                    "timing": f"HIP events recorded by the library around every {args.timed_every}th launch of this kernel on its launch stream, inside "
                               "the timed region (their cost is part of `value`); `launches` = the timed ones",
                     "algorithmic_bytes_per_launch": int(g["by"] / g["n"]), "gflop_per_launch": round(g["fl"] / g["n"] / 1e9, 2),
                     "launches": g["n"], "avg_launch_us": round(g["ms"] * 1e3 / g["n"], 2),

@@ -419,12 +419,17 @@ def gen_seq(name, cfg, H, W_, nkf, neighbor_edge_num, loop_edge_num, rel_pose_th
                     res[f"e{n}_pose"] = pose[0].numpy(); res[f"e{n}_conf"] = np.float32(float(c))
                     res[f"e{n}_accepted"] = np.array(confs is not None)
                 if confs is not None:
-                    scales = np.full(2, np.nan, np.float32); sconf = np.full(2, np.nan, np.float32)
+                    scales = np.full(2, np.nan, np.float32); sconf = np.full(2, np.nan, np.float32); sabs = np.full(2, np.nan, np.float32)
                     for k, (v, depth, pcl_conf) in enumerate(zip([i, j], depths, confs)):   # slam.py:203-218
                         if v in first_node:
                             depth_other, conf_other = first_node[v]
                             scales[k] = float(su.estimate_scale_with_depth_and_confidence(depth, depth_other, pcl_conf, conf_other))
                             sconf[k] = float((pcl_conf * conf_other).sqrt().mean())
+                            # conditioning of that ratio: the same sums with |Di Dj| in the numerator.  The estimate is
+                            # sum(w Di Dj) / sum(w Di Di); with procedural weights depths have both signs and the numerator cancels
+                            # (|s| down to 0.06 while sum(w |Di Dj|) / sum(w Di Di) ~ 1), so an error is judged against this figure
+                            w_ = (pcl_conf * conf_other).clamp(min=1e-6).double()
+                            sabs[k] = float((w_ * (depth.double() * depth_other.double()).abs()).sum() / (w_ * depth.double() ** 2).sum())
                         else:
                             first_node[v] = (depth, pcl_conf)
                     if record:
@@ -436,7 +441,7 @@ def gen_seq(name, cfg, H, W_, nkf, neighbor_edge_num, loop_edge_num, rel_pose_th
                         res[f"e{n}_intri"] = intri.numpy()
                         res[f"e{n}_confs_l2"] = np.sqrt((confs.double().numpy() ** 2).sum())
                         res[f"e{n}_depths_l2"] = np.sqrt((depths.double().numpy() ** 2).sum())
-                        res[f"e{n}_scale"] = scales; res[f"e{n}_scale_conf"] = sconf
+                        res[f"e{n}_scale"] = scales; res[f"e{n}_scale_conf"] = sconf; res[f"e{n}_scale_abs"] = sabs
                 n += 1
         return res, nonadj, n
 

@@ -96,7 +96,14 @@ def compare_seq_edges(edges, g, meta, tol=1e-3):
             got = r["scales"][k]
             assert np.isnan(want) == (got is None or np.isnan(got)), (e, k, want, got)        # the same views get scale edges
             if not np.isnan(want):
-                note("scale", np.array([got]), np.array([want]))
+                # s = sum(w Di Dj) / sum(w Di Di): with procedural weights the depths have both signs and the numerator cancels
+                # (|s| down to 0.06), so the error is judged against the same ratio with |Di Dj| (`scale_abs`, stored by the
+                # generator from the reference's tensors) - the magnitude the rounding errors of the maps actually scale with
+                ref_mag = max(abs(want), float(g[f"e{e}_scale_abs"][k]))
+                es = abs(float(got) - want) / ref_mag
+                worst["scale"] = max(worst.get("scale", 0.0), es)
+                worst["scale_rel_to_itself"] = max(worst.get("scale_rel_to_itself", 0.0), abs(float(got) - want) / abs(want))
+                assert es < tol, ("scale", e, k, got, want, ref_mag)
                 note("scale_conf", np.array([r["scale_confs"][k]]), np.array([float(g[f"e{e}_scale_conf"][k])]))
     assert worst.get("confs_norm", 0.0) < tol and worst.get("depths_norm", 0.0) < tol, worst
     return worst

@@ -200,9 +200,6 @@ def test_keyframe_sequence_oracle_vs_reference_golden(case):
             edges.append(rec)
     acc = [e["accepted"] for e in edges]
     assert any(acc) and not all(acc)
-    # 2e-4: the scale edges are ratios of signed sums (procedural weights give depths of both signs: sum(w Di Dj) cancels), so an
-    # fp32 restatement differs from the reference's own fp32 by up to ~1e-4 there; every other field holds 5e-5
-    worst = compare_seq_edges(edges, g, meta, tol=2e-4)
-    assert all(v < 5e-5 for k, v in worst.items() if not k.startswith("scale")), worst
+    worst = compare_seq_edges(edges, g, meta, tol=5e-5)      # (scale edges: judged against their conditioning, helpers.compare_seq_edges)
     assert any(e["scales"][0] is not None or e["scales"][1] is not None for e in edges), "fixture holds no scale edge"
     assert worst["pose"] < TOL
