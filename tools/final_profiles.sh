@@ -11,5 +11,6 @@ timeout 600 python tools/prec_check.py f16x3h f16x3 > gpurun_out/round/precision
 timeout 600 python tools/prec_check.py --stress f16x3h f16x3 >> gpurun_out/round/precision_table.txt 2>&1
 timeout 600 python tools/prec_check.py --outlier f16x3h f16x3 >> gpurun_out/round/precision_table.txt 2>&1
 timeout 600 python tools/prec_check.py --fullstress f16x3h f16x3 >> gpurun_out/round/precision_table.txt 2>&1
-timeout 300 python tools/ab_slam_libs.py > gpurun_out/round/ab_vs_r3_slam.txt 2>&1
+timeout 300 python tools/ab_slam_libs.py > gpurun_out/round/ab_vs_round_start_slam.txt 2>&1
+for b in 8 4 2 1; do AB_B=$b timeout 200 python tools/ab_inproc.py 2>&1 | tail -1; done > gpurun_out/round/ab_vs_round_start.txt
 tail -5 gpurun_out/profile_round.log

@@ -72,7 +72,10 @@ def shapes(variants, steps=3):
     import collections
     import ctypes as C
     m = STAFrontend(W.FULL, "cuda:0", precision=os.environ.get("STA_PRECISION", "f16x3h")).load_procedural(seed=43)
-    B, H, Wd = 8, 384, 512
+    B, H, Wd = int(os.environ.get("AB_B", 8)), 384, 512
+    for kv in os.environ.get("STA_DEBUG_OPT", "").split(","):          # e.g. STA_DEBUG_OPT=3:1 -> sta_debug_set_option(h, 3, 1)
+        if ":" in kv:
+            _lib.check(m.lib.sta_debug_set_option(m._h, int(kv.split(":")[0]), int(kv.split(":")[1])))
     imgs = torch.from_numpy(W.synth_images(2 * B, H, Wd, seed=43, tag=0)).cuda()
     table = collections.OrderedDict()
     for v in variants:

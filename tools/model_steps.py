@@ -7,13 +7,15 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 from vista_slam_amd import weights as W, _lib
-from vista_slam_amd import _lib as _hooks_lib; _hooks_lib.use_test_hooks()      # tools use the test-hooks build (include/sta_mi355_debug.h)
 from vista_slam_amd.sta_frontend import STAFrontend
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+if variant != 0:
+    _lib.use_test_hooks()      # a forced tile family needs the test-hooks build; variant 0 profiles the PRODUCT library
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 prec = sys.argv[3] if len(sys.argv) > 3 else "f16x3"
 m = STAFrontend(W.FULL, "cuda:0", precision=prec).load_procedural(seed=43)
-_lib.check(m.lib.sta_set_gemm_variant(m._h, variant))
+if variant != 0:
+    _lib.check(m.lib.sta_set_gemm_variant(m._h, variant))
 B, H, Wd = (int(os.environ.get(k, d)) for k, d in (("AB_B", 8), ("AB_H", 384), ("AB_W", 512)))      # workload: env AB_B / AB_H / AB_W
 imgs = torch.from_numpy(W.synth_images(2 * B, H, Wd, seed=43, tag=0)).cuda()
 for _ in range(steps):
