@@ -163,7 +163,9 @@ class STAFrontend:
             y = torch.arange(hp, device=self.device)
             x = torch.arange(wp, device=self.device)
             self._pos_cache[key] = torch.cartesian_prod(y, x)
-        return self._pos_cache[key].view(1, hp * wp, 2).expand(B, -1, 2).clone()
+        t = self._pos_cache[key].view(1, hp * wp, 2).expand(B, -1, 2).clone()
+        t._sta_grid = (hp, wp)          # provenance: this tensor IS the patch grid (checked without a device sync in _grid_from_pos)
+        return t
 
     def _f32(self, t: torch.Tensor) -> torch.Tensor:
         if t.device != self.device:
@@ -191,13 +193,21 @@ class STAFrontend:
         return feat, self._positions(B, hp, wp)
 
     def _grid_from_pos(self, pos: torch.Tensor, N: int):
-        """Recover the (hp, wp) patch grid; positions are the cartesian (y,x) grid by construction."""
-        cand = [(hp, wp) for (hp, wp) in self._pos_cache if hp * wp == N]
-        if len(cand) == 1:
-            return cand[0]
-        mx = pos[0].max(dim=0).values.tolist()     # rare path (ambiguous / foreign positions): one D2H sync
+        """The (hp, wp) patch grid of a positions tensor - and the CHECK that it is the patch grid.  The reference rotates q / k by
+        whatever positions it is handed (sta_blocks.py:134-137,196-199); here RoPE is fused into the QKV epilogues and evaluated
+        on the (y, x) grid itself, so other positions are not served: tensors this frontend produced (what slam.py:144 stores and
+        feeds back at :162) carry a provenance tag and cost nothing; a foreign tensor is compared with the grid (one D2H sync) and
+        refused loudly if it differs."""
+        g = getattr(pos, "_sta_grid", None)
+        if g is not None and g[0] * g[1] == N and tuple(pos.shape[1:]) == (N, 2):
+            return g
+        assert pos.dim() == 3 and tuple(pos.shape[1:]) == (N, 2), f"positions must be [B, {N}, 2] (got {tuple(pos.shape)})"
+        mx = pos[0].max(dim=0).values.tolist()
         hp, wp = int(mx[0]) + 1, int(mx[1]) + 1
-        assert hp * wp == N, "positions are not a full (y,x) grid"
+        ok = hp * wp == N and bool(torch.equal(pos.to(self.device, torch.int64), self._positions(pos.shape[0], hp, wp)))
+        if not ok:
+            raise NotImplementedError("positions other than the (y, x) patch grid of the frame are not served: RoPE is fused into the "
+                                      "QKV epilogues and evaluated on the grid itself (INTEGRATION.md section 4)")
         return hp, wp
 
     def _decode_stereo(self, feat1: torch.Tensor, feat2: torch.Tensor, pose1: torch.Tensor, pose2: torch.Tensor,
@@ -214,6 +224,7 @@ class STAFrontend:
             f"both views must have the same token grid (got {tuple(feat1.shape)} and {tuple(feat2.shape)})"
         assert feat2.shape == feat1.shape and E == self.cfg.enc_embed_dim
         hp, wp = self._grid_from_pos(pose1, N)
+        assert self._grid_from_pos(pose2, N) == (hp, wp), "the two views' positions describe different patch grids"
         L = self.cfg.dec_depth + 1
         want = range(L) if layers is None else layers
         D = self.cfg.dec_embed_dim
@@ -359,7 +370,7 @@ class STAFrontend:
         img_s = torch.cat([self._f32(v["img"]) for v in support], 0)             # [k*B, 3, H, W], support-major
         assert img_s.shape[0] == k * B and img_s.shape[1:] == img_m.shape[1:], "support views must match the main view's shape"
         feat_s, pos_s = self._encode_image(img_s, None, normalize=False)
-        feat_mk, pos_mk = feat_m.repeat(k, 1, 1), pos_m.repeat(k, 1, 1)
+        feat_mk, pos_mk = feat_m.repeat(k, 1, 1), self._positions(k * B, H // 16, W_ // 16)
         hooks = self.cfg.hooks                      # decoder list indices hooks[i] - 1 (dpt_head.py:112)
         layers = sorted({hk - 1 for hk in hooks[1:]})
         d1, d2 = self._decode_stereo(feat_mk, feat_s, pos_mk, pos_s, layers=layers)
