@@ -406,7 +406,22 @@ def distributed_fields(runner, dt, steps, first_step_checksums=None):
         "all_gather_ms_median": round(g[len(g) // 2], 4) if g else None,
         "all_gather_bytes_per_rank": int(runner.B * runner.P.compact_elems_per_pair(runner.H, runner.W) * 4),
         "world_size_reported_by_backend": dist.get_world_size(), "backend": dist.get_backend(),
-        "distinct_gpus": distinct, "ranks": ident}
+        "distinct_gpus": distinct, "ranks": ident, "collective_library": collective_library()}
+
+
+def collective_library():
+    """Which library the ranks met through: torch's NCCL binding is RCCL on ROCm (its version as torch reports it; also echoed on
+    stderr).  NCCL_DEBUG=VERSION would print the same banner - to STDOUT, in front of the one JSON line - so it is not set here."""
+    import torch
+    import torch.distributed as dist
+    if dist.get_backend() != "nccl":
+        return dist.get_backend()
+    try:
+        v = "RCCL " + ".".join(str(x) for x in torch.cuda.nccl.version()) + f" (torch {torch.__version__}, HIP {torch.version.hip})"
+    except Exception as e:   # noqa: BLE001
+        v = f"nccl backend (version query failed: {e})"
+    print(f"[bench] collective library: {v}", file=sys.stderr, flush=True)
+    return v
 
 
 def host_cores():
@@ -527,7 +542,6 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("NCCL_DEBUG", "VERSION")          # RCCL prints its version line to stderr at init: which library the ranks really met through
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = local_device(local, torch.cuda.device_count())
