@@ -533,6 +533,13 @@ def main():
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         sys.exit(subprocess.call(cmd, env=env))
 
+    # stdout carries exactly ONE line, the JSON result: native libraries write there too (RCCL prints a five-line version banner
+    # to stdout when its first communicator is created), so fd 1 is pointed at stderr for the whole run and the result line goes to
+    # the saved descriptor at the end
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from vista_slam_amd import weights as Wt
@@ -645,7 +652,8 @@ def main():
                 res["slam_replay"] = slam_replay(model, dev, frames=args.slam_frames)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_subprocess(224, 224) if args.cpu_baseline_224 else cpu_baseline_subprocess(H, W_)
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(res) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 
