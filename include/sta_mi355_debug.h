@@ -26,7 +26,7 @@ int sta_set_gemm_variant(sta_handle* h, int variant);
  * tests/test_tile_table.py replays profiles/r03_tile_table.txt through it).  amode: 0 dense, 1 3x3 convolution; epi: 0 f32,
  * 1 f16 planes, 2 qkv, 3 convT, 4 gelu, 5 f32 in-place residual, 6 fused head; M without the pose-token tail rows; split: 1 for
  * the f16x3 / f16x3h precisions; cstride / Ho / Wo: convolutions only (0 otherwise).  Returns 1, 2, 3, 5, 6 or 8
- * (sta_api.hip: pick_family). */
+ * (sta_launch.inc: pick_family). */
 int sta_debug_pick_family(int amode, int epi, long long M, int N, int K, int split, int cstride, int Ho, int Wo);
 
 /* nn.Linear (+GELU/ReLU, +residual): out[M,N] = act(A[M,K] W[N,K]^T + bias) (+resid).

@@ -2,7 +2,7 @@
 
 profiles/r03_tile_table.txt (tools/tile_table.py, MI355X) holds, for every GEMM / convolution shape of the forward at
 B in {1, 2, 4, 8} x {224x224, 384x512}, the in-model launch duration under the product's choice and under every forced tile
-family.  launch_gemm's choice is a pure host function (sta_api.hip: pick_family, exported as sta_debug_pick_family) - so this
+family.  launch_gemm's choice is a pure host function (sta_launch.inc: pick_family, exported as sta_debug_pick_family) - so this
 test needs no GPU: it replays every row through the CURRENT library and asserts
   * the family the library picks now is the one the table was measured with (the table is not stale), and
   * that family is within 3 % of the best measured family for the row (per family the fastest of its samples; a gap below

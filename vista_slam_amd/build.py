@@ -15,7 +15,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libsta_mi355.so")
 TEST_LIB = os.path.join(PKG, "libsta_mi355_test.so")
 SOURCES = ["sta_api.hip"]
-DEPS = ["sta_api.hip", "sta_debug.inc", "sta_rows.inc", "sta_bench.inc", "gemm.h", "gemm2.h", "conv3h.h", "attention.h", "elementwise.h", "sta_common.h",
+DEPS = ["sta_api.hip", "sta_launch.inc", "sta_forward.inc", "sta_debug.inc", "sta_rows.inc", "sta_bench.inc", "gemm.h", "gemm2.h", "conv3h.h", "attention.h", "elementwise.h", "sta_common.h",
         os.path.join("..", "..", "include", "sta_mi355.h"), os.path.join("..", "..", "include", "sta_mi355_debug.h")]
 
 
