@@ -1101,8 +1101,9 @@ def test_keyframe_sequence_schedules_agree(G):
 # The documented integration path (slam.py:9,95-106): a checkpoint FILE -> torch.load ->
 # STA().load_state_dict(checkpoint['model'], strict=True) -> .to(device) -> .eval(), reached through the reference's own import
 # path with no edit to the caller (vista_slam_amd.install_as_reference).
-_STANDIN_CALLER = '''"""Stand-in for the frontend half of vista_slam/slam.py (which needs pypose / cv2 / DBoW3Py): the same import, the same
-construction and loading sequence, the same four split calls per edge."""
+_STANDIN_CALLER = '''"""Stand-in for the frontend half of the SLAM loop (vista_slam/slam.py needs pypose / cv2 / DBoW3Py): it imports the model class by
+the reference's module path, builds it with no arguments, loads a checkpoint file strictly, moves it to the GPU, switches to eval
+- the steps of load_frontend (slam.py:95-106) - and then uses the four split entry points like regress_two_views does."""
 import torch
 from .sta_model.sta_model import SymmetricTwoViewAssociation as STA
 
@@ -1110,24 +1111,23 @@ from .sta_model.sta_model import SymmetricTwoViewAssociation as STA
 class Loop:
     def __init__(self, ckpt_path):
         self.device = torch.device("cuda")
-        frontend = STA()
-        checkpoint = torch.load(ckpt_path, map_location="cpu", weights_only=False)
-        frontend.load_state_dict(checkpoint["model"], strict=True)
-        del checkpoint
-        frontend.to(self.device)
-        frontend.eval()
-        self.frontend = frontend
-        self.total_params = sum(p.numel() for p in frontend.parameters())
+        model = STA()
+        weights = torch.load(ckpt_path, map_location="cpu", weights_only=False)["model"]
+        model.load_state_dict(weights, strict=True)
+        model.to(self.device)
+        model.eval()
+        self.frontend = model
+        self.total_params = sum(t.numel() for t in model.parameters())
 
     def pair(self, img_i, img_j, shape):
+        m = self.frontend
         with torch.no_grad():
-            fi, pi = self.frontend._encode_image(img_i, shape, normalize=False)
-            fj, pj = self.frontend._encode_image(img_j, shape, normalize=False)
-            dij, dji = self.frontend._decode_stereo(fi, fj, pi, pj)
-            pose = self.frontend.head_pose_s(dij[-1][:, 0, :])
-            ij = self.frontend.head_pts([fi] + [t[:, 1:, :].float() for t in dij], shape)
-            ji = self.frontend.head_pts([fj] + [t[:, 1:, :].float() for t in dji], shape)
-        return pose, ij, ji
+            (fi, pi), (fj, pj) = (m._encode_image(x, shape, normalize=False) for x in (img_i, img_j))
+            toks_i, toks_j = m._decode_stereo(fi, fj, pi, pj)
+            pose = m.head_pose_s(toks_i[-1][:, 0, :])
+            out_i = m.head_pts([fi] + [t[:, 1:, :].float() for t in toks_i], shape)
+            out_j = m.head_pts([fj] + [t[:, 1:, :].float() for t in toks_j], shape)
+        return pose, out_i, out_j
 '''
 
 

@@ -71,19 +71,22 @@ class NodeBook:
 
 def regress_two_views_split(frontend: STAFrontend, feat_i, feat_j, pos_i, pos_j, adjacent: bool, rel_pose_thres: float,
                             H: int, W: int) -> EdgeResult:
-    """`OnlineSLAM.regress_two_views` (slam.py:153-189) through the four split entry points, call for call."""
-    dec_ij, dec_ji = frontend._decode_stereo(feat_i, feat_j, pos_i, pos_j)
-    pose_ij = frontend.head_pose_s(dec_ij[-1][:, 0, :])
-    conf = float(pose_ij["conf"][0])                                  # the reference's host read (`if rel_pose_conf_ij < ...`, :169)
-    if conf < rel_pose_thres and not adjacent:
-        return EdgeResult(pose_ij["pose"][0], conf, False)
-    ts = [[H, W]]
-    ji_ret = frontend.head_pts([feat_j] + [t[:, 1:, :] for t in dec_ji], ts)
-    ij_ret = frontend.head_pts([feat_i] + [t[:, 1:, :] for t in dec_ij], ts)
-    pcls = torch.cat([ij_ret["pts3d"], ji_ret["pts3d"]], dim=0)
-    confs = torch.cat([ij_ret["conf"], ji_ret["conf"]], dim=0)
-    intri = estimate_intrinsic_from_pts3d(frontend, pcls, confs, shared_intrinsic=True)
-    return EdgeResult(pose_ij["pose"][0], conf, True, confs, intri, pcls[..., 2], pcls)
+    """One edge (i, j) through the four split entry points, in the order `OnlineSLAM.regress_two_views` uses them
+    (slam.py:153-189): decode both directions, pose head on the i -> j token, the host-side accept / reject test (:169), then the
+    point-map head on the j side and on the i side, the pair-shared intrinsics and the depths."""
+    tokens_i, tokens_j = frontend._decode_stereo(feat_i, feat_j, pos_i, pos_j)
+    head = frontend.head_pose_s(tokens_i[-1][:, 0, :])
+    conf = float(head["conf"][0])                                     # the one host read per edge (the reference compares on the host too)
+    if not adjacent and conf < rel_pose_thres:
+        return EdgeResult(head["pose"][0], conf, False)
+    shape = [[H, W]]
+    maps = {}
+    for side, feat, toks in (("j", feat_j, tokens_j), ("i", feat_i, tokens_i)):      # j side first, like slam.py:179-180
+        maps[side] = frontend.head_pts([feat] + [t[:, 1:, :] for t in toks], shape)
+    pts = torch.cat([maps["i"]["pts3d"], maps["j"]["pts3d"]], dim=0)               # view order [i -> j, j -> i] (slam.py:182)
+    conf_maps = torch.cat([maps["i"]["conf"], maps["j"]["conf"]], dim=0)
+    K = estimate_intrinsic_from_pts3d(frontend, pts, conf_maps, shared_intrinsic=True)
+    return EdgeResult(head["pose"][0], conf, True, conf_maps, K, pts[..., 2], pts)
 
 
 def replay(frontend: STAFrontend, n_keyframes: int, add_view: Callable[[int], Tuple[torch.Tensor, Optional[torch.Tensor]]],
