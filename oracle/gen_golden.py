@@ -529,17 +529,20 @@ CASES = {
 }
 
 # Multi-keyframe replays of OnlineSLAM.step's frontend calls in the edge regimes of the reference's configs (BASELINE configs[2-3]):
-# configs/tumrgbd.yaml:26,29 = 3 neighbour + <= 2 loop edges; configs/7scenes.yaml:26,29 = 2 + 3.  `_t075`: the yamls' own
+# configs/tumrgbd.yaml:26,29 = 3 neighbour + <= 2 loop edges; configs/7scenes.yaml:26,29 = 2 + 3; configs/default.yaml:26,29 = 3 + 3.  `_t075`: the yamls' own
 # rel_pose_thres (0.75, :46); the others: a mid threshold so that accepted AND rejected non-adjacent edges occur.
 SEQ_CASES = {
     "seq": [
         dict(name="seq_tum_tiny_48x64", cfg=W.TINY, H=48, W_=64, nkf=10, neighbor_edge_num=3, loop_edge_num=2, sub=2, config_name="tumrgbd.yaml regime"),
         dict(name="seq_7scenes_tiny_48x64", cfg=W.TINY, H=48, W_=64, nkf=10, neighbor_edge_num=2, loop_edge_num=3, sub=2, tag=32, config_name="7scenes.yaml regime"),
         dict(name="seq_tum_tiny_48x64_t075", cfg=W.TINY, H=48, W_=64, nkf=8, neighbor_edge_num=3, loop_edge_num=2, rel_pose_thres=0.75, sub=4, config_name="tumrgbd.yaml regime, rel_pose_thres 0.75"),
+        # configs/default.yaml:26,29 (what the ScanNet runs of BASELINE configs[4] use): 3 neighbour + <= 3 loop edges, up to 6 edges per keyframe
+        dict(name="seq_default_tiny_48x64", cfg=W.TINY, H=48, W_=64, nkf=10, neighbor_edge_num=3, loop_edge_num=3, sub=2, tag=33, config_name="default.yaml regime"),
     ],
     "seqfull": [
         dict(name="seq_tum_full_224", cfg=W.FULL, H=224, W_=224, nkf=8, neighbor_edge_num=3, loop_edge_num=2, sub=16, nrand=512, config_name="tumrgbd.yaml regime"),
         dict(name="seq_7scenes_full_224", cfg=W.FULL, H=224, W_=224, nkf=8, neighbor_edge_num=2, loop_edge_num=3, sub=16, nrand=512, tag=32, config_name="7scenes.yaml regime"),
+        dict(name="seq_default_full_224", cfg=W.FULL, H=224, W_=224, nkf=9, neighbor_edge_num=3, loop_edge_num=3, sub=16, nrand=512, tag=33, config_name="default.yaml regime"),
     ],
 }
 

@@ -1022,10 +1022,10 @@ def test_decode_stereo_unequal_token_counts_is_refused(G):
 
 # ---------------------------------------------------------------------------------------------------------
 # BASELINE configs[2-3] as a workload: the frontend call sequence of OnlineSLAM.step over a growing feature cache, in the
-# tumrgbd.yaml (3 neighbour + <= 2 loop edges) and 7scenes.yaml (2 + 3) edge regimes, against REFERENCE goldens
+# tumrgbd.yaml (3 neighbour + <= 2 loop edges), 7scenes.yaml (2 + 3) and default.yaml (3 + 3: the ScanNet runs) edge regimes, against REFERENCE goldens
 # (oracle/gen_golden.py gen_seq: add_view + connect_view_i_j replayed on the imported reference model, slam.py:142-241,244-297).
-SEQ_TINY = ["seq_tum_tiny_48x64", "seq_7scenes_tiny_48x64", "seq_tum_tiny_48x64_t075"]
-SEQ_FULL = ["seq_tum_full_224", "seq_7scenes_full_224"]
+SEQ_TINY = ["seq_tum_tiny_48x64", "seq_7scenes_tiny_48x64", "seq_tum_tiny_48x64_t075", "seq_default_tiny_48x64"]
+SEQ_FULL = ["seq_tum_full_224", "seq_7scenes_full_224", "seq_default_full_224"]
 
 
 def _seq_run(G, case, schedule, prec=DEFAULT):

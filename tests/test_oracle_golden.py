@@ -167,7 +167,7 @@ def test_torch_cpu_port_vs_reference_golden(case):
             assert rel_l2(r[side][k], g[f"{side}_{gk}"]) < tol, (side, k)
 
 
-@pytest.mark.parametrize("case", ["seq_tum_tiny_48x64", "seq_7scenes_tiny_48x64", "seq_tum_tiny_48x64_t075"])
+@pytest.mark.parametrize("case", ["seq_tum_tiny_48x64", "seq_7scenes_tiny_48x64", "seq_tum_tiny_48x64_t075", "seq_default_tiny_48x64"])
 def test_keyframe_sequence_oracle_vs_reference_golden(case):
     """The multi-keyframe replay of OnlineSLAM.step's frontend calls (oracle/gen_golden.py gen_seq: add_view + connect_view_i_j
     over a growing cache in the tumrgbd.yaml / 7scenes.yaml edge regimes, slam.py:142-241,244-297) through the ORACLE's
