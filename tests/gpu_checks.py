@@ -326,11 +326,16 @@ def check_ops_golden(precision):
 
 
 # ------------------------------------------------------------------------------------------ end to end
-def run_golden_case(name, precision, taps=True, variant=0):
-    """HIP forward on the procedural inputs of a golden case; returns {key: rel-L2 error}."""
+def run_golden_case(name, precision, taps=True, variant=0, frontend=None):
+    """HIP forward on the procedural inputs of a golden case; returns {key: rel-L2 error}.  frontend: a frontend that already holds
+    the weights the fixture was generated with (the real-checkpoint kit: weights from a FILE) instead of the procedural ones."""
     g, meta = load_golden(name)
     cfg_name = "tiny" if int(meta["cfg_enc_embed_dim"]) == W.TINY.enc_embed_dim else "full"
-    m = model(cfg_name, float(meta["qk_gain"]), precision, int(meta["seed"]), int(meta.get("outlier", 0)), hooks=variant != 0)
+    if frontend is not None:
+        m = frontend
+        m.set_precision(precision)
+    else:
+        m = model(cfg_name, float(meta["qk_gain"]), precision, int(meta["seed"]), int(meta.get("outlier", 0)), hooks=variant != 0)
     set_variant(m, variant)
     cfg = m.cfg
     m.range_report(reset=True)

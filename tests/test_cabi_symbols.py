@@ -14,11 +14,15 @@ def declared_symbols(hdr):
     return set(re.findall(r"\b(sta_[a-z0-9_]+)\s*\(", src))
 
 
-def exported_symbols(path):
-    """Dynamic symbols `sta_*` of a built library (nm -D; no GPU, nothing is called)."""
+def all_exported(path):
+    """EVERY defined dynamic symbol of a built library (nm -D; no GPU, nothing is called)."""
     import subprocess
     out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
-    return {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("sta_")}
+    return {ln.split()[-1] for ln in out.splitlines() if ln.split()}
+
+
+def exported_symbols(path):
+    return {s for s in all_exported(path) if s.startswith("sta_")}
 
 
 def test_library_builds_and_exports_every_declared_symbol():
@@ -32,6 +36,11 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert dbg == set(_lib.TEST_SIGNATURES), (dbg ^ set(_lib.TEST_SIGNATURES))
     assert exported_symbols(_lib.LIB_PATH) == prod, (exported_symbols(_lib.LIB_PATH) ^ prod)          # no test hooks in the product ABI
     assert exported_symbols(_lib.TEST_LIB_PATH) == prod | dbg, (exported_symbols(_lib.TEST_LIB_PATH) ^ (prod | dbg))
+    # -fvisibility=hidden + STA_API: the dynamic symbol table is the header and NOTHING else - no __device_stub__ kernel launch
+    # stubs, no helper functions (linker-defined section markers aside)
+    linker = {"_init", "_fini", "_edata", "_end", "__bss_start"}
+    assert all_exported(_lib.LIB_PATH) - linker == prod, sorted(all_exported(_lib.LIB_PATH) - linker - prod)[:10]
+    assert all_exported(_lib.TEST_LIB_PATH) - linker == prod | dbg, sorted(all_exported(_lib.TEST_LIB_PATH) - linker - prod - dbg)[:10]
     lib = _lib.load()
     for name in prod:
         assert hasattr(lib, name), f"{name} declared in include/sta_mi355.h but not exported"

@@ -40,6 +40,8 @@ SIGNATURES = {
     "sta_set_deterministic": (_i, [_vp, _i]),
     "sta_set_side_lanes": (_i, [_vp, _i]),
     "sta_pipeline_streams": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_i)]),
+    "sta_reserve": (_i, [_vp, _i, _i, _i, _i, C.POINTER(_vp), _i]),
+    "sta_alloc_stats": (_i, [_vp, C.POINTER(_i64)]),
     "sta_num_expected_tensors": (_i, [_vp]),
     "sta_num_loaded_tensors": (_i, [_vp]),
     "sta_load_tensor": (_i, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i, _i]),

@@ -15,7 +15,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libsta_mi355.so")
 TEST_LIB = os.path.join(PKG, "libsta_mi355_test.so")
 SOURCES = ["sta_api.hip"]
-DEPS = ["sta_api.hip", "sta_launch.inc", "sta_forward.inc", "sta_debug.inc", "sta_rows.inc", "sta_bench.inc", "gemm.h", "gemm2.h", "conv3h.h", "attention.h", "elementwise.h", "sta_common.h",
+DEPS = ["sta_exports.map", "sta_api.hip", "sta_launch.inc", "sta_forward.inc", "sta_debug.inc", "sta_rows.inc", "sta_bench.inc", "gemm.h", "gemm2.h", "conv3h.h", "attention.h", "elementwise.h", "sta_common.h",
         os.path.join("..", "..", "include", "sta_mi355.h"), os.path.join("..", "..", "include", "sta_mi355_debug.h")]
 
 
@@ -26,6 +26,12 @@ def hipcc_path():
     return None
 
 
+# -fvisibility=hidden: the dynamic symbol table is the STA_API declarations of include/*.h and nothing else (no __device_stub__
+# launch stubs, no helpers); tests/test_cabi_symbols.py asserts it
+# + a linker version script (csrc/sta_exports.map) for what visibility attributes cannot reach: hipcc's kernel handle objects,
+# libstdc++ template instantiations, the __hip_cuid_ marker
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wno-unused-value",
+              "-Wl,--version-script=" + os.path.join(CSRC, "sta_exports.map")]
 HASH_FILE = LIB + ".srchash"
 TEST_HASH_FILE = TEST_LIB + ".srchash"
 
@@ -46,7 +52,7 @@ def source_hash():
     snapshot copy, so staleness is decided by content) and of the build flags."""
     import hashlib
     h = hashlib.sha256()
-    h.update(" ".join(extra_flags()).encode())
+    h.update(" ".join([f.replace(CSRC, "csrc") for f in BASE_FLAGS] + extra_flags()).encode())      # (path-independent: the snapshot on the GPU box lives elsewhere)
     for d in DEPS:
         with open(os.path.join(CSRC, d), "rb") as f:
             h.update(f.read())
@@ -61,7 +67,7 @@ def is_stale(lib=LIB, hash_file=HASH_FILE):
 
 
 def _cmd(hipcc, out, hooks):
-    return ([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-o", out] + extra_flags() +
+    return ([hipcc] + BASE_FLAGS + ["-o", out] + extra_flags() +
             (["-DSTA_TEST_HOOKS"] if hooks else []) + [os.path.join(CSRC, s) for s in SOURCES])
 
 
@@ -84,11 +90,19 @@ def build_lib(force=False, verbose=True, test_hooks=True):
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         procs.append((subprocess.Popen(cmd, cwd=CSRC), cmd))
+    failed = None
     for (p, cmd), (out, hf, _hooks) in zip(procs, jobs):
+        if failed is not None:             # a sibling compile already failed: do not leave this one running un-waited
+            p.kill()
+            p.wait()
+            continue
         if p.wait() != 0:
-            raise subprocess.CalledProcessError(p.returncode, cmd)
+            failed = subprocess.CalledProcessError(p.returncode, cmd)
+            continue
         with open(hf, "w") as f:
             f.write(source_hash())
+    if failed is not None:
+        raise failed
     return LIB
 
 

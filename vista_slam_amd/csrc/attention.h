@@ -411,20 +411,46 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     const float inv = 1.0f / l_tot;
     const int64_t orows = (int64_t)p.S * p.nq + (p.pose ? p.S : 0);
     if constexpr (SPLIT) {
-        constexpr int RS = 144, QS = 2 * RS;            // LDS bytes per (query, column block) / per query
+        // LDS image per wave: 64 rows of 128 B, row R = d * 32 + query = [hi 4 chunks | lo 4 chunks] of 16 B (8 d each), chunk c of
+        // row R stored at position c ^ (R & 7).  Round 6: the first form ([query][d block] rows of 144 B, ds_write_b64 straight from
+        // the accumulator registers) put lanes l, l+4, l+8, l+12 of every 16-lane store group on one bank pair (288-B query stride
+        // = 8 banks mod 32: 4-way) and two to three lanes of a b128 read group on one slot - ALL of the kernel's bank conflicts
+        // (SQ_LDS_BANK_CONFLICT = 13 % of its LDS cycles, profiles/r05_lds_util_summary.txt; the K / V^T fragment reads are
+        // conflict-free by the swizzle above).  Now one v_permlane32_swap per register pair first gives every lane a WHOLE 16-B
+        // chunk (the same exchange the P^T operand uses: half 0 gets d 16j .. 16j+7, half 1 d 16j+8 .. 16j+15), so the tile is
+        // written with ds_write_b128 - 8 consecutive lanes = 8 consecutive queries = 8 different positions of the same chunk:
+        // one 128-B bank row per 8-lane group - and read back with ds_read_b128 whose four 16-lane groups each cover the 16
+        // slots of a 256-B bank row exactly once (rows of equal parity differ in their chunk set, the XOR permutes inside it).
         __syncthreads();                                // every wave is done with the K / V^T stages (all waves reach this point)
-        char* const wl = smem + wave * (32 * QS);
+        char* const wl = smem + wave * (64 * 128);
         RangeAcc ra;        // never flushed (dead code): a convex combination of V rows stays inside V's range
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+        for (int d = 0; d < 2; ++d) {
+            const int rowb = (d * 32 + l31) * 128, sw = l31 & 7;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                H4 oh, ol;
+            for (int j = 0; j < 2; ++j) {               // register groups g = 2j, 2j+1 -> chunks 2j (lane half 0), 2j+1 (half 1)
+                union { uint4 u4; unsigned u[4]; } ch, cl;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) split_f16(oacc[d][g * 4 + e] * inv, oh.e[e], ol.e[e], ra);
-                *reinterpret_cast<uint2*>(wl + l31 * QS + d * RS + (8 * g + 4 * lhi) * 2) = oh.u;
-                *reinterpret_cast<uint2*>(wl + l31 * QS + d * RS + 64 + (8 * g + 4 * lhi) * 2) = ol.u;
+                for (int gg = 0; gg < 2; ++gg) {
+                    H4 oh, ol;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) split_f16(oacc[d][(2 * j + gg) * 4 + e] * inv, oh.e[e], ol.e[e], ra);
+                    ch.u[2 * gg] = oh.u.x; ch.u[2 * gg + 1] = oh.u.y; cl.u[2 * gg] = ol.u.x; cl.u[2 * gg + 1] = ol.u.y;
+                }
+                // u[0..1] = X (group 2j: d 16j + 4 lhi + 0..3), u[2..3] = Y (group 2j+1: d 16j + 8 + 4 lhi + 0..3); after the swap
+                // half 0 = [own X, partner X] = d 16j .. 16j+7, half 1 = [partner Y, own Y] = d 16j+8 .. 16j+15
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    auto r1 = __builtin_amdgcn_permlane32_swap(ch.u[e], ch.u[2 + e], false, false);
+                    ch.u[e] = r1[0]; ch.u[2 + e] = r1[1];
+                    auto r2 = __builtin_amdgcn_permlane32_swap(cl.u[e], cl.u[2 + e], false, false);
+                    cl.u[e] = r2[0]; cl.u[2 + e] = r2[1];
+                }
+                const int c = 2 * j + lhi;
+                *reinterpret_cast<uint4*>(wl + rowb + ((c ^ sw) << 4)) = ch.u4;
+                *reinterpret_cast<uint4*>(wl + rowb + (((4 + c) ^ sw) << 4)) = cl.u4;
             }
+        }
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -434,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
                 if (q < nqe) {
                     const int64_t orow = q < p.nq ? (int64_t)s * p.nq + q : (int64_t)p.S * p.nq + s;
                     const size_t o = blk_off<true>(orow, h * 64 + d * 32, orows);
-                    *reinterpret_cast<uint4*>(p.O_hi + o + ch * 8) = *reinterpret_cast<const uint4*>(wl + qq * QS + d * RS + ch * 16);
+                    *reinterpret_cast<uint4*>(p.O_hi + o + ch * 8) = *reinterpret_cast<const uint4*>(wl + (d * 32 + qq) * 128 + ((ch ^ (qq & 7)) << 4));
                 }
             }
     } else {

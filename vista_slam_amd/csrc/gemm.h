@@ -119,7 +119,10 @@ __device__ __forceinline__ int qkv_rope_pos(const GemmParams& p, int t, bool pos
     const int ty = fast_div(tt, p.wp, p.wp_magic);
     return (xpart ? tt - ty * p.wp : ty) + 1;
 }
-typedef uint2 __attribute__((aligned(2))) uint2_a2;   // 8-byte store of 4 halves at 2-byte alignment
+// 8-byte store of 4 halves at 2-byte alignment (a V^T run starts at any token index): the copy carries the destination's real
+// alignment (an assignment through an under-aligned vector typedef is what -Walign-mismatch warned about); gfx950 global
+// memory takes unaligned dwordx2 stores, and hipcc emits one (checked in the ISA of qkv_finish_kernel)
+__device__ __forceinline__ void store8_a2(f16* dst, const uint2& v) { __builtin_memcpy(dst, &v, 8); }
 
 // QKV epilogue of one 32x32 accumulator tile: +bias, 2-D RoPE on q/k (pair partner = lane^16, cos/sin
 // from the table), head-major Q/K stores, and V written TRANSPOSED ([d][token]) - a lane owns one d
@@ -187,8 +190,8 @@ __device__ __forceinline__ void epilogue_qkv_tile(const GemmParams& p, const flo
                 H4 ph, pl;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { ph.e[e] = hh[e]; pl.e[e] = ll[e]; }
-                *reinterpret_cast<uint2_a2*>(p.Vt_hi + o) = ph.u;
-                if (SPLIT) *reinterpret_cast<uint2_a2*>(p.Vt_lo + o) = pl.u;
+                store8_a2(p.Vt_hi + o, ph.u);
+                if (SPLIT) store8_a2(p.Vt_lo + o, pl.u);
             } else if (col_ok) {                                      // sequence boundary / M tail
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -595,8 +598,8 @@ __global__ __launch_bounds__(256) void qkv_finish_kernel(const GemmParams p) {
         H4 ph, pl;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { ph.e[e] = hh[e]; pl.e[e] = ll[e]; }
-        *reinterpret_cast<uint2_a2*>(p.Vt_hi + o) = ph.u;
-        if (SPLIT) *reinterpret_cast<uint2_a2*>(p.Vt_lo + o) = pl.u;
+        store8_a2(p.Vt_hi + o, ph.u);
+        if (SPLIT) store8_a2(p.Vt_lo + o, pl.u);
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

@@ -2,6 +2,9 @@
 // Host orchestration only: every FLOP runs in the hand-written gfx950 kernels of gemm.h,
 // attention.h and elementwise.h.  No torch, no BLAS, no CPU fallback.
 #include "../../include/sta_mi355.h"
+#ifdef STA_TEST_HOOKS
+#include "../../include/sta_mi355_debug.h"      // the test-hooks build exports these too (STA_API = default visibility comes from the declarations)
+#endif
 #include "gemm.h"
 #include "gemm2.h"
 #include "conv3h.h"
@@ -147,6 +150,10 @@ struct sta_handle {
     int lanes_mode = STA_LANES_AUTO;   // sta_set_side_lanes
     std::vector<hipStream_t> pipe_streams; int pipe_verified = 0;   // sta_pipeline_streams: library-owned streams probed to overlap pairwise
     int lane = 0;       // 1 while dpt_impl enqueues on the context's side stream (launch_gemm then hands out the side lane's split-K scratch)
+    // sta_reserve / sta_alloc_stats: device allocations (hipMalloc / hipFree / hipHostMalloc / stream and event creation count as
+    // one each) and device-wide synchronisations the COMPUTE entry points made since sta_create - after sta_reserve neither moves
+    int64_t n_alloc = 0, n_devsync = 0;
+    bool reserve_only = false;      // inside sta_reserve: plan_and_run sizes and allocates, launches nothing
 };
 
 static int dalloc(sta_handle* h, void** p, int64_t bytes) {
@@ -188,7 +195,7 @@ static int stream_ctx(sta_handle* h, hipStream_t st) {
         StreamCtx* lru = nullptr;
         for (auto& c : h->ctx) if (!c.rv_open && (!lru || c.last_use < lru->last_use)) lru = &c;
         REQUIRE(lru, "all %d scratch contexts of this handle have a split-phase scheduler call pending (sta_regress_views_begin without _finish)", MAX_STREAM_CTX);
-        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipDeviceSynchronize()); h->n_devsync++;
         lru->st = st; lru->last_use = ++h->use_clock;
         h->cur = lru;
         return 0;
@@ -196,6 +203,7 @@ static int stream_ctx(sta_handle* h, hipStream_t st) {
     StreamCtx c; c.st = st; c.last_use = ++h->use_clock;
     HIPCHK(hipMalloc((void**)&c.skbuf, (size_t)SKBUF_ELEMS * 4));
     if (hipMalloc((void**)&c.slab, (size_t)SKBUF_ELEMS * 4) != hipSuccess) { hipFree(c.skbuf); return set_err("split-K slab alloc failed"); }
+    h->n_alloc += 2;
     h->ctx.push_back(c);          // (reserve()d in sta_create: pointers into the vector stay valid)
     h->cur = &h->ctx.back();
     return 0;
@@ -207,11 +215,12 @@ static int ensure_ws(sta_handle* h, int64_t bytes, hipStream_t st) {
     // phase B of a pending scheduler call still reads what phase A left in it
     REQUIRE(!c.rv_open, "a scheduler call begun with sta_regress_views_begin is pending on this stream: finish (or abort) it before the next call on the same stream");
     if (bytes <= c.ws_cap) return 0;
-    HIPCHK(hipDeviceSynchronize());
-    if (c.ws) HIPCHK(hipFree(c.ws));
+    HIPCHK(hipDeviceSynchronize()); h->n_devsync++;
+    if (c.ws) { HIPCHK(hipFree(c.ws)); h->n_alloc++; }
     c.ws = nullptr; c.ws_cap = 0;
-    int64_t want = bytes + (bytes >> 3) + (1 << 20);
-    HIPCHK(hipMalloc((void**)&c.ws, (size_t)want));
+    // a first call of a shape grows the workspace with 12.5 % of slack; sta_reserve takes the exact maximum of its plans
+    int64_t want = h->reserve_only ? bytes : bytes + (bytes >> 3) + (1 << 20);
+    HIPCHK(hipMalloc((void**)&c.ws, (size_t)want)); h->n_alloc++;
     c.ws_cap = want;
     return 0;
 }
@@ -237,9 +246,9 @@ static Bump cur_bump(sta_handle* h) { return Bump{h->cur->ws, h->cur->ws_cap}; }
 static int ensure_side(sta_handle* h) {
     StreamCtx& c = *h->cur;
     // every resource on its own: a failure half way leaves what exists in place for the next attempt (nothing is leaked twice)
-    if (!c.side_skbuf) HIPCHK(hipMalloc((void**)&c.side_skbuf, (size_t)SKBUF_ELEMS * 4));
-    for (auto& e : c.side_ev) if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    if (!c.side) HIPCHK(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+    if (!c.side_skbuf) { HIPCHK(hipMalloc((void**)&c.side_skbuf, (size_t)SKBUF_ELEMS * 4)); h->n_alloc++; }
+    for (auto& e : c.side_ev) if (!e) { HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->n_alloc++; }
+    if (!c.side) { HIPCHK(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking)); h->n_alloc++; }
     return 0;
 }
 static inline float* lane_skbuf(sta_handle* h) { return h->lane ? h->cur->side_skbuf : h->cur->skbuf; }
@@ -578,6 +587,7 @@ static int plan_and_run(sta_handle* h, hipStream_t st, F&& body) {
     h->dry = false;
     if (r != 0) return r;
     CHK(ensure_ws(h, plan.peak + 4096, st));
+    if (h->reserve_only) return ensure_side(h);      // sta_reserve: the plan is allocated (and the side lane with it), nothing runs
     Bump ws = cur_bump(h);
     return body(ws);
 }

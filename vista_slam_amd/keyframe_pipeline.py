@@ -66,7 +66,11 @@ class NodeBook:
                 rec.scale_confs[k] = (conf * c0).sqrt().mean()
                 self.scale_edges += 1
             else:
-                self.first[v] = (depth, conf, rec.intri)
+                # copies, not views: depth / conf are slices of the scheduler call's whole [k, 2, H, W] outputs and intri of its
+                # [k, 3, 3] - kept as views a view's first node would pin all k edges' maps for the rest of the run (with
+                # keep_records=False up to 6x the memory a keyframe needs).  Cloned on the current stream, i.e. behind the wait
+                # for the edge stream's `after` event in the pipelined schedule.
+                self.first[v] = (depth.clone(), conf.clone(), rec.intri.clone())
 
 
 def regress_two_views_split(frontend: STAFrontend, feat_i, feat_j, pos_i, pos_j, adjacent: bool, rel_pose_thres: float,

@@ -10,6 +10,7 @@ confidences, DPT + reductions only for the accepted edges.  All arithmetic runs 
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import List, Optional, Sequence
 
 import torch
@@ -36,9 +37,11 @@ class EdgeResult:
 class PendingEdges:
     """A scheduler call between its two phases (sta_regress_views_begin / _finish): the output tensors, the inputs kept
     alive, and the stream the call lives on.  While it is open its stream's scratch context inside the library is reserved;
-    `regress_views_finish` closes it, and so does `close()` / leaving a `with` block / garbage collection (an exception between
-    the phases must not leave the stream unusable: sta_regress_views_abort)."""
-    __slots__ = ("k", "H", "W", "stream", "pose", "pts", "conf", "K", "depth", "_keep", "_frontend", "_open")
+    `regress_views_finish` closes it, and so does `close()` / leaving a `with` block (an exception between the phases must not
+    leave the stream unusable: sta_regress_views_abort).  Close it EXPLICITLY: `__del__` is only a best-effort fallback and acts
+    only on the thread that created the object - the abort may block in hipEventSynchronize and the handle is not thread-safe,
+    so a garbage collection that happens to run on another thread must not enter the library."""
+    __slots__ = ("k", "H", "W", "stream", "pose", "pts", "conf", "K", "depth", "_keep", "_frontend", "_open", "_tid")
 
     def close(self):
         """Abort the call if it is still pending (idempotent)."""
@@ -57,7 +60,8 @@ class PendingEdges:
 
     def __del__(self):
         try:
-            self.close()
+            if getattr(self, "_tid", None) == threading.get_ident():
+                self.close()
         except Exception:
             pass
 
@@ -83,7 +87,7 @@ def regress_views_begin(frontend: STAFrontend, enc_feat_i: torch.Tensor, enc_fea
     p.K = torch.empty(k, 3, 3, device=dev, dtype=torch.float32)
     p.depth = torch.empty(k, 2, H, W, device=dev, dtype=torch.float32)
     p._keep = (fi, fj)
-    p._frontend, p._open = frontend, False
+    p._frontend, p._open, p._tid = frontend, False, threading.get_ident()
     _lib.check(frontend.lib.sta_regress_views_begin(frontend._h, fi.data_ptr(), ptrs, k, H, W, p.pose.data_ptr(), p.stream))
     p._open = True
     return p
@@ -99,9 +103,15 @@ def regress_views_finish(frontend: STAFrontend, p: PendingEdges, adjacent: Seque
     slot = (C.c_int * k)()
     nacc = C.c_int(0)
     assert p._open, "this scheduler call was already finished or aborted"
-    p._open = False                 # the C call closes the pending state whether it succeeds or not
-    _lib.check(frontend.lib.sta_regress_views_finish(frontend._h, adj, float(rel_pose_thres), pconf, slot, C.byref(nacc),
-                                                     p.pts.data_ptr(), p.conf.data_ptr(), p.K.data_ptr(), p.depth.data_ptr(), p.stream))
+    p._open = False
+    rc = frontend.lib.sta_regress_views_finish(frontend._h, adj, float(rel_pose_thres), pconf, slot, C.byref(nacc),
+                                               p.pts.data_ptr(), p.conf.data_ptr(), p.K.data_ptr(), p.depth.data_ptr(), p.stream)
+    if rc != 0:
+        # a failure BEFORE the C side cleared its pending flag (an argument check, a context lookup) would leave the stream
+        # reserved until sta_destroy: abort unconditionally - idempotent, 0 when nothing is pending - and keep the first error
+        msg = frontend.lib.sta_last_error()
+        frontend.lib.sta_regress_views_abort(frontend._h, p.stream)
+        raise _lib.StaError(msg.decode() if isinstance(msg, bytes) else str(msg))
     pts, conf, depth = p.pts, p.conf, p.depth
     if H > W:     # portrait: the reference sees transposed views of the same memory (utils/misc.py:60-61,81)
         pts, conf, depth = pts.swapaxes(2, 3), conf.swapaxes(2, 3), depth.swapaxes(2, 3)

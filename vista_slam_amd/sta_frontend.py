@@ -54,6 +54,7 @@ class STAFrontend:
         self._h = h
         self._finalized = False
         self._pos_cache: Dict[tuple, torch.Tensor] = {}
+        self._pos_verified: Dict[tuple, tuple] = {}       # foreign positions tensors already compared with the patch grid (_grid_from_pos)
         self.precision = precision
 
     # ------------------------------------------------------------------ nn.Module-like surface
@@ -130,6 +131,22 @@ class STAFrontend:
         self.pipeline_streams_verified = int(nv.value)
         return [torch.cuda.ExternalStream(int(ptrs[i]), device=self.device) for i in range(n)]
 
+    def reserve(self, B: int, H: int, W: int, max_edges: int = 0, streams: Sequence["torch.cuda.Stream | None"] | None = None):
+        """Allocate NOW everything calls of at most these sizes will need on `streams` (default: the current stream): scratch
+        contexts, workspaces, side lanes, the scheduler's pinned buffer, the RoPE table (sta_reserve, include/sta_mi355.h).
+        Afterwards such calls neither allocate nor synchronise the device (`alloc_stats()` stays put)."""
+        sts = [self._stream()] if streams is None else [s.cuda_stream if s is not None else None for s in streams]
+        arr = (C.c_void_p * len(sts))(*sts)
+        _lib.check(self.lib.sta_reserve(self._h, B, H, W, max_edges, arr, len(sts)))
+        return self
+
+    def alloc_stats(self):
+        """(allocations / frees / stream and event creations, device-wide synchronisations) the compute entry points of this handle
+        have made since it was created (sta_alloc_stats)."""
+        o = (C.c_int64 * 2)()
+        _lib.check(self.lib.sta_alloc_stats(self._h, o))
+        return int(o[0]), int(o[1])
+
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state: Dict[str, "torch.Tensor | np.ndarray"], strict: bool = True):
         if not strict:
@@ -164,7 +181,9 @@ class STAFrontend:
             x = torch.arange(wp, device=self.device)
             self._pos_cache[key] = torch.cartesian_prod(y, x)
         t = self._pos_cache[key].view(1, hp * wp, 2).expand(B, -1, 2).clone()
-        t._sta_grid = (hp, wp)          # provenance: this tensor IS the patch grid (checked without a device sync in _grid_from_pos)
+        # provenance: this tensor IS the patch grid (checked without a device sync in _grid_from_pos) - as long as nobody wrote
+        # to it since: the tag carries the tensor's version counter, an in-place edit (pos.add_(1), copy_) invalidates it
+        t._sta_grid = (hp, wp, t._version)
         return t
 
     def _f32(self, t: torch.Tensor) -> torch.Tensor:
@@ -199,15 +218,26 @@ class STAFrontend:
         feeds back at :162) carry a provenance tag and cost nothing; a foreign tensor is compared with the grid (one D2H sync) and
         refused loudly if it differs."""
         g = getattr(pos, "_sta_grid", None)
-        if g is not None and g[0] * g[1] == N and tuple(pos.shape[1:]) == (N, 2):
-            return g
+        if g is not None and g[0] * g[1] == N and tuple(pos.shape[1:]) == (N, 2) and g[2] == pos._version:
+            return g[0], g[1]
         assert pos.dim() == 3 and tuple(pos.shape[1:]) == (N, 2), f"positions must be [B, {N}, 2] (got {tuple(pos.shape)})"
+        # a foreign tensor (the tag does not survive .to() / .clone() / indexing / a save-load round trip) is verified ONCE: the
+        # verdict is cached by (storage address, version counter, shape), so the two device syncs below are paid per tensor, not
+        # per _decode_stereo call - the zero-edit SLAM path feeds the same cached positions back for every edge of a keyframe
+        key = (pos.data_ptr(), pos._version, tuple(pos.shape), str(pos.device))
+        hit = self._pos_verified.get(key)
+        if hit is not None:
+            return hit[0], hit[1]
         mx = pos[0].max(dim=0).values.tolist()
         hp, wp = int(mx[0]) + 1, int(mx[1]) + 1
         ok = hp * wp == N and bool(torch.equal(pos.to(self.device, torch.int64), self._positions(pos.shape[0], hp, wp)))
         if not ok:
             raise NotImplementedError("positions other than the (y, x) patch grid of the frame are not served: RoPE is fused into the "
                                       "QKV epilogues and evaluated on the grid itself (INTEGRATION.md section 4)")
+        if len(self._pos_verified) >= 4096:
+            self._pos_verified.clear()
+        # (the entry holds a reference to the tensor: its address cannot be handed to another tensor while the entry lives)
+        self._pos_verified[key] = (hp, wp, pos)
         return hp, wp
 
     def _decode_stereo(self, feat1: torch.Tensor, feat2: torch.Tensor, pose1: torch.Tensor, pose2: torch.Tensor,

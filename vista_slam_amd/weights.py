@@ -262,6 +262,21 @@ def state_dict(cfg: STAConfig = FULL, seed: int = 43, qk_gain: float = 1.0, outl
     return dict(generate(cfg, seed, qk_gain, outlier=outlier))
 
 
+def state_dict_fingerprint(sd) -> str:
+    """sha256 over the (name, shape, fp32 bytes) of every tensor of a state_dict in sorted key order - numpy arrays or torch
+    tensors.  The real-checkpoint fixtures (oracle/gen_golden.py --checkpoint) carry the fingerprint of the weights they were
+    generated with; the GPU test compares it with the checkpoint file it is handed, so fixtures and file cannot be mixed up."""
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        v = sd[k]
+        if hasattr(v, "detach"):
+            v = v.detach().to("cpu").float().numpy()
+        a = np.ascontiguousarray(v, dtype=np.float32)
+        h.update(k.encode()); h.update(str(tuple(a.shape)).encode()); h.update(a.tobytes())
+    return h.hexdigest()
+
+
 def synth_images(n: int, H: int, W: int, seed: int = 43, tag: int = 0) -> np.ndarray:
     """n synthetic RGB images, uint8 uniform[0,255] -> normalised (x/255-0.5)/0.5, NCHW fp32.
 
