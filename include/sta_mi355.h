@@ -63,11 +63,14 @@ enum {
     STA_PREC_F16X3 = 3,  /* 2-term fp16 split of both operands, 3 products (~21-bit, fp32 class)   */
     /* (4 was STA_PREC_F16MX, rounds 1-2: every linear / convolution with its two correction products as ONE block-scaled fp8
      *  MFMA.  +10 % but above the 1e-3 bar on five of the ten stress goldens; retired in round 3, the value is rejected.) */
-    STA_PREC_F16X3H = 5  /* DEFAULT.  f16x3 in the transformer (encoder, decoder, attention, embeddings, pose head); the DPT
+    STA_PREC_F16X3H = 5, /* f16x3 in the transformer (encoder, decoder, attention, embeddings, pose head); the DPT
                           * head's convolutions in the f16mx arithmetic: fp16 main product + ONE block-scaled fp8 MFMA that
                           * carries both correction products (activation bytes e5m2, weight bytes e4m3: GEMM error ~2e-5, 2 instead of 3 MFMA
                           * units).  The head is
                           * feed-forward and is not followed by any attention layer, so that error is not amplified */
+    STA_PREC_F16X3M = 6  /* f16x3h + mlp.fc2 of both transformers in the f16mx arithmetic (mlp.fc1's GELU epilogue writes the
+                          * f16mx rows).  Whether this or F16X3H is the default is decided by the written rule of DESIGN.md
+                          * section 2 ("a layer class ships in f16mx iff ...") on the measured precision table, not by taste */
 };
 
 enum { STA_DTYPE_F32 = 0, STA_DTYPE_F16 = 1, STA_DTYPE_F64 = 2 };   /* weights: F32 only; sta_rope2d_inplace_dtype: all three */

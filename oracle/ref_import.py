@@ -47,6 +47,12 @@ def load_reference_model(cfg, state):
     _install_xformers_stub()
     if REF_ROOT not in sys.path:
         sys.path.insert(0, REF_ROOT)
+    # `vista_slam_amd.install_as_reference()` (the zero-edit drop-in path, exercised by other tests of the same process) registers
+    # STAND-IN modules under the reference's package name: drop every `vista_slam*` module that does not come from the reference tree
+    for name in [n for n, m in list(sys.modules.items()) if n == "vista_slam" or n.startswith("vista_slam.")]:
+        origin = getattr(sys.modules[name], "__file__", None) or ""
+        if not origin.startswith(REF_ROOT):
+            del sys.modules[name]
     from vista_slam.sta_model.sta_model import SymmetricTwoViewAssociation as STA
     model = STA(enc_embed_dim=cfg.enc_embed_dim, enc_depth=cfg.enc_depth,
                 enc_num_heads=cfg.enc_num_heads, dec_embed_dim=cfg.dec_embed_dim,

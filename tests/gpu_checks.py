@@ -48,9 +48,11 @@ def drop_models():
 def kernel_handle(precision, variant=0):
     """precision "head_mx": the DPT head's arithmetic of the default policy (f16 main product + one block-scaled fp8 correction
     MFMA on f16mx rows) in the kernels that have it: the debug GEMM (plane epilogue), conv3x3, ConvT, bilinear."""
-    m = model("tiny", 1.0, "f16x3h" if precision == "head_mx" else precision, hooks=True)
+    # "mlp_mx": the MLP's f16mx path of precision f16x3m - mlp.fc1's GELU epilogue writing f16mx rows (via_f16 + GELU) and mlp.fc2
+    # (fp32 / in-place-residual epilogues on f16mx rows and weights)
+    m = model("tiny", 1.0, {"head_mx": "f16x3h", "mlp_mx": "f16x3m"}.get(precision, precision), hooks=True)
     _lib.check(m.lib.sta_set_gemm_variant(m._h, variant))
-    _lib.check(m.lib.sta_debug_set_option(m._h, 4, 1 if precision == "head_mx" else 0))
+    _lib.check(m.lib.sta_debug_set_option(m._h, 4, {"head_mx": 1, "mlp_mx": 2}.get(precision, 0)))
     return m, m.lib, m._h
 
 

@@ -7,7 +7,7 @@ pytestmark = pytest.mark.gpu
 
 # head_mx: the DPT head's arithmetic in the default policy (correction products as one block-scaled fp8 MFMA, ~1e-5 per GEMM),
 # for the kernels the head is made of
-TOL = {"f16x3": 2e-5, "f16": 3e-3, "head_mx": 6e-5}
+TOL = {"f16x3": 2e-5, "f16": 3e-3, "head_mx": 6e-5, "mlp_mx": 6e-5}
 PRECS = ["f16x3", "f16"]
 HEAD_PRECS = ["f16x3", "f16", "head_mx"]
 
@@ -43,6 +43,24 @@ def test_qkv_rope(G, prec, kw):
     r = G.check_qkv_rope(prec, **kw)
     assert r["q"] < TOL[prec] and r["k"] < TOL[prec] and r["v"] < TOL[prec], r
     assert r["vpad_abs"] == 0.0, "V^T padding must stay zero (0 * garbage = NaN otherwise)"
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(resid=True), dict(M=520, N=384, K=1024), dict(M=520, N=384, K=1024, resid=True), dict(act=1, via_f16=1),
+                                dict(M=129, N=128, K=64, resid=True), dict(M=700, N=512, K=256, variant=3), dict(M=385, N=384, K=96, variant=3, resid=True),
+                                dict(M=700, N=512, K=256, variant=2, resid=True), dict(M=193, N=128, K=64, variant=3, act=1, via_f16=1),
+                                dict(M=3000, N=1024, K=512, resid=True), dict(M=2400, N=768, K=3072, resid=True), dict(M=3000, N=512, K=256, act=1, via_f16=1)])
+def test_gemm_mlp_f16mx(G, kw):
+    """Precision f16x3m (round 6): mlp.fc2 in the f16mx arithmetic - fp32 and in-place-residual epilogues on f16mx rows / weights on
+    the small-grid, 192x128 and 192x256 families - and mlp.fc1's GELU epilogue writing the f16mx rows (LDS-staged and edge tiles)."""
+    r = G.check_gemm("mlp_mx", **kw)
+    assert r["rel_l2"] < TOL["mlp_mx"], r
+
+
+@pytest.mark.parametrize("kw", [dict(resid=True), dict(variant=3, N=768, K=1024, tiles_m=22, resid=True), dict(tail=1), dict(tail=32, resid=True)])
+def test_gemm_tail_rows_mlp_f16mx(G, kw):
+    """The pose-token tail blocks of mlp.fc2 in the f16mx arithmetic (gemm2_tail<MX>: fragments straight from global memory)."""
+    r = G.check_gemm_tail("mlp_mx", **kw)
+    assert r["rel_l2"] < TOL["mlp_mx"], r
 
 
 @pytest.mark.parametrize("prec", ["f16x3", "f16"])

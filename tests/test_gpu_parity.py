@@ -1424,3 +1424,16 @@ def test_checkpoint_kit_on_a_standin_checkpoint(G, tmp_path):
     for line in report:
         print("[ckpt stand-in]", line)
     assert len(report) == 4
+
+
+@pytest.mark.parametrize("case", ["full_224_b1", "full_224_b1_sharp", "full_224_b1_outlier", "full_384x512_b1_sharp"])
+def test_opt_in_precision_f16x3m_full_architecture(G, case):
+    """Precision f16x3m (round 6: f16x3h + mlp.fc2 of both transformers in the f16mx arithmetic, +2.1 % at the headline configuration)
+    is NOT the default: the written rule of DESIGN.md section 2 - every committed golden <= 0.5 x the bar in rel-L2 and < the bar
+    in the max norm - fails on two of the ten tiny-configuration stress sets (3.4e-3, 7.4e-4 / 1.0e-3).  What the opt-in mode does
+    hold is asserted here: every full-architecture golden (default, sharp, outlier statistics; 224x224 and the headline resolution)
+    within HALF the bar in both norms, no range event."""
+    r = G.run_golden_case(case, "f16x3m")
+    bad = {k: v for k, v in r.items() if not v < 0.5 * TOL}
+    assert not bad, bad
+    assert G.last_range == (0, 0)

@@ -38,7 +38,7 @@ def main(pmc_csv, stats_txt=None):
         p, us = pct.get(k[:60], (0.0, 0.0))
         rows.append((p, k, us, util, conf / act if act > 0 else 0.0))
     print(f"{'kernel':72s} {'pct_time':>8s} {'avg_us':>9s} {'lds_util':>9s} {'conflict':>9s}")
-    for p, k, us, util, cf in sorted(rows, reverse=True)[:16]:
+    for p, k, us, util, cf in (sorted(rows, reverse=True)[:16] if pct else sorted(rows, key=lambda r: -r[3])):      # without a stats file: every kernel, by LDS utilisation
         print(f"{k[:72]:72s} {p:8.2f} {us:9.1f} {util:9.3f} {cf:9.4f}")
 
 

@@ -18,7 +18,8 @@ TEST_LIB_PATH = os.path.join(PKG, "libsta_mi355_test.so")
 STA_PREC_F16 = 1
 STA_PREC_F16X3 = 3
 STA_PREC_F16X3H = 5
-PRECISIONS = {"f16": STA_PREC_F16, "f16x3": STA_PREC_F16X3, "f16x3h": STA_PREC_F16X3H}
+STA_PREC_F16X3M = 6
+PRECISIONS = {"f16": STA_PREC_F16, "f16x3": STA_PREC_F16X3, "f16x3h": STA_PREC_F16X3H, "f16x3m": STA_PREC_F16X3M}
 
 
 class StaConfig(C.Structure):

@@ -18,6 +18,7 @@
 //  * Epilogue: the ordinary plane epilogue per 32-pixel row segment (bias, ReLU, residual planes), bounded to the image.
 #pragma once
 #include "gemm2.h"
+#include <type_traits>
 
 #define C3H_PW 34     // halo width: 32 output columns + 2
 
@@ -91,14 +92,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3h_kernel(const Gem
     char* const sH = smem;
     char* const sB = smem + 2 * HALO;
 
-    auto issue_b = [&](int cb, int tap, int stage) {           // weight K tile (tap, cb): K order of the packed weights is (ky, kx, ci)
-        const f16* base = p.B_hi + (size_t)(tap * cblocks + cb) * b_kstride;
+    // weight K tile (tap, cb): K order of the packed weights is (ky, kx, ci), the loop runs cb outermost - the tile's base is a running
+    // byte offset (next tap: + cblocks K tiles; next channel block: back to tap 0, + 1 K tile) instead of a 64-bit multiply per step
+    const size_t b_tap_bytes = (size_t)cblocks * b_kstride * 2, b_cb_bytes = b_kstride * 2;
+    size_t b_off = 0;                                          // byte offset of the NEXT tile issue_b will be asked for
+    auto issue_b = [&](int /*cb*/, int tap, int stage) {
+        const char* base = reinterpret_cast<const char*>(p.B_hi) + b_off;
+        b_off = tap == 8 ? b_off - 8 * b_tap_bytes + b_cb_bytes : b_off + b_tap_bytes;
 #pragma unroll
         for (int s = 0; s < SB; ++s) {
             if (NSB % NW != 0 && wave + NW * s >= NSB) continue;
             unsigned o = b_src[s];
             asm volatile("" : "+v"(o));
-            glds16(reinterpret_cast<const char*>(base) + o, sB + stage * B_TILE + (wave + NW * s) * 1024);
+            glds16(base + o, sB + stage * B_TILE + (wave + NW * s) * 1024);
         }
     };
     auto issue_halo = [&](int j, int cb, int stage) {          // halo slot j (RPS halo pixels) of channel block cb
@@ -125,6 +131,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3h_kernel(const Gem
     __syncthreads();
     if (p.stamps) st1 = __builtin_amdgcn_s_memrealtime();
 
+    // The K loop exists twice, with the input ReLU of resConfUnit*.conv1 resolved at COMPILE time (round 6): tested per fragment
+    // inside the loop, the wave-uniform flag was six branches per K step - basic-block boundaries hipcc schedules nothing across
+    // (every fragment read waited right in front of its MFMAs), in the kernels with no ReLU at all (head.0, the fused tail) too.
+    auto k_loop = [&](auto relu_c) {
+    constexpr bool RELU = decltype(relu_c)::value;
     int cb = 0, tap = 0;
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1, hs = cb & 1;
@@ -152,7 +163,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3h_kernel(const Gem
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     ah[i] = *reinterpret_cast<const half8*>(hA + lds2_off<true>(hp[i], chunk));
-                    if (p.relu_in) {
+                    if (RELU) {
                         union { half8 h; unsigned u[4]; } tt; tt.h = ah[i];
 #pragma unroll
                         for (int w = 0; w < 4; ++w) { const unsigned sgn = (tt.u[w] >> 15) & 0x00010001u; tt.u[w] &= ~((sgn << 16) - sgn); }
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3h_kernel(const Gem
             for (int i = 0; i < MT; ++i) {
                 a8[i].q.x = *reinterpret_cast<const int4v*>(hA + lds2_off<true>(hp[i], 4 + 2 * lhi));
                 a8[i].q.y = *reinterpret_cast<const int4v*>(hA + lds2_off<true>(hp[i], 5 + 2 * lhi));
-                if (p.relu_in) {
+                if (RELU) {
 #pragma unroll
                     for (int w = 0; w < 8; ++w) { const unsigned u = (unsigned)a8[i].v[w]; const unsigned sgn = (u >> 7) & 0x00010001u; a8[i].v[w] = (int)(u & ~((sgn << 16) - sgn)); }
                 }
@@ -199,7 +210,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3h_kernel(const Gem
                 for (int i = 0; i < MT; ++i) {
                     a_hi[i] = *reinterpret_cast<const half8*>(hA + lds2_off<SPLIT>(hp[i], chunk));
                     if (SPLIT) a_lo[i] = *reinterpret_cast<const half8*>(hA + lds2_off<SPLIT>(hp[i], 4 + chunk));
-                    if (p.relu_in) {         // relu(hi + lo): the sign of hi decides (packed-half integer form, gemm2.h)
+                    if (RELU) {              // relu(hi + lo): the sign of hi decides (packed-half integer form, gemm2.h)
                         union { half8 h; unsigned u[4]; } ah, al;
                         ah.h = a_hi[i]; al.h = a_lo[i];
 #pragma unroll
@@ -241,6 +252,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3h_kernel(const Gem
         __syncthreads();
         tap = ntap; cb = ncb;
     }
+    };
+    if (EPI != EPI_HEAD && p.relu_in) k_loop(std::integral_constant<bool, true>{});
+    else k_loop(std::integral_constant<bool, false>{});
 
     if (p.stamps) { asm volatile("" ::"v"(acc[MT - 1][NT - 1][15]), "v"(acc[0][0][0]) : "memory"); st2 = __builtin_amdgcn_s_memrealtime(); }
     // ---- epilogue: MFMA tile (i, j) of this wave = the 32 pixels (y0 + wm*MT + i, x0 .. x0 + 31) x 32 channels

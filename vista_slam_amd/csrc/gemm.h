@@ -354,9 +354,15 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
         for (int r = 0; r < 16; ++r) {
             const int k = (r & 3) + 8 * (r >> 2) + 4 * lhi;
             const float v = gelu_erf(acc[r] + bv);
-            f16 h, l; split_f16(v, h, l, ra);
-            *reinterpret_cast<f16*>(wave_lds + k * RS + c * 2) = h;
-            *reinterpret_cast<f16*>(wave_lds + k * RS + 64 + c * 2) = l;
+            if (p.c_mx) {     // consumer = mlp.fc2 in the f16mx arithmetic (precision f16x3m): [hi 64 B | 32 byte pairs] - same row size
+                f16 h; unsigned short pr; split_mx1<false>(v, ra, h, pr);
+                *reinterpret_cast<f16*>(wave_lds + k * RS + c * 2) = h;
+                *reinterpret_cast<unsigned short*>(wave_lds + k * RS + 64 + c * 2) = pr;
+            } else {
+                f16 h, l; split_f16(v, h, l, ra);
+                *reinterpret_cast<f16*>(wave_lds + k * RS + c * 2) = h;
+                *reinterpret_cast<f16*>(wave_lds + k * RS + 64 + c * 2) = l;
+            }
         }
         const size_t o0 = blk_off<SPLIT>(row0, col - c, p.c_rp);       // first element of the tile's first row block (64 elements per row)
 #pragma unroll
@@ -374,7 +380,8 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
             const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
             const float v = gelu_erf(acc[r] + bv);
             const size_t o = blk_off<SPLIT>(row, col, p.c_rp);
-            if (SPLIT) { f16 h, l; split_f16(v, h, l, ra); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
+            if (SPLIT && p.c_mx) store_mx1<false>(p.C_hi, o, v, ra);
+            else if (SPLIT) { f16 h, l; split_f16(v, h, l, ra); p.C_hi[o] = h; p.C_hi[o + 32] = l; }
             else p.C_hi[o] = to_f16_sat(v, ra);
         }
         return;
@@ -510,7 +517,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const floatx1
         return fmaxf(x, floor_) + pre[r];
     };
     if (EPI == EPI_GELU || EPI == EPI_F16) {
-        if (SPLIT && EPI == EPI_F16 && p.c_mx) {
+        if (SPLIT && p.c_mx) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (ok[r]) store_mx1<false>(p.C_hi, blk_off<SPLIT>(row0 + 4 * lhi + (r & 3) + 8 * (r >> 2), col, p.c_rp), value(r), ra);

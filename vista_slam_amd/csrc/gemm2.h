@@ -20,6 +20,7 @@
 //    resident on one XCD share A / W panels in that XCD's L2.
 #pragma once
 #include "gemm.h"
+#include <type_traits>
 
 typedef short short8 __attribute__((ext_vector_type(8)));
 
@@ -120,7 +121,10 @@ __device__ __forceinline__ void head_epilogue(const GemmParams& p, const floatx1
 // Tail block tb owns the 32 columns [32 tb, 32 tb + 32): its NW waves split K between them, every wave runs one
 // 32x32 MFMA tile straight from global memory (the operands are L2-hot: the main tiles stream the same weights), the
 // partial tiles meet in LDS and wave 0 runs the ordinary epilogue.  ~2-4 us of work per block, dispatched first.
-template <bool SPLIT, int EPI, int NW>
+// MX (round 6, mlp.fc2 in the f16mx arithmetic): the operands are f16mx rows - per K tile two fp16 MFMAs on the hi halves + ONE
+// block-scaled fp8 MFMA on the 32 pair bytes of the lane's half (bytes [64 + 32 lhi, 64 + 32 lhi + 32) of the row block: chunks
+// 4 + 2 lhi, 5 + 2 lhi - exactly what compute_tile's MX branch reads from LDS).
+template <bool SPLIT, int EPI, int NW, bool MX = false>
 __device__ __forceinline__ void gemm2_tail(const GemmParams& p, const int tb, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -140,13 +144,29 @@ __device__ __forceinline__ void gemm2_tail(const GemmParams& p, const int tb, ch
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             f.ah[ks] = ldg16(a + ks * 16); f.bh[ks] = ldg16(b + ks * 16);
-            if (SPLIT) { f.al[ks] = ldg16(a + 32 + ks * 16); f.bl[ks] = ldg16(b + 32 + ks * 16); }
+            if (MX) {           // al / bl: the lane half's 32 pair bytes (two 16-B chunks), ap / bp already carry + lhi * 8 elements
+                f.al[ks] = ldg16(a - lhi * 8 + 32 + lhi * 16 + ks * 8); f.bl[ks] = ldg16(b - lhi * 8 + 32 + lhi * 16 + ks * 8);
+            } else if (SPLIT) { f.al[ks] = ldg16(a + 32 + ks * 16); f.bl[ks] = ldg16(b + 32 + ks * 16); }
         }
     };
     floatx16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     auto mma = [&](const Frag& f) {
+        if constexpr (MX) {
+            typedef int int4v __attribute__((ext_vector_type(4)));
+            typedef int int8v __attribute__((ext_vector_type(8)));
+            union U8 { struct { uint4 x, y; } q; int8v v; } a8, b8;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                H8 ah, bh; ah.u = f.ah[ks]; bh.u = f.bh[ks];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h, bh.h, acc, 0, 0, 0);
+            }
+            a8.q.x = f.al[0]; a8.q.y = f.al[1]; b8.q.x = f.bl[0]; b8.q.y = f.bl[1];
+            constexpr int sc_a = 127 - STA_MX_A_SLO, sc_b = 127 - STA_MX_W_SHI;
+            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8.v, b8.v, acc, 1 /* A: e5m2 */, 0 /* B: e4m3 */, 0, sc_a, 0, sc_b);
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             H8 ah, al, bh, bl; ah.u = f.ah[ks]; bh.u = f.bh[ks];
@@ -200,12 +220,12 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
 
     // skinny tail blocks come first in the grid (launch_gemm2 adds them): short, they overlap the first round of tiles
     int block_id = block_id_in;
-    constexpr bool HAS_TAIL = AMODE == A_DENSE && !MX && NSTG == 2 && ABL_ == 0 && BM >= 192 &&
-                              (EPI == EPI_F32 || EPI == EPI_F32R || EPI == EPI_GELU || EPI == EPI_QKV);
+    constexpr bool HAS_TAIL = AMODE == A_DENSE && NSTG == 2 && ABL_ == 0 && BM >= 192 &&
+                              (EPI == EPI_F32 || EPI == EPI_F32R || ((EPI == EPI_GELU || EPI == EPI_QKV) && !MX));
     if constexpr (HAS_TAIL) {
         if (p.m_tail > 0) {
             const int ntail = (p.N + 31) >> 5;
-            if (block_id < ntail) { gemm2_tail<SPLIT, EPI, NW>(p, block_id, smem); return; }
+            if (block_id < ntail) { gemm2_tail<SPLIT, EPI, NW, MX>(p, block_id, smem); return; }
             block_id -= ntail;
         }
     }
@@ -362,7 +382,11 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
     // (slow, back-pressured) LDS-DMA issue.
     const bool late_dma = (ABL & 8) && !RING && wave >= NW / 2;
     // the arithmetic of ONE K tile held in LDS stage `cur` (kt: its index in this block's slice, for the STAGGER experiment)
-    auto compute_tile = [&](const int cur, const int kt) {
+    // relu_c: the input ReLU of resConfUnit*.conv1 (implicit-GEMM convolutions) as a COMPILE-time constant - the main loop below
+    // exists once per value (round 6: as a wave-uniform runtime flag it was a branch per fragment inside the K tile, and hipcc
+    // schedules nothing across those basic-block boundaries)
+    auto compute_tile = [&](const int cur, const int kt, auto relu_c) {
+        constexpr bool RELU = AMODE == A_CONV3 && decltype(relu_c)::value;
         const char* sA = smem + cur * STAGE;
         const char* sB = sA + A_TILE;
         if (MX) {
@@ -382,7 +406,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     ah[i] = *reinterpret_cast<const half8*>(sA + lds2_off<true>(wm * WM + i * 32 + l31, chunk));
-                    if (AMODE == A_CONV3 && p.relu_in) {      // relu on the f16 hi fragment (packed sign masks, see the f16x3 path)
+                    if (RELU) {      // relu on the f16 hi fragment (packed sign masks, see the f16x3 path)
                         union { half8 h; unsigned u[4]; } t; t.h = ah[i];
 #pragma unroll
                         for (int w = 0; w < 4; ++w) { const unsigned sgn = (t.u[w] >> 15) & 0x00010001u; t.u[w] &= ~((sgn << 16) - sgn); }
@@ -404,7 +428,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
                 const int ra = wm * WM + i * 32 + l31;
                 a8[i].q.x = *reinterpret_cast<const int4v*>(sA + lds2_off<true>(ra, 4 + 2 * lhi));
                 a8[i].q.y = *reinterpret_cast<const int4v*>(sA + lds2_off<true>(ra, 5 + 2 * lhi));
-                if (AMODE == A_CONV3 && p.relu_in) {          // a pair (hi8, lo8) is 16 bits: zero it when hi8 is negative
+                if (RELU) {          // a pair (hi8, lo8) is 16 bits: zero it when hi8 is negative
 #pragma unroll
                     for (int w = 0; w < 8; ++w) { const unsigned u = (unsigned)a8[i].v[w]; const unsigned sgn = (u >> 7) & 0x00010001u; a8[i].v[w] = (int)(u & ~((sgn << 16) - sgn)); }
                 }
@@ -439,7 +463,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
                 a_hi[i] = *reinterpret_cast<const half8*>(sA + lds2_off<SPLIT>(ra, chunk));
                 if (SPLIT) a_lo[i] = *reinterpret_cast<const half8*>(sA + lds2_off<SPLIT>(ra, 4 + chunk));
                 if (AMODE == A_CONV3) {
-                    if (p.relu_in) {   // relu(hi + lo): the sign of hi decides.  Packed-half integer form, 5 VALU per
+                    if (RELU) {   // relu(hi + lo): the sign of hi decides.  Packed-half integer form, 5 VALU per
                         // 32-bit word for both planes (the vector compare scalarises to ~11 per word):
                         // s = sign bits at bit 0 / 16, m = 0xFFFF in every negative half, x &= ~m
                         union { half8 h; unsigned u[4]; } ah, al;
@@ -504,6 +528,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
             if ((ABL & 8) && ks == 0 && late_dma && kt + 1 < nkt) issue_tile(kt0 + kt + 1, cur ^ 1);
         }
     };
+    auto main_loop = [&](auto relu_c) {
     if (RING) {
         // Steady state: every step waits for the same number of younger tiles and issues one more - a fixed wait immediate, an
         // unconditional issue, the stage indices as wrapping counters.  (As ONE loop with the wait count, the issue condition and
@@ -515,7 +540,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTG - 2) * GPW) : "memory");      // tile kt landed; every wave finished tile kt-1
             if (p.stamps && kt == 0) st1 = __builtin_amdgcn_s_memrealtime();
             if (!(ABL & 1)) issue_tile(kt0 + kt + NSTG - 1, nxt);                                    // into the stage tile kt-1 left
-            compute_tile(cur, kt);
+            compute_tile(cur, kt, relu_c);
             cur = cur + 1 == NSTG ? 0 : cur + 1;
             nxt = nxt + 1 == NSTG ? 0 : nxt + 1;
         }
@@ -526,18 +551,23 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
             else if (rem == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * GPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * GPW) : "memory");
             if (p.stamps && kt == 0) st1 = __builtin_amdgcn_s_memrealtime();
-            compute_tile(cur, kt);
+            compute_tile(cur, kt, relu_c);
             cur = cur + 1 == NSTG ? 0 : cur + 1;
         }
     } else {
         for (int kt = 0; kt < nkt; ++kt) {
             const int cur = kt & 1;
             if (kt + 1 < nkt && !(ABL & 1) && !late_dma) issue_tile(kt0 + kt + 1, cur ^ 1);
-            compute_tile(cur, kt);
+            compute_tile(cur, kt, relu_c);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
     }
+    };
+    if constexpr (AMODE == A_CONV3) {
+        if (p.relu_in) main_loop(std::integral_constant<bool, true>{});
+        else main_loop(std::integral_constant<bool, false>{});
+    } else main_loop(std::integral_constant<bool, false>{});
 
     if (p.stamps) {      // after the LAST MFMA has delivered (the stamp is scalar code: without the data dependence it is scheduled early)
         asm volatile("" ::"v"(acc[MT - 1][NT - 1][15]), "v"(acc[0][0][0]) : "memory");

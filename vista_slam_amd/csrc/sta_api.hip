@@ -62,7 +62,7 @@ static inline Planes slice_rows(const Planes& p, int64_t r0) {
 // layer classes of the precision policy: the DPT head's convolutions may run "f16 main product + one block-scaled fp8 correction
 // MFMA" (the f16mx arithmetic, sta_common.h; precision f16x3h); the transformer and the pose head never do (round 3: the
 // all-layers form failed the stress goldens and was retired)
-enum { CLS_NONE = 0, CLS_HEAD = 16 /* DPT head convolutions */ };
+enum { CLS_NONE = 0, CLS_HEAD = 16 /* DPT head convolutions */, CLS_FC2 = 32 /* mlp.fc2 of both transformers (precision f16x3m) */ };
 struct Lin { Planes w; Planes wmx; float* bias = nullptr; int N = 0, K = 0; int cls = CLS_NONE; };   // wmx: second packed copy in the f16mx row format (head only)
 struct LNp { float* g = nullptr; float* b = nullptr; };
 struct EncBlk { LNp n1, n2; Lin qkv, proj, fc1, fc2; };
@@ -326,7 +326,7 @@ static int build_schema(sta_handle* h) {
         CHK(reg_linear(h, p + "attn.proj", b.proj, E, E));
         CHK(reg_ln(h, p + "norm2", b.n2, E));
         CHK(reg_linear(h, p + "mlp.fc1", b.fc1, R * E, E));
-        CHK(reg_linear(h, p + "mlp.fc2", b.fc2, E, R * E));
+        CHK(reg_linear(h, p + "mlp.fc2", b.fc2, E, R * E, true, CLS_FC2));
     }
     CHK(reg_ln(h, "enc_norm", h->enc_norm, E));   // only applied by _encode_image(normalize=True) (sta_model.py:172-173); the forward / SLAM paths pass False
     CHK(reg_linear(h, "decoder_embed", h->dec_embed, D, E));
@@ -348,7 +348,7 @@ static int build_schema(sta_handle* h) {
         CHK(reg_ln(h, p + "norm2", b.n2, D));
         CHK(reg_ln(h, p + "norm3", b.n3, D));
         CHK(reg_linear(h, p + "mlp.fc1", b.fc1, R * D, D));
-        CHK(reg_linear(h, p + "mlp.fc2", b.fc2, D, R * D));
+        CHK(reg_linear(h, p + "mlp.fc2", b.fc2, D, R * D, true, CLS_FC2));
         CHK(reg_ln(h, p + "norm_y", b.ny, D));
     }
     CHK(reg_ln(h, "dec_norm", h->dec_norm, D));
@@ -398,8 +398,9 @@ static int build_schema(sta_handle* h) {
 
 // ------------------------------------------------------------------------------------------ API: lifecycle
 static int mask_of_precision(int prec) {
-    return prec == STA_PREC_F16X3H ? CLS_HEAD : 0;
+    return prec == STA_PREC_F16X3H ? CLS_HEAD : (prec == STA_PREC_F16X3M ? (CLS_HEAD | CLS_FC2) : 0);
 }
+static bool known_precision(int p) { return p == STA_PREC_F16 || p == STA_PREC_F16X3 || p == STA_PREC_F16X3H || p == STA_PREC_F16X3M; }
 
 extern "C" void sta_default_config(sta_config* c) {
     c->patch_size = 16; c->enc_embed_dim = 1024; c->enc_depth = 24; c->enc_num_heads = 16;
@@ -418,7 +419,7 @@ extern "C" int sta_create(const sta_config* cfg, int device, sta_handle** out) {
     REQUIRE(cfg->enc_embed_dim % 128 == 0 && cfg->enc_embed_dim <= 1024, "enc_embed_dim must be a multiple of 128, <= 1024");
     REQUIRE(cfg->dec_embed_dim % 128 == 0 && cfg->dec_embed_dim <= 1024, "dec_embed_dim must be a multiple of 128, <= 1024");
     REQUIRE(cfg->dec_depth > 9, "dec_depth must be > 9 (heads/dpt_head.py:102)");
-    REQUIRE(cfg->precision == STA_PREC_F16 || cfg->precision == STA_PREC_F16X3 || cfg->precision == STA_PREC_F16X3H, "unknown precision %d", cfg->precision);
+    REQUIRE(known_precision(cfg->precision), "unknown precision %d", cfg->precision);
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     REQUIRE(device >= 0 && device < ndev, "device %d out of range (%d visible)", device, ndev);
@@ -473,7 +474,7 @@ extern "C" int sta_destroy(sta_handle* h) {
 
 extern "C" int sta_set_precision(sta_handle* h, int precision) {
     REQUIRE(h, "null handle");
-    REQUIRE(precision == STA_PREC_F16 || precision == STA_PREC_F16X3 || precision == STA_PREC_F16X3H, "unknown precision %d", precision);
+    REQUIRE(known_precision(precision), "unknown precision %d", precision);
     h->prec = precision; h->mx_mask = mask_of_precision(precision);
     return 0;
 }
