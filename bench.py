@@ -147,6 +147,10 @@ def slam_replay(model, dev, frames=120, warm=12, res=(224, 224), src_hw=(480, 64
         placement = {"source": "sta_pipeline_streams (library-owned, pairwise overlap measured by a spin probe)",
                      "verified_concurrent": model.pipeline_streams_verified}
     enc_stream, edge_streams = streams[0], list(streams[1:3])
+    # everything the replay's calls will need on its streams, allocated NOW (sta_reserve): one 224x224 frame, up to
+    # neighbor_edge_num + loop_edge_num candidate edges per keyframe, the current stream (single-stream schedule) and the three lanes.
+    # (The f3 input step and the f4 cloud size themselves lazily: tables per source geometry / workspace per view count.)
+    model.reserve(1, Hr, Wr, max_edges=neighbor_edge_num + loop_edge_num, streams=[torch.cuda.current_stream(dev)] + list(streams[:3]))
 
     def run(nf, thres, pipelined):
         from vista_slam_amd.keyframe_pipeline import replay
@@ -206,8 +210,9 @@ def slam_replay(model, dev, frames=120, warm=12, res=(224, 224), src_hw=(480, 64
         ms["f4"] = t4.elapsed_time(t5)
         return ms, stats, npts, len(ids)
 
-    _, st_w, _, _ = run(warm, -1.0, False)                               # warm-up: workspace, tables, threshold
-    run(warm, -1.0, True)                                                # ... and the lanes' scratch contexts
+    _, st_w, _, _ = run(warm, -1.0, False)                               # warm-up: f3 tables, threshold (the workspaces are reserved)
+    run(warm, -1.0, True)
+    alloc_after_warmup = model.alloc_stats()
     conf = sorted(st_w["nonadj_conf"])
     thres = conf[int(0.4 * len(conf))] if conf else -1.0
     torch.cuda.synchronize()
@@ -224,9 +229,11 @@ def slam_replay(model, dev, frames=120, warm=12, res=(224, 224), src_hw=(480, 64
         ms, st, npts, nviews = run(frames, thres, True)
         dts.append(time.perf_counter() - t0)
     dt = dts[-1]
+    alloc_end = model.alloc_stats()
     nonadj = len(st["nonadj_conf"])
     return {"frames": frames, "keyframes_per_s": round(frames / dt, 2), "ms_per_keyframe": round(dt / frames * 1e3, 3),
             "first_pass_keyframes_per_s": round(frames / dts[0], 2), "stream_placement": placement,
+            "library_allocations_and_device_syncs_during_the_three_measured_passes": [alloc_end[0] - alloc_after_warmup[0], alloc_end[1] - alloc_after_warmup[1]],
             "same_result_as_single_stream": bool(npts == npts_s and st["rejected"] == st_s["rejected"] and st["edges"] == st_s["edges"]),
             "schedule": "three streams: f3 + encode of keyframe i+1 | decode + pose heads of keyframe i's edges (regress_views_begin) | DPT heads, "
                         "reductions and node bookkeeping of keyframe i-1 (regress_views_finish); one library scratch context per stream",
@@ -556,6 +563,8 @@ def main():
 
     model = STAFrontend(Wt.FULL, dev, precision=args.precision).load_procedural(seed=43)      # sta_create(device = LOCAL_RANK)
     B = args.pairs
+    model.reserve(B, H, W_)          # workspace, scratch context and side lane of this stream up front: no call below allocates (sta_reserve)
+    alloc_reserved = model.alloc_stats()
     imgs = Wt.synth_images(2 * B, H, W_, seed=43, tag=rank)          # different pairs on every rank
     img_a = torch.from_numpy(imgs[:B]).to(dev)
     img_b = torch.from_numpy(imgs[B:]).to(dev)
@@ -586,7 +595,9 @@ def main():
         from vista_slam_amd import _lib
         _lib.check(model.lib.sta_kernel_timing_filter(model._h, dom["epi"], dom["amode"], dom["fam"], dom["mx"], args.timed_every))
         model.kernel_timing(3)
+    alloc_before = model.alloc_stats()
     dt, step_ms, out = timed_region(runner, args.steps)
+    alloc_after = model.alloc_stats()
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     dist_fields = None
     if use_dist:
@@ -643,6 +654,10 @@ def main():
                "gflop_per_pair": round(flops_pair / 1e9, 2),
                "whole_path_tflops": round(pairs * flops_pair / dt / 1e12, 1),
                "workspace_gb": round(model.workspace_bytes() / 1e9, 2),
+               # sta_alloc_stats: (allocations / frees / stream + event creations, device-wide synchronisations) of the library's compute
+               # entry points - everything was reserved before the first step (sta_reserve), the timed region adds nothing
+               "hidden_allocations": {"after_sta_reserve": list(alloc_reserved), "added_by_warmup_and_survey": [alloc_before[0] - alloc_reserved[0], alloc_before[1] - alloc_reserved[1]],
+                                      "added_inside_timed_region": [alloc_after[0] - alloc_before[0], alloc_after[1] - alloc_before[1]]},
                "roofline": roof}
         if use_dist:
             res.update(dist_fields)

@@ -9,6 +9,12 @@ array that exists on both sides must not move by one bit).
     python oracle/check_oracle_vs_ref.py                       # a quick default selection (~1 min)
     python oracle/check_oracle_vs_ref.py tiny stress full224   # any case groups of gen_golden.CASES / SEQ_CASES (seq, seqfull)
     python oracle/check_oracle_vs_ref.py --update tiny         # additionally copy fixtures that only GAINED keys
+    python oracle/check_oracle_vs_ref.py ckpt                  # the real-checkpoint kit on a STAND-IN file (below; ~10 min)
+
+`ckpt`: torch.save({'model': procedural full-architecture weights}) -> `gen_golden.gen_checkpoint(file)` (what
+`python oracle/gen_golden.py --checkpoint FILE` runs) -> the three fixtures it writes must be bit-identical, array by array, to the
+committed fixtures of the same weights handed over directly: ckpt_224_b1 == full_224_b1, ckpt_384x512_b1 == full_384x512_b1,
+seq_tum_ckpt_224 == seq_tum_full_224_t075.  The file path of the kit is proven on everything but the real download.
 """
 import os
 import shutil
@@ -36,6 +42,32 @@ def compare(old_path, new_path):
     return same, diff, [k for k in b.files if k not in a.files], [k for k in a.files if k not in b.files]
 
 
+def check_checkpoint_kit(scratch):
+    """The real-checkpoint acceptance kit on a stand-in checkpoint file holding the procedural weights."""
+    import torch
+    from oracle import gen_golden as G
+    from vista_slam_amd import weights as W
+    sd = W.state_dict(W.FULL, seed=43)
+    path = os.path.join(scratch, "standin_frontend_sta_weights.pth")
+    torch.save({"model": {k: torch.from_numpy(v.copy()) for k, v in sd.items()}, "epoch": 0}, path)
+    fp = W.state_dict_fingerprint(sd)
+    del sd
+    print(f"[check] stand-in checkpoint {path}: {os.path.getsize(path) / 1e9:.2f} GB, fingerprint {fp[:16]}...", flush=True)
+    G.gen_checkpoint(path, tag="ckpt", cfg=W.FULL)
+    os.remove(path)
+    bad = 0
+    for new, old in (("ckpt_224_b1", "full_224_b1"), ("ckpt_384x512_b1", "full_384x512_b1"), ("seq_tum_ckpt_224", "seq_tum_full_224_t075")):
+        same, diff, gained, lost = compare(os.path.join(GOLDEN, old + ".npz"), os.path.join(scratch, new + ".npz"))
+        z = np.load(os.path.join(scratch, new + ".npz"))
+        ok = not diff and not lost and str(z["ckpt_fingerprint"]) == fp
+        print(f"[check] {new}.npz (from the FILE) vs committed {old}.npz: {same} arrays bit-identical, {len(diff)} differ {diff}, "
+              f"gained {[k for k in gained if not k.startswith('range_')][:6]} (+{sum(k.startswith('range_') for k in gained)} range_* arrays), lost {lost}, "
+              f"fingerprint {'matches' if str(z['ckpt_fingerprint']) == fp else 'DIFFERS'} -> {'OK' if ok else 'MISMATCH'}")
+        bad += 0 if ok else 1
+    print(open(os.path.join(scratch, "ckpt_ranges.txt")).read())
+    return bad
+
+
 def main(argv):
     update = "--update" in argv
     groups = [a for a in argv if not a.startswith("--")] or ["tiny", "full224"]
@@ -47,6 +79,10 @@ def main(argv):
     torch.set_num_threads(os.cpu_count())
     bad = 0
     for grp in groups:
+        if grp == "ckpt":
+            G.OUT = scratch
+            bad += check_checkpoint_kit(scratch)
+            continue
         for c in (G.CASES.get(grp) or G.SEQ_CASES[grp]):
             G.run_any(c)
             name = c["name"] + ".npz"
