@@ -1,6 +1,6 @@
 """CPU: the tile-family rules against the measured table.
 
-profiles/r03_tile_table.txt (tools/tile_table.py, MI355X) holds, for every GEMM / convolution shape of the forward at
+profiles/r06_tile_table.txt (tools/tile_table.py, MI355X; re-measured in round 6 after the convolution-loop and fused-tail changes) holds, for every GEMM / convolution shape of the forward at
 B in {1, 2, 4, 8} x {224x224, 384x512}, the in-model launch duration under the product's choice and under every forced tile
 family.  launch_gemm's choice is a pure host function (sta_launch.inc: pick_family, exported as sta_debug_pick_family) - so this
 test needs no GPU: it replays every row through the CURRENT library and asserts
@@ -15,7 +15,7 @@ import re
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TABLE = os.path.join(ROOT, "profiles", "r03_tile_table.txt")
+TABLE = os.path.join(ROOT, "profiles", "r06_tile_table.txt")
 EPI = {"f32": 0, "f16": 1, "qkv": 2, "convT": 3, "gelu": 4, "f32r": 5, "head": 6}
 
 

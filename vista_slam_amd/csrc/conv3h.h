@@ -43,6 +43,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3h_kernel(const Gem
     constexpr int NSB = BN / RPS, SB = (NSB + NW - 1) / NW;
     static_assert((NW & (NW - 1)) == 0 && HPS <= NW && WM % 32 == 0 && WN % 32 == 0 && (!MX || SPLIT), "conv3h tile / wave mismatch");
     static_assert(EPI == EPI_F16 || EPI == EPI_HEAD, "conv3h: plane epilogue or the fused DPT tail");
+    // fused DPT tail: the MFMAs run with their operands swapped - the accumulator tiles come out TRANSPOSED (lane = pixel, register =
+    // channel), which is the layout head.4's contraction over the channels wants as an MFMA operand (head_epilogue_t, gemm2.h)
+    constexpr bool TRN = EPI == EPI_HEAD && NT == 1;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -176,7 +179,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3h_kernel(const Gem
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = TRN ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
             }
             union U8 { struct { int4v x, y; } q; int8v v; };
             U8 a8[MT], b8[NT];
@@ -200,7 +204,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3h_kernel(const Gem
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i].v, b8[j].v, acc[i][j], 1 /* A: e5m2 */, 0 /* B: e4m3 */, 0, sc_a, 0, sc_b);
+                    acc[i][j] = TRN ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[j].v, a8[i].v, acc[i][j], 0 /* A: e4m3 weights */, 1 /* B: e5m2 */, 0, sc_b, 0, sc_a)
+                                   : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i].v, b8[j].v, acc[i][j], 1 /* A: e5m2 */, 0 /* B: e4m3 */, 0, sc_a, 0, sc_b);
         } else {
             half8 a_hi[MT], a_lo[MT], b_hi[NT], b_lo[NT];
 #pragma unroll
@@ -234,18 +239,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3h_kernel(const Gem
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
                         for (int j = 0; j < NT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = TRN ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi[j], a_lo[i], acc[i][j], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
                         for (int j = 0; j < NT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = TRN ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b_lo[j], a_hi[i], acc[i][j], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
                 }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = TRN ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi[j], a_hi[i], acc[i][j], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -262,7 +267,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3h_kernel(const Gem
     if constexpr (EPI == EPI_HEAD) {
         if constexpr (BN == 128) {
             const int rows_valid = p.Ho - y0 < TR ? p.Ho - y0 : TR;
-            head_epilogue<BM, MT, NT, WM, WAVES_N>(p, acc, (int64_t)(img * p.Ho + y0) * p.Wo + x0, p.Wo, rows_valid, cols_valid, wm, wn, tid, smem);
+            if constexpr (TRN) head_epilogue_t<BM, MT, WM, WAVES_N>(p, acc, (int64_t)(img * p.Ho + y0) * p.Wo + x0, p.Wo, rows_valid, cols_valid, wm, wn, tid, smem);
+            else head_epilogue<BM, MT, NT, WM, WAVES_N>(p, acc, (int64_t)(img * p.Ho + y0) * p.Wo + x0, p.Wo, rows_valid, cols_valid, wm, wn, tid, smem);
         }
     } else {
 #pragma unroll

@@ -115,6 +115,91 @@ __device__ __forceinline__ void head_epilogue(const GemmParams& p, const floatx1
     }
 }
 
+// EPI_HEAD for TRANSPOSED accumulators (conv3h.h, round 6): the halo kernel issues its MFMAs with the operands swapped when its
+// epilogue is the fused DPT tail, so an accumulator tile holds (32 channels) x (32 pixels) - lane = pixel, register r = channel
+// (r & 3) + 8 (r >> 2) + 4 lhi of the wave's 32-channel block, the same interleave the attention kernel's score tile has for its
+// keys.  head.4 (1x1 conv 128 -> 4) is then ONE more contraction over the channels, on the matrix pipe: relu(acc + bias) becomes the
+// B operand (k = channel, n = pixel; two fp16 planes, regrouped to the natural k order by a v_permlane32_swap per register pair
+// exactly like P^T in attention.h), the A operand is head.4's weight [4 outputs, zero-padded to 32][32 channels] as fp16 hi / lo:
+// 6 MFMAs per 32-pixel tile instead of 64 FMAs + a 62-shuffle butterfly on the accumulator-holding waves (7.4 us of a 51-us
+// workgroup with nothing resident beside it to hide them).  Lanes 0-31 end up with the four partial outputs of pixel l31 over the
+// wave's 32 channels; the four channel waves meet in LDS and BM threads apply the activations as before.
+template <int BM, int MT, int WM, int WAVES_N>
+__device__ __forceinline__ void head_epilogue_t(const GemmParams& p, const floatx16 (&acc)[MT][1], int64_t pix_base, int rstride, int rows_valid,
+                                                int cols_valid, int wm, int wn, int tid, char* smem) {
+    float* red = reinterpret_cast<float*>(smem);                 // [WAVES_N][BM][4]
+    const int lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+    float bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bv[r] = p.bias ? p.bias[wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi] : 0.f;
+    // A fragments of head.4: lane l31 = output row (valid below 4), 8 consecutive channels 16 w + 8 lhi .. + 7 of the wave's block
+    half8 wh[2], wl[2];
+    {
+        RangeAcc rw;
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = l31 < 4 ? p.hw4[l31 * 128 + wn * 32 + 16 * w + 8 * lhi + e] : 0.f;
+                f16 h_, l_; split_f16(x, h_, l_, rw);
+                wh[w][e] = h_; wl[w][e] = l_;
+            }
+    }
+    __syncthreads();                                             // every wave has left the operand stages
+    RangeAcc ra;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        floatx16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            union { half8 h; unsigned u[4]; } ph, pl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = fmaxf(acc[i][0][8 * w + e] + bv[8 * w + e], 0.f);
+                f16 h_, l_; split_f16(v, h_, l_, ra);
+                ph.h[e] = h_; pl.h[e] = l_;
+            }
+            // u[0..1] = registers 8w .. 8w+3 (channels 16w + 4 lhi + 0..3), u[2..3] = 8w+4 .. 8w+7 (16w + 8 + 4 lhi + 0..3): after the
+            // swap half 0 holds channels 16w .. 16w+7 and half 1 holds 16w+8 .. 16w+15, in k order (attention.h, P^T)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                auto r1 = __builtin_amdgcn_permlane32_swap(ph.u[e], ph.u[2 + e], false, false);
+                ph.u[e] = r1[0]; ph.u[2 + e] = r1[1];
+                auto r2 = __builtin_amdgcn_permlane32_swap(pl.u[e], pl.u[2 + e], false, false);
+                pl.u[e] = r2[0]; pl.u[2 + e] = r2[1];
+            }
+            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[w], ph.h, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[w], pl.h, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[w], ph.h, o, 0, 0, 0);
+        }
+        // rows 0..3 of the result tile = registers 0..3 of lane half 0: the four outputs of pixel l31
+        if (lhi == 0) *reinterpret_cast<float4*>(red + ((size_t)wn * BM + wm * WM + i * 32 + l31) * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    ra.flush(p.range);
+    __syncthreads();
+    if (tid < BM) {
+        const int64_t pix = pix_base + (int64_t)(tid >> 5) * rstride + (tid & 31);
+        if (pix < p.M && (tid >> 5) < rows_valid && (tid & 31) < cols_valid) {
+            float4 a = *reinterpret_cast<const float4*>(red + (size_t)tid * 4);
+#pragma unroll
+            for (int w = 1; w < WAVES_N; ++w) {
+                const float4 b = *reinterpret_cast<const float4*>(red + ((size_t)w * BM + tid) * 4);
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+            const float x = a.x + p.hb4[0], y = a.y + p.hb4[1], z = a.z + p.hb4[2], c = a.w + p.hb4[3];
+            const float d = sqrtf(x * x + y * y + z * z);
+            const float sc = expm1f(d) / fmaxf(d, 1e-8f);
+            const bool second = pix >= p.hsplit;
+            const int64_t q = second ? pix - p.hsplit : pix;
+            float* pts = (second ? p.hptsB : p.hptsA) + q * 3;
+            pts[0] = x * sc; pts[1] = y * sc; pts[2] = z * sc;
+            (second ? p.hconfB : p.hconfA)[q] = 1.0f + expf(c);
+        }
+    }
+}
+
 // Skinny tail of a dense GEMM (GemmParams::m_tail <= 32 rows after a whole number of BM-row tiles; the decoder's M = 2B x
 // (768 patch tokens) + 2B pose tokens is 64 tiles of 192 rows + 16 rows).  A tile row of their own would cost every N tile a
 // BM-row tile for 16 rows - and, worse, a whole extra round of the 512 resident slots (65 x 24 tiles = 3.05 rounds).
@@ -217,6 +302,9 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
     constexpr int SA = (NSA + NW - 1) / NW, SB = (NSB + NW - 1) / NW;
     constexpr int A_ES = SPLIT ? 64 : 32;                    // global elements per activation row block
     static_assert(BM % 32 == 0 && BN % 32 == 0 && WM % 32 == 0 && WN % 32 == 0, "tile/wave mismatch");
+    // fused DPT tail (EPI_HEAD, BN == 128 == N, one 32-channel block per wave): the MFMAs run with their operands swapped, the
+    // accumulator tiles come out TRANSPOSED (lane = pixel, register = channel) - what head_epilogue_t contracts on the matrix pipe
+    constexpr bool TRN = EPI == EPI_HEAD && BN == 128 && NT == 1;
 
     // skinny tail blocks come first in the grid (launch_gemm2 adds them): short, they overlap the first round of tiles
     int block_id = block_id_in;
@@ -419,7 +507,8 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = TRN ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0)
+                                        : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
             }
             union U8 { struct { int4v x, y; } q; int8v v; };
             U8 a8[MT], b8[NT];
@@ -444,7 +533,8 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i].v, b8[j].v, acc[i][j], 1 /* A: e5m2 */, 0 /* B: e4m3 */, 0, sc_a, 0, sc_b);
+                    acc[i][j] = TRN ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[j].v, a8[i].v, acc[i][j], 0 /* A: e4m3 weights */, 1 /* B: e5m2 */, 0, sc_b, 0, sc_a)
+                                    : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i].v, b8[j].v, acc[i][j], 1 /* A: e5m2 */, 0 /* B: e4m3 */, 0, sc_a, 0, sc_b);
             return;
         }
         half8 a_hi[MT], a_lo[MT], b_hi[NT], b_lo[NT];
@@ -513,18 +603,18 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = TRN ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi[j], a_lo[i], acc[i][j], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = TRN ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b_lo[j], a_hi[i], acc[i][j], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = TRN ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi[j], a_hi[i], acc[i][j], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
             if ((ABL & 8) && ks == 0 && late_dma && kt + 1 < nkt) issue_tile(kt0 + kt + 1, cur ^ 1);
         }
     };
@@ -574,7 +664,10 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const int block_
         st2 = __builtin_amdgcn_s_memrealtime();
     }
     if constexpr (EPI == EPI_HEAD) {
-        if constexpr (BN == 128) head_epilogue<BM, MT, NT, WM, WAVES_N>(p, acc, m0, 32, BM / 32, 32, wm, wn, tid, smem);
+        if constexpr (BN == 128) {
+            if constexpr (TRN) head_epilogue_t<BM, MT, WM, WAVES_N>(p, acc, m0, 32, BM / 32, 32, wm, wn, tid, smem);
+            else head_epilogue<BM, MT, NT, WM, WAVES_N>(p, acc, m0, 32, BM / 32, 32, wm, wn, tid, smem);
+        }
     } else {
         // EPI_QKV / EPI_GELU / EPI_F16: a private LDS scratch per wave for the epilogue's transposes (the stage buffers are free)
         // (two stages: every wave is past the last barrier of the main loop.  The ring form has no barrier behind its last K tile:
