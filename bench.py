@@ -518,7 +518,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default="f16x3h", choices=["f16x3h", "f16x3"])
+    ap.add_argument("--precision", default="f16x3h", choices=["f16x3h", "f16x3", "f16x3m"],
+                    help="f16x3h = the default policy; f16x3m (opt-in, +2 %%): additionally mlp.fc2 in the f16mx arithmetic - holds every full-architecture "
+                         "golden at <= 8.1e-5 but not two of the ten tiny stress sets (DESIGN.md section 2)")
     ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="image pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-224", action="store_true", help="time the oracle on one 224x224 pair (4.3x less work) instead of 512x384")
@@ -645,7 +647,8 @@ def main():
                "value_at_median_step": round(B * world / (median_ms * 1e-3), 3),
                "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": {"f16x3": "f16x3-split MFMA (3 fp16 products per contraction), fp32 accumulate",
-                                             "f16x3h": "f16x3-split MFMA (3 fp16 products) in the transformer and the pose head; fp16 MFMA + one block-scaled fp8 correction MFMA in the DPT head's convolutions; fp32 accumulate"}[args.precision],
+                                             "f16x3h": "f16x3-split MFMA (3 fp16 products) in the transformer and the pose head; fp16 MFMA + one block-scaled fp8 correction MFMA in the DPT head's convolutions; fp32 accumulate",
+                                             "f16x3m": "OPT-IN policy, not the default: f16x3h + mlp.fc2 of both transformers as fp16 MFMA + one block-scaled fp8 correction MFMA; fp32 accumulate"}[args.precision],
                "data": "synthetic (uint8-uniform RGB pairs, procedural weights of the full 438M-parameter architecture)",
                "config": {"workload": f"512x384 batch={B} pairs/GPU STA two-view forward (BASELINE configs[1])",
                           "pairs_per_gpu": B, "H": H, "W": W_, "precision": args.precision,

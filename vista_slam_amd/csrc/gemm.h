@@ -72,6 +72,7 @@ struct GemmParams {
     int ct_k, ct_cout, ct_h, ct_w;
     // ---- EPI_HEAD: head.4 weights [4][128] / bias [4] (fp32); pixels [0, hsplit) -> (hptsA, hconfA), the rest -> (hptsB, hconfB)
     const float* hw4; const float* hb4; float* hptsA; float* hconfA; float* hptsB; float* hconfB; int64_t hsplit;
+    float hw4_scale[4] = {1.f, 1.f, 1.f, 1.f};           // powers of two, one per output row: head_epilogue_t splits hw4[o][:] * hw4_scale[o] into fp16 planes and divides the sums by it
     // ---- misc
     const f16* zero_page;                                // >= 64 B of zeros (OOB taps of the direct-to-LDS conv loader)
     unsigned long long* clk_dbg = nullptr;               // bench only: block 0 stores {shader cycles, 100 MHz ticks} of its lifetime

@@ -140,7 +140,7 @@ __device__ __forceinline__ void head_epilogue_t(const GemmParams& p, const float
         for (int w = 0; w < 2; ++w)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float x = l31 < 4 ? p.hw4[l31 * 128 + wn * 32 + 16 * w + 8 * lhi + e] : 0.f;
+                const float x = l31 < 4 ? p.hw4[l31 * 128 + wn * 32 + 16 * w + 8 * lhi + e] * p.hw4_scale[l31 & 3] : 0.f;       // (exact: a power of two into [0.5, 1))
                 f16 h_, l_; split_f16(x, h_, l_, rw);
                 wh[w][e] = h_; wl[w][e] = l_;
             }
@@ -175,7 +175,8 @@ __device__ __forceinline__ void head_epilogue_t(const GemmParams& p, const float
             o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[w], ph.h, o, 0, 0, 0);
         }
         // rows 0..3 of the result tile = registers 0..3 of lane half 0: the four outputs of pixel l31
-        if (lhi == 0) *reinterpret_cast<float4*>(red + ((size_t)wn * BM + wm * WM + i * 32 + l31) * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        if (lhi == 0) *reinterpret_cast<float4*>(red + ((size_t)wn * BM + wm * WM + i * 32 + l31) * 4) =
+            make_float4(o[0] / p.hw4_scale[0], o[1] / p.hw4_scale[1], o[2] / p.hw4_scale[2], o[3] / p.hw4_scale[3]);
     }
     ra.flush(p.range);
     __syncthreads();

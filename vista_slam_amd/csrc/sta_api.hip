@@ -121,6 +121,7 @@ struct sta_handle {
     Lin act0_0, act0_1, act1_0, act1_1, act2_0, act3_0, act3_1;
     Lin rn[4]; Refine ref[4];      // ref[0] = refinenet1 ... ref[3] = refinenet4
     Lin head0, head2; F32Lin head4;
+    float head4_scale[4] = {1.f, 1.f, 1.f, 1.f};   // per output row of head.4: the power of two that brings its largest |weight| into [0.5, 1) - the fused tail contracts fp16 hi / lo planes of the SCALED rows (sta_finalize_weights)
     F32Lin pm0, pm1, pm2, pt, pr, pc;
     // staging + workspace
     float* stage = nullptr; int64_t stage_elems = 0;
@@ -558,6 +559,21 @@ extern "C" int sta_finalize_weights(sta_handle* h) {
         REQUIRE(kv.second.loaded, "missing key in state_dict: %s", kv.first.c_str());
     DEV_SCOPE(h->device);
     HIPCHK(hipDeviceSynchronize());
+    {   // head.4 (1x1 conv 128 -> 4) enters the fused DPT tail as fp16 hi / lo planes (head_epilogue_t, gemm2.h).  Its values can be far
+        // below fp16's normal range (a checkpoint whose DPT feature maps are large has correspondingly small head.4 weights: the outlier
+        // goldens scale them by 1/300 -> 1e-5, subnormal in fp16, 1e-3 relative error) - so they are split AFTER an exact power-of-two
+        // scaling into [0.5, 1) and the result is scaled back
+        std::vector<float> w4(4 * 128);
+        HIPCHK(hipMemcpy(w4.data(), h->head4.w, w4.size() * 4, hipMemcpyDeviceToHost));
+        for (int o = 0; o < 4; ++o) {
+            float mx = 0.f;
+            for (int c = 0; c < 128; ++c) mx = fmaxf(mx, fabsf(w4[o * 128 + c]));
+            int e = 0;
+            if (mx > 0.f && std::isfinite(mx)) (void)frexpf(mx, &e);        // mx = f * 2^e, f in [0.5, 1)
+            if (e > 100) e = 100; if (e < -100) e = -100;
+            h->head4_scale[o] = ldexpf(1.0f, -e);
+        }
+    }
     h->finalized = true;
     return 0;
 }
