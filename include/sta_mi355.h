@@ -172,7 +172,9 @@ STA_API int sta_set_side_lanes(sta_handle* h, int mode);
  * counters live in the handle since round 4 - two handles on one GPU no longer see each other's events; the call
  * synchronises the device).  QKV / attention / mlp.fc1 outputs
  * are bounded by their LayerNorm inputs and are not counted (0.7 % of the step if they were).  A non-zero counts[0] means the
- * forward left the range the parity goldens cover - the reference (fp32) has no such limit.  reset != 0 clears them. */
+ * forward left the range the parity goldens cover - the reference (fp32) has no such limit.  reset != 0 clears them.
+ * counts[0] also includes, permanently, the number of loaded MFMA-operand weight tensors whose EVERY value is below 2^-12 in
+ * magnitude (not all zero): such a tensor would enter the matrix pipe as fp16 subnormals (the LOW end of the range). */
 STA_API int sta_range_report(sta_handle* h, unsigned long long counts[2], int reset);
 
 /* Number of state_dict entries the handle expects / has received so far. */

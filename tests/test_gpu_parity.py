@@ -1486,3 +1486,23 @@ def test_batch8_stress_weights_on_the_throughput_kernels(G, case):
     assert rel_l2(m1["pts3d_pred"].cpu().numpy(), main["pts3d_pred"][i:i + 1].cpu().numpy()) < 1e-4
     assert rel_l2(s1["relative_pose"].cpu().numpy(), supp["relative_pose"][i:i + 1].cpu().numpy()) < 1e-4
     print(f"[b8 stress] {case}: " + " ".join(f"{k}={v:.1e}" for k, v in sorted(errs.items())))
+
+
+def test_tiny_weight_tensor_is_reported(G):
+    """The low end of the fp16 range: a packed weight tensor whose every value is below 2^-12 (its operand planes would be fp16
+    subnormals) shows up in the range report - permanently, as a property of the loaded weights - and disappears when the slot is
+    loaded with ordinary values again; an all-zero tensor is not an event."""
+    import numpy as np
+    from vista_slam_amd import weights as W
+    from vista_slam_amd.sta_frontend import STAFrontend
+    sd = W.state_dict(W.TINY, seed=43)
+    key = "enc_blocks.0.mlp.fc2.weight"
+    m = STAFrontend(W.TINY, "cuda:0").load_state_dict(sd, strict=True)
+    assert m.range_report() == (0, 0)
+    m._load_one(key, sd[key] * np.float32(1e-6))
+    assert m.range_report() == (1, 0) and m.range_report() == (1, 0)          # survives the reset
+    m._load_one(key, np.zeros_like(sd[key]))
+    assert m.range_report() == (0, 0)
+    m._load_one(key, sd[key] * np.float32(1e-6))
+    m._load_one(key, sd[key])
+    assert m.range_report() == (0, 0)

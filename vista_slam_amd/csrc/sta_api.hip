@@ -81,6 +81,7 @@ struct Slot {
     int reps = 1;                    // SK_B_CONVT: k*k
     int64_t N = 0, K = 0, n_off = 0; // packed-weight geometry: rows of the whole Lin, contraction length, row offset
     bool loaded = false;
+    bool loaded_tiny = false;        // the tensor last loaded into this slot was all below 2^-12 (sta_load_tensor)
 };
 
 static const int KSTAMP_WG = 2048, KSTAMP_LAUNCHES = 512;      // in-model stamps (tools/model_stamps.py): workgroups kept per launch, launches per dump
@@ -153,6 +154,7 @@ struct sta_handle {
     int lane = 0;       // 1 while dpt_impl enqueues on the context's side stream (launch_gemm then hands out the side lane's split-K scratch)
     // sta_reserve / sta_alloc_stats: device allocations (hipMalloc / hipFree / hipHostMalloc / stream and event creation count as
     // one each) and device-wide synchronisations the COMPUTE entry points made since sta_create - after sta_reserve neither moves
+    int tiny_tensors = 0;     // packed (MFMA-operand) weight tensors whose every value is below 2^-12: their fp16 planes are subnormal (sta_range_report adds them to counts[0])
     int64_t n_alloc = 0, n_devsync = 0;
     bool reserve_only = false;      // inside sta_reserve: plan_and_run sizes and allocates, launches nothing
 };
@@ -503,6 +505,7 @@ extern "C" int sta_range_report(sta_handle* h, unsigned long long counts[2], int
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(counts, h->range, 16, hipMemcpyDeviceToHost));
     if (reset) HIPCHK(hipMemset(h->range, 0, 16));
+    counts[0] += (unsigned long long)h->tiny_tensors;      // a property of the loaded weights: survives a reset
     return 0;
 }
 extern "C" int sta_num_expected_tensors(const sta_handle* h) { return h ? (int)h->slots.size() : -1; }
@@ -528,6 +531,17 @@ extern "C" int sta_load_tensor(sta_handle* h, const char* name, const void* host
     for (int i = 0; i < ndim; ++i) {
         REQUIRE(shape[i] == s.shape[i], "size mismatch for %s: dim %d is %lld, expected %lld", name, i, (long long)shape[i], (long long)s.shape[i]);
         n *= shape[i];
+    }
+    if (s.kind == SK_W_ID || s.kind == SK_W_CONV || s.kind == SK_W_CONVT) {
+        // the LOW end of the fp16 range: a weight is carried as hi = fp16(w), lo = fp16(w - hi), both with an absolute floor of 2^-25.
+        // Mixed-magnitude tensors do not care (the floor is 1e-6 of a typical 0.02 weight), but a tensor whose EVERY value is below
+        // 2^-12 would enter the MFMAs as subnormals with a few bits each - counted as a range event (reported, not silent) unless
+        // the tensor is all zeros.  (head.4, the one layer the outlier statistics push there, is fp32 and pre-scaled: sta_finalize_weights.)
+        const float* w = static_cast<const float*>(host_ptr);
+        float mx = 0.f;
+        for (int64_t i = 0; i < n; ++i) { const float a = fabsf(w[i]); mx = a > mx ? a : mx; }
+        if (!s.loaded_tiny && mx > 0.f && mx < 0x1p-12f) { s.loaded_tiny = true; h->tiny_tensors++; }
+        else if (s.loaded_tiny && !(mx > 0.f && mx < 0x1p-12f)) { s.loaded_tiny = false; h->tiny_tensors--; }
     }
     if (s.kind != SK_DROP) {
         REQUIRE(n <= h->stage_elems, "tensor %s too large for staging", name);
