@@ -1506,3 +1506,33 @@ def test_tiny_weight_tensor_is_reported(G):
     m._load_one(key, sd[key] * np.float32(1e-6))
     m._load_one(key, sd[key])
     assert m.range_report() == (0, 0)
+
+
+def test_fused_tail_implicit_gemm_form_matches_halo_form(G):
+    """The fused DPT tail exists on two kernels - the halo-tiled convolution (the product's choice wherever it is legal) and the
+    implicit-GEMM 192x128 tile (experiment switch 0 at >= 2M pixels; tools/ab_option.py 0 0 1) - both on transposed accumulators
+    with head.4 on the matrix pipe (head_epilogue_t).  The cost model leaves the second one unused in the product flow, so it is
+    exercised here: 8 pairs @512x384, outputs equal to the halo form's up to summation order, slot 0 against the reference golden."""
+    import numpy as np
+    import torch
+    from helpers import load_golden, rel_l2
+    from vista_slam_amd import _lib, weights as W
+    g, meta = load_golden("full_384x512_b1")
+    G.drop_models()
+    m = G.model("full", 1.0, DEFAULT, hooks=True)
+    sub, B = int(meta["sub"]), 8
+    im = W.synth_images(2, 384, 512, seed=43, tag=0)
+    extra = W.synth_images(2 * B, 384, 512, seed=43, tag=5)
+    a = torch.from_numpy(np.concatenate([im[:1], extra[:B - 1]])).cuda()
+    b = torch.from_numpy(np.concatenate([im[1:], extra[B:2 * B - 1]])).cuda()
+    outs = []
+    for sw in (0, 1):
+        _lib.check(m.lib.sta_debug_set_option(m._h, 0, sw))
+        main, supp = m.forward_pair(a, b)
+        torch.cuda.synchronize()
+        outs.append((main["pts3d_pred"].clone(), supp["conf"].clone()))
+    _lib.check(m.lib.sta_debug_set_option(m._h, 0, 0))
+    assert not torch.equal(outs[0][0], outs[1][0]), "the switch did not change the kernel"
+    assert rel_l2(outs[1][0].cpu().numpy(), outs[0][0].cpu().numpy()) < 1e-6 and rel_l2(outs[1][1].cpu().numpy(), outs[0][1].cpu().numpy()) < 1e-6
+    assert rel_l2(outs[1][0][:1].cpu().numpy()[:, ::sub, ::sub], g["main_pts3d"]) < TOL
+    assert m.range_report() == (0, 0)

@@ -240,7 +240,6 @@ __device__ __forceinline__ void gemm2_tail(const GemmParams& p, const int tb, ch
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     auto mma = [&](const Frag& f) {
         if constexpr (MX) {
-            typedef int int4v __attribute__((ext_vector_type(4)));
             typedef int int8v __attribute__((ext_vector_type(8)));
             union U8 { struct { uint4 x, y; } q; int8v v; } a8, b8;
 #pragma unroll
