@@ -11,6 +11,8 @@ from vista_slam_amd.sta_frontend import STAFrontend
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 if variant != 0:
     _lib.use_test_hooks()      # a forced tile family needs the test-hooks build; variant 0 profiles the PRODUCT library
+if os.environ.get("STA_AB_LIB"):      # profile ANOTHER build of the library (kernel-level A/B on one box: tools/r6/run_s.sh)
+    _lib._lib = _lib.load_other(os.environ["STA_AB_LIB"])
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 prec = sys.argv[3] if len(sys.argv) > 3 else "f16x3"
 m = STAFrontend(W.FULL, "cuda:0", precision=prec).load_procedural(seed=43)

@@ -11,8 +11,9 @@
 //  * LDS image of the halo: one 128-B row [hi32 | lo32] per halo pixel hp = hy * 34 + hx, 16-B chunk index XOR
 //    (hp >> 1) & 7 - the same involution as the GEMM tiles, keyed on the HALO pixel: a fragment read touches 32
 //    consecutive halo pixels of one halo row, i.e. 16 distinct hp mod 16 per ds_read_b128 lane group = all 64 banks once.
-//  * Two halo stages (channel block cb + 1 streams in, spread over the nine taps of cb) and two weight stages
-//    (tap t + 1 under tap t); one vmcnt(0) + barrier per K step; out-of-image halo pixels read the zero page.
+//  * Two halo stages (channel block cb + 1 streams in, spread over the K steps of cb) and two weight stages (step s + 1 under
+//    step s); one vmcnt(0) + barrier per K step; a K step is one tap (256-column tiles) or two (128-column tiles, round 6);
+//    out-of-image halo pixels read the zero page.
 //  * 16 waves (4 x 4), one workgroup per CU: 256 x 128 tile (wave 64 x 32) for Cout = 128 - its epilogue can be the fused DPT
 //    tail (EPI_HEAD) - and 256 x 256 (wave 64 x 64) for Cout = 256.  f16 / f16x3 / f16mx arithmetic as in gemm2.h.
 //  * Epilogue: the ordinary plane epilogue per 32-pixel row segment (bias, ReLU, residual planes), bounded to the image.
@@ -24,11 +25,16 @@
 
 template <bool SPLIT, int BM>
 constexpr int conv3h_halo_bytes() { return ((BM / 32 + 2) * C3H_PW * (SPLIT ? 128 : 64) + 1023) / 1024 * 1024; }
+// taps per K step (= per barrier): two for the 128-column tiles (a weight tile of one tap is only 16 KiB and carries 256 MFMA clocks per
+// wave - a barrier + a DMA round trip per tap is what the period of those kernels was made of), one for the 256-column tiles (two
+// 64-KiB weight stages would not fit next to the two halo stages)
+template <int BN>
+constexpr int conv3h_tps() { return BN == 128 ? 2 : 1; }
 template <bool SPLIT, int BM, int BN>
-constexpr int conv3h_smem_bytes() { return 2 * conv3h_halo_bytes<SPLIT, BM>() + 2 * BN * (SPLIT ? 128 : 64); }
+constexpr int conv3h_smem_bytes() { return 2 * conv3h_halo_bytes<SPLIT, BM>() + 2 * conv3h_tps<BN>() * BN * (SPLIT ? 128 : 64); }
 
-// (A 3-stage weight ring with counted vmcnt, an 8-wave 256 x 128 tile and Cout = 256 as two 128-column tiles were measured
-// and dropped: -0.3 %, equal, -4 %)
+// (A 3-stage weight ring with counted vmcnt, an 8-wave 256 x 128 tile, Cout = 256 as two 128-column tiles and a persistent tile loop
+// were measured and dropped: -0.3 %, equal, -4 %, equal; LABNOTES.md.)
 template <bool SPLIT, int EPI, int BM, int BN, int WAVES_M, int WAVES_N, bool MX>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3h_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -39,7 +45,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3h_kernel(const Gem
     constexpr int HALO = conv3h_halo_bytes<SPLIT, BM>(), B_TILE = BN * RB;
     constexpr int HPIX = (TR + 2) * C3H_PW;
     constexpr int NHS = (HPIX + RPS - 1) / RPS;            // 1-KiB DMA slots of one halo
-    constexpr int HPS = (NHS + 8) / 9;                     // halo slots issued per K step (the next halo streams in over the 9 taps), one per wave
+    constexpr int TPS = conv3h_tps<BN>();                  // taps per K step
+    // the next channel block's halo streams in over the K steps of this one, HPS slots per step, one per wave.  TPS == 1: nine steps.
+    // TPS == 2: a step may hold tap 8 of block cb AND tap 0 of cb + 1, so (a) the halo of cb + 1 has to be complete one step early and
+    // (b) stage (cb + 1) & 1 may only be overwritten by a step whose FIRST tap belongs to cb (no tap of that step reads cb - 1): the steps
+    // with first tap 0..7 of cb, of which every block has exactly four (taps 0,2,4,6 or 1,3,5,7)
+    constexpr int NISS = TPS == 1 ? 9 : 4;
+    constexpr int HPS = (NHS + NISS - 1) / NISS;
     constexpr int NSB = BN / RPS, SB = (NSB + NW - 1) / NW;
     static_assert((NW & (NW - 1)) == 0 && HPS <= NW && WM % 32 == 0 && WN % 32 == 0 && (!MX || SPLIT), "conv3h tile / wave mismatch");
     static_assert(EPI == EPI_F16 || EPI == EPI_HEAD, "conv3h: plane epilogue or the fused DPT tail");
@@ -99,15 +111,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3h_kernel(const Gem
     // byte offset (next tap: + cblocks K tiles; next channel block: back to tap 0, + 1 K tile) instead of a 64-bit multiply per step
     const size_t b_tap_bytes = (size_t)cblocks * b_kstride * 2, b_cb_bytes = b_kstride * 2;
     size_t b_off = 0;                                          // byte offset of the NEXT tile issue_b will be asked for
-    auto issue_b = [&](int /*cb*/, int tap, int stage) {
+    int b_tap = 0;                                             // ... and its tap (tiles are requested in K-loop order)
+    auto issue_b = [&](int slot) {                             // -> weight slot `slot` of 2 * TPS (stage * TPS + tap within the step)
         const char* base = reinterpret_cast<const char*>(p.B_hi) + b_off;
-        b_off = tap == 8 ? b_off - 8 * b_tap_bytes + b_cb_bytes : b_off + b_tap_bytes;
+        if (b_tap == 8) { b_off = b_off - 8 * b_tap_bytes + b_cb_bytes; b_tap = 0; } else { b_off += b_tap_bytes; ++b_tap; }
 #pragma unroll
         for (int s = 0; s < SB; ++s) {
             if (NSB % NW != 0 && wave + NW * s >= NSB) continue;
             unsigned o = b_src[s];
             asm volatile("" : "+v"(o));
-            glds16(base + o, sB + stage * B_TILE + (wave + NW * s) * 1024);
+            glds16(base + o, sB + slot * B_TILE + (wave + NW * s) * 1024);
         }
     };
     auto issue_halo = [&](int j, int cb, int stage) {          // halo slot j (RPS halo pixels) of channel block cb
@@ -129,7 +142,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3h_kernel(const Gem
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     for (int j = wave; j < NHS; j += NW) issue_halo(j, 0, 0);
-    issue_b(0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < TPS; ++u) if (u < nkt) issue_b(u);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (p.stamps) st1 = __builtin_amdgcn_s_memrealtime();
@@ -139,20 +153,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3h_kernel(const Gem
     // (every fragment read waited right in front of its MFMAs), in the kernels with no ReLU at all (head.0, the fused tail) too.
     auto k_loop = [&](auto relu_c) {
     constexpr bool RELU = decltype(relu_c)::value;
-    int cb = 0, tap = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1, hs = cb & 1;
-        int ncb = cb, ntap = tap + 1;
-        if (ntap == 9) { ntap = 0; ncb = cb + 1; }
-        if (kt + 1 < nkt) issue_b(ncb, ntap, cur ^ 1);
-        if (cb + 1 < cblocks) {                                // halo of the next channel block: HPS slots per tap, one per wave
-            const int q = (wave - tap * HPS) & (NW - 1);
-            const int j = tap * HPS + q;
-            if (q < HPS && j < NHS) issue_halo(j, cb + 1, hs ^ 1);
+    int cb = 0, tap = 0;                                       // first tap of the step
+    for (int kt = 0; kt < nkt; kt += TPS) {
+        const int cur = (kt / TPS) & 1;
+#pragma unroll
+        for (int u = 0; u < TPS; ++u) if (kt + TPS + u < nkt) issue_b((cur ^ 1) * TPS + u);
+        if (cb + 1 < cblocks && (TPS == 1 || tap < 8)) {       // halo of the next channel block: HPS slots per issuing step, one per wave
+            const int is = TPS == 1 ? tap : tap >> 1;
+            const int q = (wave - is * HPS) & (NW - 1);
+            const int j = is * HPS + q;
+            if (q < HPS && j < NHS) issue_halo(j, cb + 1, (cb & 1) ^ 1);
         }
+        auto do_tap = [&](int cb, int tap, int slot) {
+        const int hs = cb & 1;
         const int ky = tap / 3, kx = tap - ky * 3;
         const char* hA = sH + hs * HALO;
-        const char* bB = sB + cur * B_TILE;
+        const char* bB = sB + slot * B_TILE;
         int hp[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) hp[i] = (wm * MT + i + ky) * C3H_PW + l31 + kx;
@@ -253,9 +269,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3h_kernel(const Gem
                         acc[i][j] = TRN ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi[j], a_hi[i], acc[i][j], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
             }
         }
+        };      // do_tap
+#pragma unroll
+        for (int u = 0; u < TPS; ++u) {
+            if (u > 0 && kt + u >= nkt) break;
+            int c = cb, t = tap + u;
+            if (t >= 9) { t -= 9; ++c; }
+            do_tap(c, t, cur * TPS + u);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        tap = ntap; cb = ncb;
+        tap += TPS;
+        if (tap >= 9) { tap -= 9; ++cb; }
     }
     };
     if (EPI != EPI_HEAD && p.relu_in) k_loop(std::integral_constant<bool, true>{});
