@@ -10,7 +10,7 @@
  *           (vista_slam/slam.py:95-106).  Tensor names == reference state_dict keys.
  *   sta_encode        <- _encode_image(image, true_shape, normalize=False)
  *                        (sta_model.py:163-174, called from slam.py:144)
- *   sta_decode        <- _decode_stereo(feat1, feat2, pos1, pos2)
+ *   sta_decode        <- _decode_stereo(feat1, feat2, pos1, pos2)   (positions = the patch grid; sta_decode_pos: any positions)
  *                        (sta_model.py:177-244, called from slam.py:162)
  *   sta_head_pose     <- head_pose_s(tok[:,0,:])        (heads/pose_head.py:109-120, slam.py:165)
  *   sta_head_pts      <- head_pts(list14, true_shape)   (heads/dpt_head.py:34-66 +
@@ -206,6 +206,16 @@ STA_API int sta_encoder_norm(sta_handle* h, const float* feat_dev, int64_t rows,
  * last index has dec_norm applied (sta_model.py:241-242). */
 STA_API int sta_decode(sta_handle* h, const float* feat1, const float* feat2, int B, int hp, int wp,
                float* const* out1, float* const* out2, void* stream);
+
+/* _decode_stereo with CALLER positions (sta_model.py:177-244 hands pos1 / pos2 to every decoder block, whose attentions rotate
+ * q / k by them: sta_blocks.py:134-137,196-199): pos1 / pos2 are device int64 [B, N, 2] (y, x) as _encode_image returns them,
+ * but need not be the patch grid - a window of a larger grid, a permuted token order, repeated positions.  Values must lie in
+ * [-1, pos_max] (out-of-range values are clamped); the RoPE table grows to pos_max on first use.  N = tokens per view (both
+ * views: the two sides run as one batch).  Implementation: the QKV epilogues of the call rotate by the identity and one small kernel
+ * per Q / K buffer rotates it in place from the positions table - the grid form (sta_decode) stays the fast path, and with the patch
+ * grid's own positions the two agree to the rounding of one more fp16-plane split (~1e-7), not bit for bit. */
+STA_API int sta_decode_pos(sta_handle* h, const float* feat1, const float* feat2, const int64_t* pos1, const int64_t* pos2,
+                   int B, int N, int pos_max, float* const* out1, float* const* out2, void* stream);
 
 /* tok: B rows of dec_dim floats, consecutive rows `tok_stride` floats apart.
  * pose [B,16] row-major 4x4, conf [B]. */

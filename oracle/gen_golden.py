@@ -498,6 +498,58 @@ def gen_seq(name, cfg, H, W_, nkf, neighbor_edge_num, loop_edge_num, rel_pose_th
 # The checkpoint is loaded the way slam.py:97-100 loads it (torch.load(...)['model'], strict=True); every fixture carries the
 # fingerprint of the weights it was made with (vista_slam_amd.weights.state_dict_fingerprint), which the GPU test checks against the
 # file it is handed.
+def decpos_variants(pa, pb, hp, wp):
+    """The foreign-position sets of the `decpos_*` fixtures (integer arrays [B, N, 2], numpy or torch): what a caller other than
+    slam.py could hand to _decode_stereo - every one of them is rotated by as given in the reference (sta_blocks.py:134-137,196-199)."""
+    N = hp * wp
+    flip = pb[:, ::-1] if isinstance(pb, np.ndarray) else pb.flip(1)
+    other = None
+    for h2 in range(2, N):                      # another grid with the same token count (e.g. 3 x 4 -> 2 x 6)
+        if N % h2 == 0 and h2 != hp:
+            other = (h2, N // h2); break
+    out = {
+        "shift": (pa + np.array([2, 5]) if isinstance(pa, np.ndarray) else pa + torch.tensor([2, 5]), pb + (np.array([0, 3]) if isinstance(pb, np.ndarray) else torch.tensor([0, 3]))),   # windows of a larger grid
+        "flip": (pa, flip),                     # the second view's tokens carry the grid positions in reverse order
+    }
+    if other is not None:
+        y, x = np.divmod(np.arange(N), other[1])
+        g = np.stack([y, x], -1)[None].repeat(pa.shape[0], 0).astype(np.int64)
+        out["regrid"] = (pa, g if isinstance(pa, np.ndarray) else torch.from_numpy(g))
+    return out
+
+
+def gen_decpos(name, cfg, H, W_, B, tsub=1, seed=43, qk_gain=1.0):
+    """_decode_stereo (sta_model.py:177-244) with positions that are NOT the patch grid: encoder features of a procedural pair, then
+    the decoder under each set of decpos_variants.  Recorded: the positions (inputs) and, per set, the decoder outputs the heads read
+    (hook layers, pose token row included) of both sides."""
+    t0 = time.time()
+    sd = W.state_dict(cfg, seed=seed, qk_gain=qk_gain)
+    model = load_reference_model(cfg, sd)
+    imgs = W.synth_images(2 * B, H, W_, seed=seed, tag=0)
+    ts = torch.tensor([[H, W_]] * B)
+    fa, pa = model._encode_image(torch.from_numpy(imgs[:B].copy()), ts, normalize=False)
+    fb, pb = model._encode_image(torch.from_numpy(imgs[B:].copy()), ts, normalize=False)
+    hp, wp = H // cfg.patch_size, W_ // cfg.patch_size
+    res = {"enc_feat_a": fa.numpy(), "enc_feat_b": fb.numpy()} if tsub == 1 else {}     # (full size: the consumer encodes the procedural pair itself)
+    for tag, (qa, qb) in decpos_variants(pa, pb, hp, wp).items():
+        d1, d2 = model._decode_stereo(fa, fb, qa, qb)
+        res[f"{tag}_pos_a"] = qa.numpy().astype(np.int64); res[f"{tag}_pos_b"] = qb.numpy().astype(np.int64)
+        for hk in cfg.hooks[1:]:
+            res[f"{tag}_dec1_hook{hk - 1}"] = d1[hk - 1].numpy()[:, ::tsub].copy()
+            res[f"{tag}_dec2_hook{hk - 1}"] = d2[hk - 1].numpy()[:, ::tsub].copy()
+            res[f"{tag}_dec1_hook{hk - 1}_l2"] = np.sqrt((d1[hk - 1].double().numpy() ** 2).sum(axis=(1, 2)))
+    # the grid itself, for scale: how far the foreign sets move the output (a loader that ignored the positions would reproduce THIS)
+    d1, _ = model._decode_stereo(fa, fb, pa, pb)
+    res["grid_dec1_last"] = d1[cfg.hooks[-1] - 1].numpy()[:, ::tsub].copy()
+    meta = dict(H=H, W=W_, B=B, tsub=tsub, seed=seed, qk_gain=qk_gain)
+    res["meta_keys"] = np.array(list(meta.keys())); res["meta_vals"] = np.array([float(v) for v in meta.values()], dtype=np.float64)
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **{k: (v.astype(np.float32) if v.dtype == np.float64 and not k.startswith("meta") and not k.endswith("_l2") else v) for k, v in res.items()})
+    print(f"[golden] {name}: {os.path.getsize(path) / 1e6:.2f} MB in {time.time() - t0:.1f}s", flush=True)
+
+
+
 def load_checkpoint_sd(path):
     ck = torch.load(path, map_location="cpu", weights_only=False)
     sd = ck["model"] if isinstance(ck, dict) and "model" in ck else ck                # slam.py:97-100
@@ -675,9 +727,19 @@ SEQ_CASES = {
 }
 
 
+# _decode_stereo with foreign positions (round 6: sta_decode_pos)
+SEQ_CASES["decpos"] = [
+    dict(name="decpos_tiny_48x64_b2", cfg=W.TINY, H=48, W_=64, B=2, decpos=True),
+    dict(name="decpos_tiny_48x80_sharp", cfg=W.TINY, H=48, W_=80, B=1, qk_gain=4.0, decpos=True),
+    dict(name="decpos_full_224_b1", cfg=W.FULL, H=224, W_=224, B=1, tsub=7, decpos=True),
+]
+
+
 def run_any(c):
     """One case of CASES (forward goldens) or SEQ_CASES (keyframe sequences): used by check_oracle_vs_ref.py."""
-    if "nkf" in c:
+    if c.get("decpos"):
+        gen_decpos(**{k: v for k, v in c.items() if k != "decpos"})
+    elif "nkf" in c:
         gen_seq(**c)
     else:
         run_case(**c)
@@ -710,7 +772,7 @@ if __name__ == "__main__":
             gen_f2("f2_tiny_80x48_portrait", W.TINY, 80, 48, nview=4, tag=22)
         elif s in SEQ_CASES:
             for c in SEQ_CASES[s]:
-                gen_seq(**c)
+                run_any(c)
         else:
             for c in CASES[s]:
                 run_case(**c)

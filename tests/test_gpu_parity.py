@@ -1219,9 +1219,10 @@ def test_checkpoint_with_fp16_tensors_and_shuffled_keys(G, tmp_path):
 
 
 def test_decode_stereo_positions_are_checked(G):
-    """VERDICT r4 'missing' item 5: `_decode_stereo` does not rotate by arbitrary positions (RoPE is fused into the QKV epilogues on
-    the patch grid).  That is now ASSERTED instead of assumed: the tensors `_encode_image` returned pass through a provenance tag
-    (no device sync), a foreign tensor with the same values is accepted after a comparison, any other positions are refused."""
+    """`_decode_stereo` and its positions argument.  RoPE is fused into the QKV epilogues and evaluated on the patch grid, so the shim
+    has to KNOW whether a positions tensor is the grid: the tensors `_encode_image` returned pass through a provenance tag (no device
+    sync), a foreign tensor with the same values is accepted after one comparison (cached), and since round 6 any OTHER positions
+    are served by sta_decode_pos (the reference rotates by whatever it is handed; parity: test_decode_stereo_foreign_positions_*)."""
     import torch
     from vista_slam_amd import weights as W
     m = G.model("tiny", 1.0, DEFAULT)
@@ -1233,28 +1234,82 @@ def test_decode_stereo_positions_are_checked(G):
     got1, got2 = m._decode_stereo(fa, fb, pa.clone().cpu(), pb.clone())          # foreign tensors (no tag, one on the CPU): same grid -> same result
     torch.cuda.synchronize()
     assert torch.equal(ref1[-1], got1[-1]) and torch.equal(ref2[-1], got2[-1])
-    with pytest.raises(NotImplementedError, match="patch grid"):
-        m._decode_stereo(fa, fb, pa + 1, pb)                                       # shifted positions: the reference would rotate by them
-    with pytest.raises(NotImplementedError, match="patch grid"):
-        m._decode_stereo(fa, fb, pa, pb.flip(1))                                   # permuted positions
+    sh1, _ = m._decode_stereo(fa, fb, pa + 1, pb)                                  # shifted positions: rotated by as given (sta_decode_pos)
+    assert not torch.equal(sh1[-1], ref1[-1])
     with pytest.raises(AssertionError):
         m._decode_stereo(fa, fb, pa, pb[:, :6])                                    # another token count
+    with pytest.raises(ValueError, match="below -1"):
+        m._decode_stereo(fa, fb, pa - 2, pb)
+    # the table form with the GRID's own positions = the grid form up to one more fp16-plane split of q / k (same angles, same table)
+    import ctypes as C
+    from vista_slam_amd import _lib
+    L = m.cfg.dec_depth + 1
+    o1 = [torch.empty(1, 13, m.cfg.dec_embed_dim, device="cuda") for _ in range(L)]
+    o2 = [torch.empty(1, 13, m.cfg.dec_embed_dim, device="cuda") for _ in range(L)]
+    p1 = (C.c_void_p * L)(*[t.data_ptr() for t in o1]); p2 = (C.c_void_p * L)(*[t.data_ptr() for t in o2])
+    qa, qb = pa.contiguous(), pb.contiguous()
+    _lib.check(m.lib.sta_decode_pos(m._h, fa.data_ptr(), fb.data_ptr(), qa.data_ptr(), qb.data_ptr(), 1, 12, 3, p1, p2, m._stream()))
+    torch.cuda.synchronize()
+    for a, b in zip(o1 + o2, list(ref1) + list(ref2)):
+        assert float((a - b).norm() / b.norm()) < 2e-6 and not torch.equal(a, torch.zeros_like(a))
     # the provenance tag carries the tensor's version counter - an IN-PLACE edit of a tagged tensor keeps the Python
-    # attribute but no longer passes as the patch grid
+    # attribute but no longer passes as the patch grid: it is classified by its VALUES (here: a shifted window -> the table form)
     pc = m._encode_image(imgs[:1], None, normalize=False)[1]
     pc.add_(1)
-    assert getattr(pc, "_sta_grid", None) is not None
-    with pytest.raises(NotImplementedError, match="patch grid"):
-        m._decode_stereo(fa, fb, pc, pb)
+    assert getattr(pc, "_sta_grid", None) is not None and m._grid_from_pos(pc, 12) == (None, None, 4)
+    ed1, _ = m._decode_stereo(fa, fb, pc, pb)
+    torch.cuda.synchronize()
+    assert torch.equal(ed1[-1], sh1[-1])
     # ... and a verified foreign tensor is compared with the grid ONCE (cached by address / version / shape), not per call
     foreign = pa.clone()
     m._decode_stereo(fa, fb, foreign, pb)
     n0 = len(m._pos_verified)
     m._decode_stereo(fa, fb, foreign, pb)
-    assert len(m._pos_verified) == n0 and any(v[2] is foreign for v in m._pos_verified.values())
-    foreign.add_(1)                                                                # edited after it was verified: checked again, refused
-    with pytest.raises(NotImplementedError, match="patch grid"):
-        m._decode_stereo(fa, fb, foreign, pb)
+    assert len(m._pos_verified) == n0 and any(v[3] is foreign for v in m._pos_verified.values())
+    foreign.add_(1)                                                                # edited after it was verified: classified again
+    assert m._grid_from_pos(foreign, 12) == (None, None, 4)
+
+
+@pytest.mark.parametrize("prec", [DEFAULT, "f16x3"])
+@pytest.mark.parametrize("case", ["decpos_tiny_48x64_b2", "decpos_tiny_48x80_sharp", "decpos_full_224_b1"])
+def test_decode_stereo_foreign_positions_vs_reference_golden(G, case, prec):
+    """VERDICT r5 'missing' item 4: `_decode_stereo` with positions other than the patch grid (`sta_blocks.py:134-137,196-199` rotate
+    by whatever they are handed).  Fixtures from the reference (`gen_golden.gen_decpos`): windows of a larger grid (both views shifted
+    differently), the second view's positions in reverse token order, another grid with the same token count; the HIP path
+    (`sta_decode_pos` through the shim) against them on every hook layer of both sides, rel-L2 and max norm."""
+    import numpy as np
+    import torch
+    from helpers import load_golden, rel_l2, max_rel
+    from vista_slam_amd import weights as W
+    g, meta = load_golden(case)
+    full = case.startswith("decpos_full")
+    if full:
+        G.drop_models()
+    cfg = W.FULL if full else W.TINY
+    m = G.model("full" if full else "tiny", float(meta["qk_gain"]), prec, seed=int(meta["seed"]))
+    m.range_report(reset=True)
+    H, Wd, B, tsub = int(meta["H"]), int(meta["W"]), int(meta["B"]), int(meta["tsub"])
+    imgs = torch.from_numpy(W.synth_images(2 * B, H, Wd, seed=int(meta["seed"]), tag=0)).cuda()
+    fa, pa = m._encode_image(imgs[:B], None, normalize=False)
+    fb, pb = m._encode_image(imgs[B:], None, normalize=False)
+    if not full:        # tiny: the decoder alone, on the reference's own encoder features
+        assert rel_l2(fa.cpu().numpy(), g["enc_feat_a"]) < TOL
+        fa, fb = torch.from_numpy(g["enc_feat_a"]).cuda(), torch.from_numpy(g["enc_feat_b"]).cuda()
+    last = cfg.hooks[-1] - 1
+    errs = {}
+    for tag in ("shift", "flip", "regrid"):
+        qa, qb = torch.from_numpy(g[f"{tag}_pos_a"]), torch.from_numpy(g[f"{tag}_pos_b"]).cuda()      # one on the CPU, one on the device
+        d1, d2 = m._decode_stereo(fa, fb, qa, qb)
+        torch.cuda.synchronize()
+        for hk in cfg.hooks[1:]:
+            for side, d in (("dec1", d1), ("dec2", d2)):
+                got, want = d[hk - 1].cpu().numpy()[:, ::tsub], g[f"{tag}_{side}_hook{hk - 1}"]
+                errs[f"{tag}_{side}_hook{hk - 1}"] = max(rel_l2(got, want), max_rel(got, want))
+        assert rel_l2(g["grid_dec1_last"], g[f"{tag}_dec1_hook{last}"]) > 3 * TOL, tag     # the positions matter (least at full depth with default-scale weights: 4e-3 ... 3e-2)
+    print(case, prec, "worst", max(errs.values()))
+    bad = {k: v for k, v in errs.items() if v > TOL}
+    assert not bad, bad
+    assert tuple(m.range_report(reset=True)) == (0, 0)
 
 
 def test_reserve_then_no_allocation_and_no_device_sync(G):

@@ -203,3 +203,26 @@ def test_keyframe_sequence_oracle_vs_reference_golden(case):
     worst = compare_seq_edges(edges, g, meta, tol=5e-5)      # (scale edges: judged against their conditioning, helpers.compare_seq_edges)
     assert any(e["scales"][0] is not None or e["scales"][1] is not None for e in edges), "fixture holds no scale edge"
     assert worst["pose"] < TOL
+
+
+@pytest.mark.parametrize("case", ["decpos_tiny_48x64_b2", "decpos_tiny_48x80_sharp"])
+def test_decode_stereo_foreign_positions_oracle_vs_reference_golden(case):
+    """_decode_stereo with positions that are not the patch grid (shifted windows, reversed order, another grid of the same token
+    count): the reference rotates q / k by whatever it is handed (sta_blocks.py:134-137,196-199) - fixtures from the reference
+    (oracle/gen_golden.py gen_decpos), the oracle's decode_stereo on the recorded encoder features and positions."""
+    g, meta = load_golden(case)
+    sd = W.state_dict(W.TINY, seed=int(meta["seed"]), qk_gain=float(meta["qk_gain"]))
+    tol = TOL_SHARP if float(meta["qk_gain"]) != 1.0 else TOL
+    tags = sorted({k.split("_pos_a")[0] for k in g if k.endswith("_pos_a")})
+    assert tags == ["flip", "regrid", "shift"], tags
+    last = W.TINY.hooks[-1] - 1
+    for tag in tags:
+        d1, d2 = O.decode_stereo(W.TINY, sd, g["enc_feat_a"], g["enc_feat_b"], g[f"{tag}_pos_a"], g[f"{tag}_pos_b"])
+        errs = {}
+        for hk in W.TINY.hooks[1:]:
+            errs[f"dec1_hook{hk - 1}"] = rel_l2(d1[hk - 1], g[f"{tag}_dec1_hook{hk - 1}"])
+            errs[f"dec2_hook{hk - 1}"] = rel_l2(d2[hk - 1], g[f"{tag}_dec2_hook{hk - 1}"])
+        bad = {k: v for k, v in errs.items() if v > tol}
+        assert not bad, (tag, bad)
+        # the positions matter: the same features under the patch grid give a visibly different decoder output
+        assert rel_l2(g["grid_dec1_last"], g[f"{tag}_dec1_hook{last}"]) > 30 * tol, tag

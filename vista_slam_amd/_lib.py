@@ -49,6 +49,7 @@ SIGNATURES = {
     "sta_finalize_weights": (_i, [_vp]),
     "sta_encode": (_i, [_vp, _fp, _i, _i, _i, _fp, _vp]),
     "sta_decode": (_i, [_vp, _fp, _fp, _i, _i, _i, C.POINTER(_vp), C.POINTER(_vp), _vp]),
+    "sta_decode_pos": (_i, [_vp, _fp, _fp, _vp, _vp, _i, _i, _i, C.POINTER(_vp), C.POINTER(_vp), _vp]),
     "sta_head_pose": (_i, [_vp, _fp, _i, _i64, _fp, _fp, _vp]),
     "sta_head_pts": (_i, [_vp, _fp, _i64, _fp, _i64, _fp, _i64, _fp, _i64, _i, _i, _i, _fp, _fp, _vp]),
     "sta_forward_pair": (_i, [_vp, _fp, _fp, _i, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),

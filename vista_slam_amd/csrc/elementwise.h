@@ -287,6 +287,46 @@ __global__ void emit_tokens_kernel(const float* x, int s0, int B, int N, int D, 
     }
 }
 
+// sta_decode_pos: the two views' int64 [B, N, 2] (y, x) positions -> one int32 table [2B][N][2], clamped to the RoPE table's range
+// [-1, pos_max] (the shim passes the true maximum, so nothing is clamped on that path); the tail of the grid fills `ident`, a cos / sin
+// table whose every row is the identity rotation (1, 0): the QKV epilogues of the call rotate by it, i.e. not at all
+__global__ __launch_bounds__(256) void rope_pos_table_kernel(const int64_t* pos1, const int64_t* pos2, int64_t n, int pos_max, int* out,
+                                                             float2* ident, int64_t n_ident) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < 2 * n) {
+        int64_t v = i < n ? pos1[i] : pos2[i - n];
+        v = v < -1 ? -1 : (v > pos_max ? pos_max : v);
+        out[i] = (int)v;
+    } else if (i - 2 * n < n_ident) ident[i - 2 * n] = make_float2(1.f, 0.f);
+}
+
+// sta_decode_pos: 2-D RoPE (pos_embed.py:169-185; curope kernels.cu:17-82) applied IN PLACE to a head-major Q or K buffer
+// [S][heads][npad][64] of fp16 planes, with the position of every token looked up in `pos` ([S][ntok][2]; token index ntok = the pose
+// token, position -1).  One thread per rotation pair (d, d + 16) of the y half (d < 32) or the x half of a head.  The general form of
+// what the QKV epilogue does on the patch grid - off the throughput path on purpose: the epilogue of the grid form stays free of a
+// per-row table lookup (a first version with the lookup inside the epilogue put the 192x128 QKV kernel on 256 B of scratch: x0.6).
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void rope_planes_kernel(f16* hi, f16* lo, int S, int heads, int npad, int ntok, const int* pos,
+                                                          const float* tab, unsigned long long* rng) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)S * heads * (ntok + 1) * 32;
+    if (i >= total) return;
+    const int j = (int)(i & 31), xp = j >> 4, f = j & 15;
+    int64_t r = i >> 5;
+    const int t = (int)(r % (ntok + 1)); r /= ntok + 1;
+    const int hd = (int)(r % heads), s = (int)(r / heads);
+    const int ps = t < ntok ? pos[((int64_t)s * ntok + t) * 2 + xp] : -1;
+    const float2 cs = *reinterpret_cast<const float2*>(tab + ((size_t)(ps + 1) * 16 + f) * 2);
+    const int64_t o = (((int64_t)s * heads + hd) * npad + t) * 64 + xp * 32 + f;
+    float v0 = (float)hi[o], v1 = (float)hi[o + 16];
+    if (SPLIT) { v0 += (float)lo[o]; v1 += (float)lo[o + 16]; }
+    const float r0 = v0 * cs.x - v1 * cs.y, r1 = v1 * cs.x + v0 * cs.y;
+    RangeAcc ra;
+    if (SPLIT) { split_f16(r0, hi[o], lo[o], ra); split_f16(r1, hi[o + 16], lo[o + 16], ra); }
+    else { hi[o] = to_f16_sat(r0, ra); hi[o + 16] = to_f16_sat(r1, ra); }
+    ra.flush(rng);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Bilinear x2 upsample, align_corners=True (dpt_block.py:215-216,320), NHWC fp16 planes.
 // Output may be cropped to (Hc,Wc) <= (2Hi,2Wi) (dpt_head.py:58); interpolation ratios always use

@@ -136,6 +136,9 @@ struct sta_handle {
     int gemm_variant = 0;   // tests / tools: 0 auto, 1..4 forced GEMM families, 8 = conv3h wherever legal, 9 = auto WITHOUT conv3h (A/B)
     // rope table
     float* rope_tab = nullptr; int rope_P = 0;
+    // sta_decode_pos, for the duration of the call: the decoder's QKV epilogues rotate by the identity table and rope_planes_kernel
+    // rotates Q / K by the caller's positions afterwards (decode_impl)
+    bool rope_foreign = false; const int* rope_pos = nullptr; const float* rope_ident = nullptr;
     // timing
     bool timing = false; hipEvent_t ev[5]; bool ev_ok = false;
     // per-launch timing of the dominant kernel (gemm_kernel<*, A_DENSE, EPI_F32>) for the roofline report
@@ -669,6 +672,39 @@ extern "C" int sta_decode(sta_handle* h, const float* feat1, const float* feat2,
     return plan_and_run(h, st, [&](Bump& ws) {
         float* x = (float*)ws.take(xbytes);
         return decode_impl(h, ws, feat1, feat2, B, hp, wp, x, out1, out2, true, st);
+    });
+}
+
+// _decode_stereo with positions that are NOT the patch grid (a crop of a larger grid, a permuted token order): the reference rotates
+// q / k by whatever positions it is handed (sta_blocks.py:134-137 self-attention, :196-199 cross-attention: q by the own side's
+// positions, k by the other side's).  The positions become a [2B][N][2] int32 table in the workspace and every QKV epilogue of the
+// call rotates by the IDENTITY (a table of (1, 0) rows), after which rope_planes_kernel rotates the Q / K buffers in place, row by row from
+// that table (decode_impl) - the throughput form's epilogues stay untouched.
+extern "C" int sta_decode_pos(sta_handle* h, const float* feat1, const float* feat2, const int64_t* pos1, const int64_t* pos2,
+                              int B, int N, int pos_max, float* const* out1, float* const* out2, void* stream) {
+    REQUIRE(h, "null handle");
+    DEV_SCOPE(h->device);
+    CHK(check_ready(h, B, 16, 16));
+    REQUIRE(feat1 && feat2 && pos1 && pos2, "null device pointer");
+    REQUIRE(N > 0 && pos_max >= 0 && pos_max < (1 << 20), "bad argument (N %d, pos_max %d)", N, pos_max);
+    hipStream_t st = (hipStream_t)stream;
+    CHK(ensure_rope(h, pos_max + 1));
+    const int D = h->cfg.dec_embed_dim;
+    const int64_t xbytes = (int64_t)2 * B * (N + 1) * D * 4;
+    struct Scope { sta_handle* h; ~Scope() { h->rope_foreign = false; h->rope_pos = nullptr; h->rope_ident = nullptr; } } scope{h};
+    h->rope_foreign = true;
+    return plan_and_run(h, st, [&](Bump& ws) {
+        float* x = (float*)ws.take(xbytes);
+        int* rp = (int*)ws.take((int64_t)2 * B * N * 2 * 4);
+        const int64_t n_ident = (int64_t)(N + 2) * 16;            // the grid form of the call is 1 x N: table rows 0 .. N + 1
+        float2* ident = (float2*)ws.take(n_ident * 8);
+        if (!h->dry) {
+            const int64_t n = (int64_t)B * N * 2;
+            hipLaunchKernelGGL(rope_pos_table_kernel, dim3((unsigned)((2 * n + n_ident + 255) / 256)), dim3(256), 0, st, pos1, pos2, n, pos_max, rp, ident, n_ident);
+            HIPCHK(hipGetLastError());
+            h->rope_pos = rp; h->rope_ident = (const float*)ident;
+        }
+        return decode_impl(h, ws, feat1, feat2, B, 1, N, x, out1, out2, true, st);
     });
 }
 

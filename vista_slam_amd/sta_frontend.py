@@ -212,33 +212,39 @@ class STAFrontend:
         return feat, self._positions(B, hp, wp)
 
     def _grid_from_pos(self, pos: torch.Tensor, N: int):
-        """The (hp, wp) patch grid of a positions tensor - and the CHECK that it is the patch grid.  The reference rotates q / k by
-        whatever positions it is handed (sta_blocks.py:134-137,196-199); here RoPE is fused into the QKV epilogues and evaluated
-        on the (y, x) grid itself, so other positions are not served: tensors this frontend produced (what slam.py:144 stores and
-        feeds back at :162) carry a provenance tag and cost nothing; a foreign tensor is compared with the grid (one D2H sync) and
-        refused loudly if it differs."""
+        """Classify a positions tensor: (hp, wp, None) when it IS the (y, x) patch grid of an hp x wp frame - RoPE is then evaluated on
+        the grid inside the QKV epilogues (sta_decode) -, (None, None, pos_max) for any other positions - the reference rotates q / k
+        by whatever it is handed (sta_blocks.py:134-137,196-199), served by sta_decode_pos, which looks every row's position up in a
+        table.  Tensors this frontend produced (what slam.py:144 stores and feeds back at :162) carry a provenance tag and cost
+        nothing; a foreign tensor is compared with the grid ONCE (two device syncs) and the verdict is cached."""
         g = getattr(pos, "_sta_grid", None)
         if g is not None and g[0] * g[1] == N and tuple(pos.shape[1:]) == (N, 2) and g[2] == pos._version:
-            return g[0], g[1]
+            return g[0], g[1], None
         assert pos.dim() == 3 and tuple(pos.shape[1:]) == (N, 2), f"positions must be [B, {N}, 2] (got {tuple(pos.shape)})"
         # a foreign tensor (the tag does not survive .to() / .clone() / indexing / a save-load round trip) is verified ONCE: the
-        # verdict is cached by (storage address, version counter, shape), so the two device syncs below are paid per tensor, not
+        # verdict is cached by (storage address, version counter, shape), so the device syncs below are paid per tensor, not
         # per _decode_stereo call - the zero-edit SLAM path feeds the same cached positions back for every edge of a keyframe
         key = (pos.data_ptr(), pos._version, tuple(pos.shape), str(pos.device))
         hit = self._pos_verified.get(key)
         if hit is not None:
-            return hit[0], hit[1]
+            return hit[0], hit[1], hit[2]
+        assert not pos.dtype.is_floating_point, "positions are integer (y, x) coordinates (PositionGetter, sta_blocks.py:241-247)"
         mx = pos[0].max(dim=0).values.tolist()
         hp, wp = int(mx[0]) + 1, int(mx[1]) + 1
         ok = hp * wp == N and bool(torch.equal(pos.to(self.device, torch.int64), self._positions(pos.shape[0], hp, wp)))
-        if not ok:
-            raise NotImplementedError("positions other than the (y, x) patch grid of the frame are not served: RoPE is fused into the "
-                                      "QKV epilogues and evaluated on the grid itself (INTEGRATION.md section 4)")
+        if ok:
+            verdict = (hp, wp, None)
+        else:
+            lo, hi = int(pos.min()), int(pos.max())
+            if lo < -1:
+                raise ValueError(f"positions below -1 ({lo}) are not served (-1 is the pose token's position; the reference's python RoPE "
+                                 "indexes its cos / sin tables with the position)")
+            verdict = (None, None, max(hi, 0))
         if len(self._pos_verified) >= 4096:
             self._pos_verified.clear()
         # (the entry holds a reference to the tensor: its address cannot be handed to another tensor while the entry lives)
-        self._pos_verified[key] = (hp, wp, pos)
-        return hp, wp
+        self._pos_verified[key] = verdict + (pos,)
+        return verdict
 
     def _decode_stereo(self, feat1: torch.Tensor, feat2: torch.Tensor, pose1: torch.Tensor, pose2: torch.Tensor,
                        layers: Sequence[int] | None = None):
@@ -253,8 +259,9 @@ class STAFrontend:
         assert feat2.shape[1] == N and feat2.shape[0] == B, \
             f"both views must have the same token grid (got {tuple(feat1.shape)} and {tuple(feat2.shape)})"
         assert feat2.shape == feat1.shape and E == self.cfg.enc_embed_dim
-        hp, wp = self._grid_from_pos(pose1, N)
-        assert self._grid_from_pos(pose2, N) == (hp, wp), "the two views' positions describe different patch grids"
+        g1, g2 = self._grid_from_pos(pose1, N), self._grid_from_pos(pose2, N)
+        assert pose1.shape[0] == B and pose2.shape[0] == B, "one positions row per batch entry"
+        on_grid = g1[2] is None and g2[2] is None and g1[:2] == g2[:2]
         L = self.cfg.dec_depth + 1
         want = range(L) if layers is None else layers
         D = self.cfg.dec_embed_dim
@@ -267,7 +274,14 @@ class STAFrontend:
             out2[i] = torch.empty(B, N + 1, D, device=self.device, dtype=torch.float32)
             p1[i] = out1[i].data_ptr()
             p2[i] = out2[i].data_ptr()
-        _lib.check(self.lib.sta_decode(self._h, feat1.data_ptr(), feat2.data_ptr(), B, hp, wp, p1, p2, self._stream()))
+        if on_grid:
+            _lib.check(self.lib.sta_decode(self._h, feat1.data_ptr(), feat2.data_ptr(), B, g1[0], g1[1], p1, p2, self._stream()))
+        else:       # any other positions (a window of a larger grid, a permuted order, two different grids of equal token count)
+            q1 = pose1.to(self.device, torch.int64).contiguous()
+            q2 = pose2.to(self.device, torch.int64).contiguous()
+            pos_max = max(g[2] if g[2] is not None else max(g[0], g[1]) - 1 for g in (g1, g2))
+            _lib.check(self.lib.sta_decode_pos(self._h, feat1.data_ptr(), feat2.data_ptr(), q1.data_ptr(), q2.data_ptr(),
+                                               B, N, pos_max, p1, p2, self._stream()))
         return out1, out2
 
     def head_pose_s(self, pose_token: torch.Tensor):
