@@ -140,7 +140,8 @@ STA_API int sta_set_deterministic(sta_handle* h, int on);
  * allocations, frees and stream / event creations, out[1] = device-wide synchronisations the compute entry points have made
  * since sta_create (weight loading, sta_range_report, sta_destroy and the timing tools are not compute entry points).  Not covered
  * (their sizes depend on other arguments): sta_preprocess_frame (tables per source geometry: the first frame of a geometry
- * allocates and synchronises), sta_world_pointcloud (workspace per view count). */
+ * allocates and synchronises), sta_world_pointcloud (workspace per view count), sta_decode_pos (its RoPE table grows with pos_max and
+ * its plan holds the positions table on top of sta_decode's). */
 STA_API int sta_reserve(sta_handle* h, int B, int H, int W, int max_edges, void* const* streams, int n_streams);
 STA_API int sta_alloc_stats(const sta_handle* h, int64_t out[2]);
 
